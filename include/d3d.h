@@ -1,0 +1,138 @@
+/*
+ * d3d.h -- C ABI of libd3d_hip.so, the MI355X (gfx950) engine for Diff3DHPE's DDIM sampling hot path.
+ *
+ * The reference (csiro-icvg/Diff3DHPE) is pure Python and has no FFI/plugin interface; its boundary for this
+ * path is the Python object protocol of two classes.  Each entry point below names the reference code it
+ * replaces (paths relative to the reference root):
+ *   DIFF = common/conditional_diffusion_ddim_normal_directPredict_variableLoss_both_crossFrames.py
+ *   DIFF-S2F = common/conditional_diffusion_s2f_ddim_normal_directPredict_variableLoss_both_crossFrames.py
+ *   S2S  = common/nets/model_conditional_diffusion_mixste_s2s_grand_linLift.py
+ *   S2F  = common/nets/model_conditional_diffusion_mixste_s2f_grand_linLift.py
+ *   LOSS = common/loss.py,  RUN = run_conditionalDiffusionDDIM3dhpeNormalDirectPredictVariableLoss.py
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "dev" is a device (HBM) pointer owned by the caller;
+ *     "host" pointers are ordinary host memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - every function returns 0 on success, a negative D3D_E* code on failure; d3d_last_error() gives the message
+ *     (thread-local).  No exception crosses the ABI.  Nothing here falls back to a CPU implementation: without a
+ *     HIP device the compute entry points fail with D3D_EHIP.
+ *   - one engine per device; an engine is not thread-safe, distinct engines are independent.
+ *   - tensors are row-major fp32: x2d (B,T,J,in_chans), y / x0 / out (B,T,J,3) [(B,1,J,3) for seq2frame].
+ */
+#ifndef D3D_H_
+#define D3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3D_OK 0
+#define D3D_EINVAL (-1)   /* bad argument / shape                        */
+#define D3D_ESTATE (-2)   /* call order (weights not committed, ...)     */
+#define D3D_EHIP (-3)     /* HIP runtime error or no device              */
+#define D3D_ENOMEM (-4)   /* workspace too small                         */
+#define D3D_EUNSUP (-5)   /* configuration outside what the kernels support */
+
+#define D3D_PREC_FP32 0     /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 everywhere (parity mode) */
+#define D3D_PREC_F16X3 1    /* fp32-accurate GEMMs from 3 fp16 MFMAs on hi/lo operand splits      */
+#define D3D_PREC_BF16 2     /* bf16 MFMA operands, fp32 accumulate / residual / LN / softmax       */
+
+typedef struct d3d_engine d3d_engine;
+
+/* Shape-defining constructor arguments of the denoiser (S2S:140-142 / S2F ctor; runner passes them at RUN:178-180). */
+typedef struct d3d_config {
+  int32_t num_frame;     /* T  */
+  int32_t num_joints;    /* J  */
+  int32_t in_chans;      /* 2  */
+  int32_t embed_dim;     /* D  */
+  int32_t depth;         /* number of (spatial, temporal) block pairs */
+  int32_t num_heads;     /* H  */
+  int32_t mlp_hidden;    /* int(D * mlp_ratio) */
+  int32_t with_time_emb; /* 0/1: 0 removes every time_mlp (S2S:163-177,104-107) */
+  int32_t seq2frame;     /* 0 = ...S2S..., 1 = ...S2F... (LOADNET:5-10) */
+  int32_t precision;     /* D3D_PREC_* */
+} d3d_config;
+
+const char* d3d_last_error(void);
+int d3d_version(void);
+
+/* ---- construction: replaces HPE_model(name)(**kw) + GaussianDiffusion(model=...) (RUN:176-189) ------------------- */
+int d3d_engine_create(const d3d_config* cfg, d3d_engine** out);
+void d3d_engine_destroy(d3d_engine* e);
+
+/* Number of weight tensors the engine expects, and the i-th expected name / element count (reference state_dict keys
+ * without the "model." prefix, e.g. "STEblocks.3.attn.qkv.weight"; S2S:160-220, S2F:216-218). */
+int d3d_engine_num_weights(const d3d_engine* e);
+int d3d_engine_weight_info(const d3d_engine* e, int i, const char** name, int64_t* numel);
+
+/* Copy one fp32 tensor (host memory, torch layout) into the engine; replaces load_state_dict (RUN:226-235). */
+int d3d_engine_set_weight(d3d_engine* e, const char* name, const float* host, int64_t numel);
+/* Optional: the (D/2,) frequency table of SinusoidalPosEmb (S2S:29-36) as the host framework computes it; without it
+ * the engine uses exp() in double rounded to fp32 (differs from torch's expf in ~1 of 256 entries by 1 ulp). */
+int d3d_engine_set_time_freqs(d3d_engine* e, const float* host, int32_t n);
+/* Verify every tensor was supplied, upload + repack to kernel layouts.  Must precede any compute call. */
+int d3d_engine_commit_weights(d3d_engine* e);
+
+/* Diffusion constants: fp32 buffers `alphas_cumprod` and `sqrt_one_minus_alphas_cumprod` (num_timesteps,) as registered
+ * at DIFF:151-161, plus sampling_timesteps / ddim_sampling_eta / clip_denoised (DIFF:100-112).  Builds the integer DDIM
+ * schedule (DIFF:270-273) and the per-step time-embedding table (S2S:169-174,104-107).  Weights must be committed. */
+int d3d_engine_set_schedule(d3d_engine* e, int32_t num_timesteps, const float* alphas_cumprod_host,
+                            const float* sqrt_one_minus_alphas_cumprod_host, int32_t sampling_timesteps, float eta,
+                            int32_t clip_denoised, void* stream);
+
+/* Host-only, bit-exact restatement of `torch.linspace(-1, N-1, S+1).int()` reversed (DIFF:270-272): writes S+1 values. */
+int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out);
+
+/* Bytes of device scratch the compute calls need for a batch of B sequences. */
+size_t d3d_workspace_bytes(const d3d_engine* e, int32_t B);
+
+/* ---- compute: all asynchronous on `stream` ------------------------------------------------------------------------ */
+
+/* forward_denoise (S2S:249-257 / S2F:253-266) on cat([x2d, y], -1) (DIFF:255).  times_dev: n_times fp32 timesteps on
+ * the device, n_times == 1 (broadcast, the sampling case DIFF:254) or == B (per-row, the p_losses case DIFF:392-408).
+ * Ignored when with_time_emb == 0.  y is (B,T,J,3), or (B,1,J,3) for seq2frame (DIFF-S2F:281 repeat is done in-kernel).
+ * x0 receives the raw network output (no clamp). */
+int d3d_denoise(d3d_engine* e, const float* x2d_dev, const float* y_dev, const float* times_dev, int32_t n_times,
+                float* x0_dev, int32_t B, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ddim_sample_loop (DIFF:262-300; DIFF-S2F:263-300).  init_noise replaces torch.randn(target_shape) (DIFF:275);
+ * step_noise_dev (nullable; required when eta != 0) is (S, B,T',J,3): the per-step randn_like draws (DIFF:293).
+ * traj_rev_dev / traj_x0_dev (nullable) receive x_reverse_diffusion / x_start_est stacked on the last axis,
+ * shape (B,T',J,3,S) (DIFF:303-347).  out: (B,T',J,3); T' = 1 for seq2frame else T. */
+int d3d_ddim_sample(d3d_engine* e, const float* x2d_dev, const float* init_noise_dev, const float* step_noise_dev,
+                    float* out_dev, float* traj_rev_dev, float* traj_x0_dev, int32_t B, void* ws_dev, size_t ws_bytes,
+                    void* stream);
+
+/* q_sample (DIFF:360-366, extract DIFF:21-24): out = sqrt_ac[t_b] * x_start + sqrt(1-ac)[t_b] * noise, per row b.
+ * n = elements per batch row. */
+int d3d_q_sample(d3d_engine* e, const float* x_start_dev, const float* noise_dev, const int32_t* t_dev, float* out_dev,
+                 int32_t B, int64_t n, void* stream);
+
+/* evaluate() tail (RUN:583-590, LOSS:15-22): un-flip + average the TTA pair, multiply by scale, and reduce the masked
+ * per-joint L2 error.  sums_dev[0] += sum of joint errors over frames with mask != 0, sums_dev[1] += number of such
+ * joints (caller zeroes sums_dev).  merged_dev (nullable) receives the merged, de-normalised prediction (B,T,J,3).
+ * pred_flip_dev may be NULL (no TTA).  joints_left/right: host index lists of equal length. */
+int d3d_tta_mpjpe(const float* pred_dev, const float* pred_flip_dev, const float* gt_dev, const uint8_t* mask_dev,
+                  float scale, const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr,
+                  float* merged_dev, double* sums_dev, int32_t B, int32_t T, int32_t J, void* stream);
+
+/* ---- single-op hooks: the same kernels the engine launches, exposed for the parity tests -------------------------- */
+/* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); epi 0 none, 1 exact-erf GELU, 2 add residual R[M,N] (R may alias C). */
+int d3d_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
+                  int32_t M, int32_t N, int32_t K, int32_t epi, int32_t precision, void* stream);
+/* Row LayerNorm over the last axis (S2S:95,101,236,245 eps 1e-6; S2S:218 eps 1e-5). */
+int d3d_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* out_dev, int32_t rows,
+                     int32_t D, float eps, void* stream);
+/* GRAND attention core (S2S:75-83) on a packed qkv buffer (B*T*J, 3*D): out = (softmax(q k^T / sqrt(dh)) - I) v,
+ * token-major (B*T*J, D).  temporal = 0: groups are frames (N = J keys); 1: groups are joints (N = T keys).
+ * force_generic != 0 selects the slow any-shape kernel (cross-check). */
+int d3d_op_attention(const float* qkv_dev, float* out_dev, int32_t B, int32_t T, int32_t J, int32_t D, int32_t H,
+                     int32_t temporal, int32_t precision, int32_t force_generic, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3D_H_ */

@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Golden-vector generator -- TEST INFRASTRUCTURE ONLY, runs in the BUILD container only.
+
+Imports the *real* reference from /root/reference (CPU), drives it with the seeded synthetic
+weights/inputs of ``diff3dhpe_amd.synth`` and writes input/output vectors to ``tests/golden/*.npz``.
+Nothing of the reference travels: the fixtures are numbers only, and weights/inputs are re-derived
+from seeds on the other side, so each file holds just the expected outputs (+ small metadata).
+
+It also cross-checks ``oracle/d3d_oracle.py`` against the reference while it runs (max-abs printed,
+hard-fails above 2e-6) -- that is how the restatement is pinned.
+
+Usage:  python oracle/gen_golden.py [--only NAME ...]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+from diff3dhpe_amd.spec import DenoiserConfig, S2S_NAME, S2F_NAME  # noqa: E402
+from diff3dhpe_amd.synth import synth_state_dict, synth_inputs, hash_uniform  # noqa: E402
+from oracle import d3d_oracle as orc  # noqa: E402
+
+
+def import_reference():
+    """SURVEY.md Appendix C recipe: stub timm.DropPath (never executed in eval), then import."""
+    for name in ("timm", "timm.models", "timm.models.layers"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=None):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if not self.drop_prob or not self.training:
+                return x
+            raise RuntimeError("DropPath stub reached in training mode")
+
+    sys.modules["timm.models.layers"].DropPath = DropPath
+    sys.modules["timm"].models = sys.modules["timm.models"]
+    sys.modules["timm.models"].layers = sys.modules["timm.models.layers"]
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from common.nets.load_net import HPE_model
+    import common.conditional_diffusion_ddim_normal_directPredict_variableLoss_both_crossFrames as d_s2s
+    import common.conditional_diffusion_s2f_ddim_normal_directPredict_variableLoss_both_crossFrames as d_s2f
+    from common.loss import mpjpe
+    return HPE_model, d_s2s.GaussianDiffusion, d_s2f.GaussianDiffusion, mpjpe
+
+
+HPE_model, GD_S2S, GD_S2F, ref_mpjpe = import_reference()
+
+
+def build_ref(cfg: DenoiserConfig, seed: int, timesteps=1000, sampling=9, eta=0.0, clip=True):
+    name = S2F_NAME if cfg.seq2frame else S2S_NAME
+    net = HPE_model(name)(num_frame=cfg.num_frame, num_joints=cfg.num_joints, in_chans=cfg.in_chans,
+                          embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                          qkv_bias=True, qk_scale=None, drop_path_rate=0.1, with_time_emb=cfg.with_time_emb)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed).items()}
+    missing, unexpected = net.load_state_dict(sd, strict=True), None
+    GD = GD_S2F if cfg.seq2frame else GD_S2S
+    diff = GD(model=net, timesteps=timesteps, sampling_timesteps=sampling, loss_type="l2", clip_denoised=clip,
+              beta_schedule="cosine", ddim_sampling_eta=eta, clipLoss=True).eval()
+    return net, diff, sd
+
+
+class inject_noise:
+    """Replace torch.randn / randn_like inside the unmodified reference loop (Appendix C)."""
+
+    def __init__(self, init_noise: torch.Tensor):
+        self.init = init_noise
+
+    def __enter__(self):
+        self._randn, self._randn_like = torch.randn, torch.randn_like
+        init = self.init
+        torch.randn = lambda *a, **k: init.clone()
+        torch.randn_like = lambda t, **k: torch.zeros_like(t)
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._randn, self._randn_like
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def check(tag, a: torch.Tensor, b: torch.Tensor, tol=2e-6):
+    d = (a - b).abs().max().item()
+    print(f"  oracle-vs-reference {tag}: max-abs {d:.3e}")
+    if not d <= tol:
+        raise SystemExit(f"oracle restatement diverges from the reference at {tag}: {d}")
+    return d
+
+
+def cfg_small(T=81, **kw):
+    return DenoiserConfig(num_frame=T, embed_dim=32, depth=4, **kw)
+
+
+def cfg_full(T, **kw):
+    return DenoiserConfig(num_frame=T, embed_dim=512, depth=8, **kw)
+
+
+# ----------------------------------------------------------------------------------------------- generators
+
+def gen_schedules():
+    net, diff, _ = build_ref(cfg_small(9), 0)
+    out = {}
+    for k, v in diff.state_dict().items():
+        if not k.startswith("model."):
+            out["cosine/" + k] = v.numpy()
+    tabs = orc.diffusion_tables("cosine", 1000)
+    for k in tabs:
+        assert torch.equal(tabs[k], diff.state_dict()[k]), k
+    for sched in ("linear", "logcosine"):
+        d = GD_S2S(model=net, timesteps=1000, sampling_timesteps=9, beta_schedule=sched)
+        for k in ("betas", "alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_alphas_cumprod"):
+            out[f"{sched}/{k}"] = d.state_dict()[k].numpy()
+            assert torch.equal(orc.diffusion_tables(sched, 1000)[k], d.state_dict()[k]), (sched, k)
+    d100 = GD_S2S(model=net, timesteps=100, sampling_timesteps=20, beta_schedule="cosine")
+    out["cosine100/alphas_cumprod"] = d100.state_dict()["alphas_cumprod"].numpy()
+    save("schedules", **out)
+
+
+def gen_ddim_times():
+    flat, offs = [], [0]
+    for S in range(1, 1001):
+        times = torch.linspace(-1, 999, steps=S + 1)
+        tl = list(reversed(times.int().tolist()))
+        assert tl == orc.ddim_times(1000, S) == orc.ddim_times_scalar(1000, S), S
+        flat += tl
+        offs.append(len(flat))
+    extra = {}
+    for N, S in ((100, 20), (100, 100), (50, 7), (200, 33)):
+        times = torch.linspace(-1, N - 1, steps=S + 1)
+        tl = list(reversed(times.int().tolist()))
+        assert tl == orc.ddim_times_scalar(N, S), (N, S)
+        extra[f"N{N}_S{S}"] = np.asarray(tl, dtype=np.int16)
+    save("ddim_times_N1000", flat=np.asarray(flat, dtype=np.int16), offsets=np.asarray(offs, dtype=np.int32), **extra)
+
+
+def gen_temb():
+    for D, depth, ts in ((32, 4, [0, 1, 110, 443, 887, 999]), (512, 8, [0, 443, 999])):
+        cfg = DenoiserConfig(num_frame=9, embed_dim=D, depth=depth)
+        net, _, sd = build_ref(cfg, 1)
+        t = torch.tensor(ts, dtype=torch.long)
+        with torch.no_grad():
+            sin = net.time_mlp[0](t)
+            trunk = net.time_mlp(t)
+            per_block = []
+            for i in range(depth):
+                per_block.append(net.STEblocks[i].time_mlp(trunk))
+                per_block.append(net.TTEblocks[i].time_mlp(trunk))
+            per_block = torch.stack(per_block, dim=1)  # (nt, 2*depth, D) in execution order STE0,TTE0,STE1,...
+        check(f"temb trunk D={D}", orc.time_trunk(sd, t, D), trunk)
+        save(f"temb_D{D}", t=np.asarray(ts, np.int32), sinusoid=sin.numpy(), trunk=trunk.numpy(), per_block=per_block.numpy(),
+             seed=np.int32(1))
+
+
+def gen_attention():
+    out = {}
+    for tag, D, N, G in (("spatial_D512", 512, 17, 2), ("spatial_D32", 32, 17, 4), ("temporal_D512_T27", 512, 27, 1),
+                         ("temporal_D512_T81", 512, 81, 1), ("temporal_D512_T243", 512, 243, 1),
+                         ("temporal_D32_T81", 32, 81, 2)):
+        cfg = DenoiserConfig(num_frame=9, embed_dim=D, depth=1)
+        net, _, sd = build_ref(cfg, 2)
+        x = torch.from_numpy((1.5 * hash_uniform("attn_in/" + tag, G * N * D, 2)).astype(np.float32).reshape(G, N, D))
+        blk = net.STEblocks[0] if tag.startswith("spatial") else net.TTEblocks[0]
+        pfx = "STEblocks.0" if tag.startswith("spatial") else "TTEblocks.0"
+        with torch.no_grad():
+            y = blk.attn(x)
+        check("attn " + tag, orc.grand_attention(sd, pfx + ".attn", x, 8), y)
+        out[tag] = y.numpy()
+    save("attention", seed=np.int32(2), **out)
+
+
+def gen_blocks():
+    out = {}
+    for tag, D, shape in (("ste_D512", 512, (1, 4, 17, 512)), ("tte_D512_T81", 512, (1, 81, 2, 512)),
+                          ("ste_D32", 32, (2, 9, 17, 32)), ("tte_D32_T27", 32, (2, 27, 17, 32))):
+        cfg = DenoiserConfig(num_frame=shape[1], embed_dim=D, depth=1)
+        net, _, sd = build_ref(cfg, 3)
+        n = int(np.prod(shape))
+        x = torch.from_numpy((1.2 * hash_uniform("block_in/" + tag, n, 3)).astype(np.float32).reshape(shape))
+        temb = torch.from_numpy(hash_uniform("block_temb/" + tag, shape[0] * 2 * D, 3).astype(np.float32).reshape(shape[0], 2 * D))
+        spatial = tag.startswith("ste")
+        blk = net.STEblocks[0] if spatial else net.TTEblocks[0]
+        post = net.Spatial_norm if spatial else net.Temporal_norm
+        with torch.no_grad():
+            y = blk(x, is_spatial=spatial, time_emb=temb)
+            z = post(y)
+        yo = orc.mixste_block(sd, "STEblocks.0" if spatial else "TTEblocks.0", x, spatial, temb, 8)
+        check("block " + tag, yo, y)
+        out[tag + "/block"] = y.numpy()
+        out[tag + "/postnorm"] = z.numpy()
+    save("blocks", seed=np.int32(3), **out)
+
+
+def gen_denoise():
+    cases = [("small_T81", cfg_small(81), 4), ("full_T27", cfg_full(27), 2), ("full_T81", cfg_full(81), 2),
+             ("full_T243", cfg_full(243), 2), ("s2f_T27", cfg_full(27, seq2frame=True), 2),
+             ("notemb_T27", cfg_full(27, with_time_emb=False), 2), ("small_s2f_T27", cfg_small(27, seq2frame=True), 3)]
+    for tag, cfg, B in cases:
+        net, _, sd = build_ref(cfg, 4)
+        inp = synth_inputs(B, cfg.num_frame, seed=100)
+        x2d = torch.from_numpy(inp["x2d"])
+        y_t = torch.from_numpy(inp["noise"]) * 0.7
+        out = {}
+        for t in (999, 443, 0):
+            tv = torch.full((B,), t, dtype=torch.long)
+            t0 = time.time()
+            with torch.no_grad():
+                r = net.forward_denoise(torch.cat([x2d, y_t], dim=-1), tv)
+            dt = time.time() - t0
+            o = orc.forward_denoise(sd, torch.cat([x2d, y_t], dim=-1), tv, depth=cfg.depth, seq2frame=cfg.seq2frame)
+            check(f"denoise {tag} t={t} ({dt:.1f}s)", o, r)
+            out[f"t{t}"] = r.numpy()
+        # per-row timesteps (p_losses-style call), pins the non-broadcast time-embedding path
+        tv = torch.tensor([(37 * i + 5) % 1000 for i in range(B)], dtype=torch.long)
+        with torch.no_grad():
+            r = net.forward_denoise(torch.cat([x2d, y_t], dim=-1), tv)
+        out["tmixed"] = r.numpy()
+        out["tmixed_t"] = tv.numpy().astype(np.int32)
+        save("denoise_" + tag, seed=np.int32(4), input_seed=np.int32(100), B=np.int32(B), y_scale=np.float32(0.7), **out)
+
+
+def gen_ddim():
+    cases = [("small_T81_S5", cfg_small(81), 4, 5, True), ("full_T81_S9", cfg_full(81), 2, 9, False),
+             ("full_T243_S9", cfg_full(243), 2, 9, False), ("full_T243_S50", cfg_full(243), 1, 50, False),
+             ("s2f_T27_S9", cfg_full(27, seq2frame=True), 4, 9, True), ("full_T27_S7_notemb", cfg_full(27, with_time_emb=False), 2, 7, False),
+             ("small_T81_S5_noclip", cfg_small(81), 2, 5, True)]
+    for tag, cfg, B, S, traj in cases:
+        clip = "noclip" not in tag
+        net, diff, sd = build_ref(cfg, 5, sampling=S, clip=clip)
+        inp = synth_inputs(B, cfg.num_frame, seed=200)
+        x2d = torch.from_numpy(inp["x2d"])
+        noise = torch.from_numpy(inp["noise"])
+        if cfg.seq2frame:
+            noise = noise[:, :1].contiguous()
+        clean_shape = torch.zeros_like(noise)
+        t0 = time.time()
+        with inject_noise(noise), torch.no_grad():
+            if traj:
+                _, y0, rev, x0s = diff(clean_shape, x2d, None, True, False)
+            else:
+                _, y0 = diff(clean_3d_pose=clean_shape, noisy_2d_pose=x2d, output_loss=False)
+        dt = time.time() - t0
+        tabs = orc.diffusion_tables("cosine", 1000)
+        o = orc.ddim_sample_loop(sd, tabs, x2d, noise, num_timesteps=1000, sampling_timesteps=S, depth=cfg.depth,
+                                 clip_denoised=clip, seq2frame=cfg.seq2frame, return_trajectory=traj)
+        if traj:
+            check(f"ddim {tag} y0 ({dt:.1f}s)", o[0], y0, 5e-6)
+            check(f"ddim {tag} rev", o[1], rev, 5e-6)
+            check(f"ddim {tag} x0s", o[2], x0s, 5e-6)
+            save("ddim_" + tag, seed=np.int32(5), input_seed=np.int32(200), B=np.int32(B), S=np.int32(S), y0=y0.numpy(),
+                 x_reverse_diffusion=rev.numpy(), x_start_est=x0s.numpy())
+        else:
+            check(f"ddim {tag} y0 ({dt:.1f}s)", o, y0, 5e-6)
+            save("ddim_" + tag, seed=np.int32(5), input_seed=np.int32(200), B=np.int32(B), S=np.int32(S), y0=y0.numpy())
+
+
+def gen_repeat_eta():
+    """repeat_n>1 hypothesis averaging and eta>0 stochastic DDIM with supplied per-step noise (DIFF:290-297, 433-448)."""
+    cfg = cfg_small(27)
+    B, S, R = 2, 4, 3
+    net, diff, sd = build_ref(cfg, 6, sampling=S, eta=0.5)
+    inp = synth_inputs(B * R, cfg.num_frame, seed=300)
+    x2d = torch.from_numpy(inp["x2d"][:B])
+    noise = torch.from_numpy(inp["noise"])  # (B*R, ...)
+    step_noise = [torch.from_numpy(hash_uniform(f"eta_noise/{i}", noise.numel(), 6).astype(np.float32).reshape(noise.shape)) for i in range(S)]
+    it = iter(step_noise)
+    _randn, _randn_like = torch.randn, torch.randn_like
+    torch.randn = lambda *a, **k: noise.clone()
+    torch.randn_like = lambda t, **k: next(it).clone()
+    try:
+        with torch.no_grad():
+            _, y0 = diff(clean_3d_pose=torch.zeros(B, cfg.num_frame, 17, 3), noisy_2d_pose=x2d, output_loss=False, repeat_n=R)
+    finally:
+        torch.randn, torch.randn_like = _randn, _randn_like
+    tabs = orc.diffusion_tables("cosine", 1000)
+    o = orc.ddim_sample_loop(sd, tabs, x2d.repeat(R, 1, 1, 1), noise, num_timesteps=1000, sampling_timesteps=S, depth=cfg.depth,
+                             eta=0.5, step_noise=step_noise)
+    o = o.view(R, B, cfg.num_frame, 17, 3).mean(0)
+    check("ddim repeat_n/eta", o, y0, 5e-6)
+    save("ddim_small_T27_S4_eta05_rep3", seed=np.int32(6), input_seed=np.int32(300), B=np.int32(B), S=np.int32(S), R=np.int32(R),
+         eta=np.float32(0.5), y0=y0.numpy())
+
+
+def gen_plosses():
+    cfg = cfg_small(27)
+    B = 3
+    net, diff, sd = build_ref(cfg, 7, sampling=5)
+    inp = synth_inputs(B, cfg.num_frame, seed=400)
+    x2d, noise, gt = (torch.from_numpy(inp[k]) for k in ("x2d", "noise", "gt3d"))
+    gt = gt * 0.5
+    t = torch.tensor([999, 12, 500], dtype=torch.long)
+    _randint = torch.randint
+    torch.randint = lambda *a, **k: t.clone()
+    try:
+        with torch.no_grad():
+            loss = diff.p_losses(gt, x2d, noise=noise)
+            xq = diff.q_sample(gt, t, noise)
+    finally:
+        torch.randint = _randint
+    tabs = orc.diffusion_tables("cosine", 1000)
+    lo = orc.p_losses(sd, tabs, gt, x2d, t, noise, depth=cfg.depth, clip_loss=True)
+    check("p_losses", lo, loss, 5e-6)
+    check("q_sample", orc.q_sample(tabs, gt, t, noise), xq)
+    save("plosses_small_T27", seed=np.int32(7), input_seed=np.int32(400), B=np.int32(B), t=t.numpy().astype(np.int32),
+         gt_scale=np.float32(0.5), loss=loss.numpy(), q_sample=xq.numpy())
+
+
+def gen_evalmath():
+    B, T, J = 3, 9, 17
+    rng = np.random.RandomState(7)
+    pred = torch.from_numpy(rng.uniform(-1, 1, (B, T, J, 3)).astype(np.float32))
+    pred_flip = torch.from_numpy(rng.uniform(-1, 1, (B, T, J, 3)).astype(np.float32))
+    gt = torch.from_numpy(rng.uniform(-1, 1, (B, T, J, 3)).astype(np.float32))
+    mask = torch.from_numpy(rng.uniform(0, 1, (B, T)) > 0.3)
+    scale = 1.7
+    jl, jr = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    # RUN:583-590 transcribed as data flow on tensors (the harness lines themselves are script code, not importable)
+    pf = pred_flip.clone()
+    pf[:, :, :, 0] *= -1
+    pf[:, :, jl + jr] = pf[:, :, jr + jl]
+    merged = ((pred + pf) / 2.0) * scale
+    merged = merged.view(-1, J, 3)[mask.view(-1) == True, :, :].unsqueeze(1)  # noqa: E712
+    gtm = gt.view(-1, J, 3)[mask.view(-1) == True, :, :].unsqueeze(1)  # noqa: E712
+    err = ref_mpjpe(merged, gtm)
+    om = orc.merge_flip_tta(pred, pred_flip, scale, mask)
+    check("evalmath merge", om, merged, 0.0)
+    check("evalmath mpjpe", orc.mpjpe(om, gtm), err, 0.0)
+    save("evalmath", pred=pred.numpy(), pred_flip=pred_flip.numpy(), gt=gt.numpy(), target_mask=mask.numpy(), scale=np.float32(scale),
+         joints_left=np.asarray(jl, np.int32), joints_right=np.asarray(jr, np.int32), merged=merged.numpy(), mpjpe=np.float32(err.item()))
+
+
+GENERATORS = {
+    "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
+    "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name, fn in GENERATORS.items():
+        if a.only and name not in a.only:
+            continue
+        print(f"[{name}]")
+        fn()
