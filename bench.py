@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pose-sequences/sec of the DDIM sampling hot path (BASELINE.json metric).
+
+One "step" = one full S-step `d3d_ddim_sample` over one resident batch of synthetic CPN-style windows (plus the
+flip-free evaluate() tail: all-gather of the predicted sequences when N > 1 and the MPJPE reduction kernel).
+Default workload = the per-GPU shard of BASELINE.json configs[2]: T=243, J=17, D=512, depth=8, 9 DDIM steps,
+B=64 sequences per GPU (weak scaling: the 8-GPU run is the full B=512 of that config).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` (dominant kernel class, timed
+live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = a port of the reference's op
+sequence, timed on this node's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "bf16": 2500.0}     # dense MFMA peaks, MI355X_MICROARCH.md
+DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3(f32-equivalent)", "bf16": "bf16"}
+
+
+def flops_per_seq_step(T, D=512, J=17):
+    return J * T * (256 * D * D + 544 * D + 32 * T * D)       # F(T)
+
+
+def cpu_baseline(T, S, seed, budget_s=30.0):
+    """The oracle (port of the reference's eager op sequence) on the host cores, bounded to ~budget_s of CPU work."""
+    import torch
+    from oracle import d3d_oracle as orc
+    from diff3dhpe_amd.spec import DenoiserConfig
+    from diff3dhpe_amd.synth import synth_state_dict, synth_inputs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = DenoiserConfig(num_frame=T, embed_dim=512, depth=8)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed).items()}
+    tabs = orc.diffusion_tables("cosine", 1000)
+    best, runs, spent = 0.0, [], 0.0
+    for B in (1, 1, 2):
+        if spent > budget_s * 0.6 and runs:
+            break
+        inp = synth_inputs(B, T, seed=42)
+        t0 = time.time()
+        orc.ddim_sample_loop(sd, tabs, torch.from_numpy(inp["x2d"]), torch.from_numpy(inp["noise"]), num_timesteps=1000,
+                             sampling_timesteps=S, depth=8)
+        dt = time.time() - t0
+        spent += dt
+        runs.append((B, dt))
+        best = max(best, B / dt)
+    return {"value": round(best, 4), "unit": "pose-seq/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"T={T}, {S} DDIM steps, fp32 eager CPU oracle; runs (B, s): " + ", ".join(f"({b}, {d:.1f})" for b, d in runs)
+                      + "; best B reported"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--frames", type=int, default=243)
+    ap.add_argument("--sampling", type=int, default=9)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import diff3dhpe_amd as d3d
+    from diff3dhpe_amd import parallel
+    from diff3dhpe_amd.engine import tta_mpjpe
+    from diff3dhpe_amd.spec import DenoiserConfig
+    from diff3dhpe_amd.synth import synth_state_dict, synth_inputs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    T, S, Bl = a.frames, a.sampling, a.batch
+    Bg = Bl * world
+    cfg = DenoiserConfig(num_frame=T, embed_dim=512, depth=8)
+    net = d3d.HPE_model(d3d.S2S_NAME)(num_frame=T, num_joints=17, in_chans=2, embed_dim=512, depth=8, num_heads=8,
+                                      mlp_ratio=2., qkv_bias=True, qk_scale=None, drop_path_rate=0.1, with_time_emb=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 0).items()})
+    net.precision = a.precision
+    diff = d3d.GaussianDiffusion(model=net, timesteps=1000, sampling_timesteps=S, loss_type="l2", clip_denoised=True,
+                                 beta_schedule="cosine", ddim_sampling_eta=0.0, clipLoss=True).eval().to(dev)
+
+    # global synthetic batch; each rank keeps its contiguous shard resident in HBM before the timed region
+    inp = synth_inputs(Bg, T, seed=42)
+    lo, hi = parallel.shard_bounds(Bg, rank, world)
+    x2d = torch.from_numpy(inp["x2d"][lo:hi]).to(dev)
+    noise = torch.from_numpy(inp["noise"][lo:hi]).to(dev)
+    gt = torch.from_numpy(inp["gt3d"]).to(dev)
+    eng = diff._engine(dev)
+
+    def step():
+        pred = eng.ddim_sample(x2d, noise)
+        pred = parallel.all_gather_pred(pred, Bg)          # RCCL all-gather (no-op at N=1)
+        return tta_mpjpe(pred, None, gt if world > 1 else gt[lo:hi], None, 1.0, [], [])
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    eng.profile_reset()
+    eng.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        err, cnt = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+    prof = eng.profile_read()
+
+    if rank == 0:
+        value = Bg * a.steps / elapsed
+        tot_ms = sum(v["ms"] for v in prof.values()) or 1.0
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        d = prof[dom]
+        if dom == "linear" or dom == "attn_temporal":
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[a.precision]
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+        else:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4)}
+        roof.update({"kernel": dom, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                     "share_of_gpu_time": round(d["ms"] / tot_ms, 4), "traffic": None,
+                     "by_kernel_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in prof.items() if v["launches"]}})
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # per-launch PMC bytes from a separate rocprofv3 run
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                key = f"{dom}:T{T}:B{Bl}:{a.precision}"
+                roof["traffic"] = tj.get(key)
+            except Exception:
+                pass
+        whole = flops_per_seq_step(T) * S * value / 1e12
+        line = {
+            "metric": "pose_sequences_per_sec", "value": round(value, 3), "unit": "pose-seq/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[a.precision],
+            "data": "synthetic",
+            "config": {"workload": f"H36M-CPN-shape 2D windows T={T} J=17, MixSTE D=512 depth=8 random-init, {S} DDIM steps, "
+                                   f"B={Bl}/GPU (BASELINE configs[2] per-GPU shard), eta=0, clip_denoised",
+                       "global_batch": Bg, "frames": T, "sampling_timesteps": S, "parallelism": f"dp{world}",
+                       "precision": a.precision},
+            "whole_step_tflops": round(whole, 2),
+            "mpjpe_vs_synthetic_gt": round(err / max(cnt, 1), 6),
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(T, S, 0)
+            line["speedup_vs_cpu_baseline"] = round(value / max(line["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

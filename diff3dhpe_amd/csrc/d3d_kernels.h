@@ -1,0 +1,82 @@
+// Internal launcher interface between the engine (engine.hip) and the gfx950 kernels.
+// Not part of the public ABI (that is include/d3d.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace d3d {
+
+enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
+
+// ---- kernels_gemm.hip -------------------------------------------------------------------------------------------
+// C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); all row-major fp32, K % 32 == 0.
+hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
+                             int K, int epi, hipStream_t s);
+
+// ---- kernels_elem.hip -------------------------------------------------------------------------------------------
+// Row LayerNorm; optionally also writes a second LayerNorm of the first result (post-norm -> next block's norm1).
+//   y  = LN(x; g1,b1,eps1) [+ pos[(row / pos_div) % pos_mod] ] [+ tvec[(row / rows_per_batch) * tvec_stride]]
+//   h  = LN(y; g2,b2,eps2)                       (only when h != nullptr)
+struct LnArgs {
+  const float* x;
+  float* y;          // may alias x; may be nullptr when only h is wanted (then h = LN(x; g1,b1))
+  float* h;          // nullable
+  const float* g1; const float* b1; float eps1;
+  const float* g2; const float* b2; float eps2;
+  const float* pos;  // nullable, (pos_mod, D)
+  int pos_div, pos_mod;
+  const float* tvec; // nullable, per-batch vector (n, D) with row stride tvec_stride (0 = broadcast)
+  int64_t tvec_stride;
+  int rows_per_batch;
+  int rows, D;
+};
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
+
+// X[m,:] = W_f [x2d[m], y[m']] + b_f + spos[j] + tvec[b]   (S2S:250, :229-233, :113-116 of block 0)
+hipError_t launch_embed(const float* x2d, const float* y, const float* Wf, const float* bf, const float* spos,
+                        const float* tvec, int64_t tvec_stride, float* X, int B, int T, int J, int D, int in_chans,
+                        int y_bcast_T, hipStream_t s);
+
+// sinusoid + trunk + per-block projections: out (n, nblk, D)
+hipError_t launch_sinusoid(const float* times, const float* freqs, float* out, int n, int D, hipStream_t s);
+// out[n,N] = post(act_pre(in[n,K]) @ W[N,K]^T + b); act: 0 none, 1 gelu(post), 2 silu(pre)
+hipError_t launch_small_linear(const float* in, const float* W, const float* b, float* out, int n, int N, int K,
+                               int act, hipStream_t s);
+
+// seq2frame frame reduce (S2F:261-263): out[b,j,:] = sum_t w[t] X[b,t,j,:] + bias
+hipError_t launch_frame_reduce(const float* X, const float* w, const float* bias, float* out, int B, int T, int J, int D,
+                               hipStream_t s);
+
+struct HeadArgs {
+  const float* X;        // (rows, D)
+  const float* g; const float* b; float eps;   // head.0
+  const float* Wh; const float* bh;            // head.1 (3, D), (3,)
+  int rows, D;
+  // outputs
+  float* x0_raw;         // nullable: raw network output (rows,3)
+  // DDIM step (all nullable when mode == 0)
+  int mode;              // 0: raw only; 1: clamp?/DDIM update; 2: final step (y_out = clamped x0)
+  int clip;
+  const float* y_cur;    // (rows,3)
+  float* y_next;         // (rows,3) (may alias y_cur)
+  const float* noise;    // nullable (rows,3)
+  float alpha, alpha_next, somac, eta;
+  float* traj_rev; float* traj_x0; int traj_rev_stride, traj_x0_stride, traj_idx;   // nullable
+};
+hipError_t launch_head(const HeadArgs& a, hipStream_t s);
+
+hipError_t launch_q_sample(const float* x_start, const float* noise, const int32_t* t, const float* sqrt_ac,
+                           const float* somac, float* out, int B, int64_t n, hipStream_t s);
+
+hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, const uint8_t* mask, float scale,
+                            const int32_t* perm_dev, float* merged, double* sums, int B, int T, int J, hipStream_t s);
+
+// ---- kernels_attn.hip -------------------------------------------------------------------------------------------
+// qkv: (B*T*J, 3*D) -> out (B*T*J, D), GRAND core  O = softmax(q k^T * dh^-0.5) v - v
+hipError_t launch_attn_spatial_f32(const float* qkv, float* out, int B, int T, int J, int D, int H, hipStream_t s);
+hipError_t launch_attn_temporal_f32(const float* qkv, float* out, int B, int T, int J, int D, int H, hipStream_t s);
+hipError_t launch_attn_generic(const float* qkv, float* out, int B, int T, int J, int D, int H, int temporal, hipStream_t s);
+bool attn_spatial_fast_ok(int J, int D, int H);
+bool attn_temporal_fast_ok(int T, int D, int H);
+
+}  // namespace d3d

@@ -1,0 +1,719 @@
+// Host side of libd3d_hip.so: engine object, weight registry/repack, DDIM schedule, per-step launch sequence and the
+// C ABI declared in include/d3d.h.  No CPU compute path exists here: every tensor operation is a kernel from
+// kernels_*.hip; the only host arithmetic is the integer timestep schedule and table bookkeeping.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/d3d.h"
+#include "d3d_kernels.h"
+
+using namespace d3d;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+  do {                                                                                                        \
+    hipError_t _e = (expr);                                                                                   \
+    if (_e != hipSuccess)                                                                                     \
+      return fail(D3D_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+struct WeightSlot {
+  std::string name;
+  int64_t numel = 0;
+  std::vector<float> host;
+  bool set = false;
+  size_t dev_off = 0;  // float offset into the device arena
+};
+
+struct BlockW {
+  const float *n1g, *n1b, *qkvw, *qkvb, *projw, *projb, *n2g, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
+};
+
+}  // namespace
+
+struct d3d_engine {
+  d3d_config cfg{};
+  int T = 0, J = 0, D = 0, H = 0, Dm = 0, Dt = 0, depth = 0, cin = 0, nblk = 0;
+  std::vector<WeightSlot> slots;
+  std::map<std::string, int> index;
+  std::vector<float> freqs_host;
+  bool freqs_set = false;
+  bool committed = false;
+
+  float* arena = nullptr;  // all weights, device
+  size_t arena_floats = 0;
+  std::vector<BlockW> blk;  // execution order: STE0, TTE0, STE1, ...
+  const float *fus_w = nullptr, *fus_b = nullptr, *spos = nullptr, *tpos = nullptr;
+  const float *sn_g = nullptr, *sn_b = nullptr, *tn_g = nullptr, *tn_b = nullptr;
+  const float *hd_g = nullptr, *hd_b = nullptr, *hd_w = nullptr, *hd_bias = nullptr;
+  const float *tm1_w = nullptr, *tm1_b = nullptr, *tm3_w = nullptr, *tm3_b = nullptr;
+  const float *wm_w = nullptr, *wm_b = nullptr;
+  float *tblk_w = nullptr, *tblk_b = nullptr;  // concatenated per-block time projections (nblk*D, Dt), (nblk*D)
+  float* freqs_dev = nullptr;
+
+  // schedule
+  bool sched_set = false;
+  int num_timesteps = 0, S = 0, clip = 0;
+  float eta = 0.f;
+  std::vector<float> ac, somac;
+  std::vector<int32_t> times;  // S+1, reversed
+  float *ac_dev = nullptr, *somac_dev = nullptr, *sqrt_ac_dev = nullptr;
+  float* temb_sched = nullptr;  // (S, nblk, D)
+  bool has_sqrt_ac = false;
+
+  // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
+  struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+  bool profiling = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[D3D_KC_COUNT] = {0}, prof_flops[D3D_KC_COUNT] = {0}, prof_bytes[D3D_KC_COUNT] = {0};
+  int64_t prof_launches[D3D_KC_COUNT] = {0};
+
+  ~d3d_engine() {
+    for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto ev : ev_pool) (void)hipEventDestroy(ev);
+    (void)hipFree(arena); (void)hipFree(tblk_w); (void)hipFree(tblk_b); (void)hipFree(freqs_dev);
+    (void)hipFree(ac_dev); (void)hipFree(somac_dev); (void)hipFree(sqrt_ac_dev); (void)hipFree(temb_sched);
+  }
+};
+
+namespace {
+
+void add_slot(d3d_engine* e, const std::string& name, int64_t numel) {
+  WeightSlot s;
+  s.name = name;
+  s.numel = numel;
+  e->index[name] = (int)e->slots.size();
+  e->slots.push_back(std::move(s));
+}
+
+void add_block_slots(d3d_engine* e, const std::string& p) {
+  const int64_t D = e->D, Dm = e->Dm, Dt = e->Dt;
+  add_slot(e, p + ".norm1.weight", D);
+  add_slot(e, p + ".norm1.bias", D);
+  add_slot(e, p + ".attn.qkv.weight", 3 * D * D);
+  add_slot(e, p + ".attn.qkv.bias", 3 * D);
+  add_slot(e, p + ".attn.proj.weight", D * D);
+  add_slot(e, p + ".attn.proj.bias", D);
+  add_slot(e, p + ".norm2.weight", D);
+  add_slot(e, p + ".norm2.bias", D);
+  if (Dt) {
+    add_slot(e, p + ".time_mlp.1.weight", D * Dt);
+    add_slot(e, p + ".time_mlp.1.bias", D);
+  }
+  add_slot(e, p + ".mlp.fc1.weight", Dm * D);
+  add_slot(e, p + ".mlp.fc1.bias", Dm);
+  add_slot(e, p + ".mlp.fc2.weight", D * Dm);
+  add_slot(e, p + ".mlp.fc2.bias", D);
+}
+
+// Parameter inventory in the reference's registration order (S2S:160-220, S2F:216-218); mirrors diff3dhpe_amd/spec.py.
+void build_slots(d3d_engine* e) {
+  const int64_t D = e->D, Dt = e->Dt, T = e->T, J = e->J;
+  if (Dt) {
+    add_slot(e, "time_mlp.1.weight", Dt * D);
+    add_slot(e, "time_mlp.1.bias", Dt);
+    add_slot(e, "time_mlp.3.weight", Dt * Dt);
+    add_slot(e, "time_mlp.3.bias", Dt);
+  }
+  add_slot(e, "fusion_layer.weight", D * e->cin);
+  add_slot(e, "fusion_layer.bias", D);
+  add_slot(e, "Spatial_pos_embed", J * D);
+  for (int i = 0; i < e->depth; ++i) add_block_slots(e, "STEblocks." + std::to_string(i));
+  add_slot(e, "Spatial_norm.weight", D);
+  add_slot(e, "Spatial_norm.bias", D);
+  add_slot(e, "Temporal_pos_embed", T * D);
+  for (int i = 0; i < e->depth; ++i) add_block_slots(e, "TTEblocks." + std::to_string(i));
+  add_slot(e, "Temporal_norm.weight", D);
+  add_slot(e, "Temporal_norm.bias", D);
+  add_slot(e, "head.0.weight", D);
+  add_slot(e, "head.0.bias", D);
+  add_slot(e, "head.1.weight", 3 * D);
+  add_slot(e, "head.1.bias", 3);
+  if (e->cfg.seq2frame) {
+    add_slot(e, "weighted_mean.weight", T);
+    add_slot(e, "weighted_mean.bias", 1);
+  }
+}
+
+const float* wptr(const d3d_engine* e, const std::string& name) {
+  auto it = e->index.find(name);
+  if (it == e->index.end()) return nullptr;
+  return e->arena + e->slots[it->second].dev_off;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// RAII bracket: records an event pair around one kernel launch when profiling is on (no-op otherwise).
+struct Prof {
+  d3d_engine* e; hipStream_t s; bool on; d3d_engine::ProfRec r{};
+  Prof(d3d_engine* e_, int cls, double flops, double bytes, hipStream_t s_) : e(e_), s(s_), on(e_->profiling) {
+    if (!on) return;
+    auto get = [&]() {
+      hipEvent_t ev = nullptr;
+      if (!e->ev_pool.empty()) { ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
+      else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+      return ev;
+    };
+    r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = get(); r.b = get();
+    if (!r.a || !r.b) { on = false; return; }
+    (void)hipEventRecord(r.a, s);
+  }
+  ~Prof() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    e->recs.push_back(r);
+  }
+};
+
+// Workspace carve-up (float offsets).  AO (attention output) aliases HN: norm1(x) is dead once the qkv GEMM has run.
+struct Workspace {
+  float *X, *HN, *QKV, *HID, *Y0, *Y1, *TEMB, *TSCR, *RED, *TIMES;
+  size_t total_bytes;
+};
+
+Workspace carve(const d3d_engine* e, int B, void* base) {
+  const size_t M = (size_t)B * e->T * e->J;
+  const size_t D = e->D;
+  size_t off = 0;
+  auto take = [&](size_t nfloats) {
+    size_t o = off;
+    off += align_up(nfloats, 64);
+    return o;
+  };
+  float* b = reinterpret_cast<float*>(base);
+  Workspace w{};
+  size_t oX = take(M * D), oHN = take(M * D), oQKV = take(M * 3 * D), oHID = take(M * e->Dm);
+  size_t oY0 = take(M * 3), oY1 = take(M * 3);
+  size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
+  size_t oRED = take((size_t)B * e->J * D), oTI = take((size_t)B + 64);
+  w.X = b + oX; w.HN = b + oHN; w.QKV = b + oQKV; w.HID = b + oHID; w.Y0 = b + oY0; w.Y1 = b + oY1;
+  w.TEMB = b + oTE; w.TSCR = b + oTS; w.RED = b + oRED; w.TIMES = b + oTI;
+  w.total_bytes = off * sizeof(float);
+  return w;
+}
+
+// time-embedding table for n timesteps: out (n, nblk, D).  scratch: n*(D + 2*Dt) floats.
+int compute_temb(d3d_engine* e, const float* times_dev, int n, float* out, float* scratch, hipStream_t s) {
+  float* sin_buf = scratch;
+  float* h1 = sin_buf + (size_t)n * e->D;
+  float* h2 = h1 + (size_t)n * e->Dt;
+  HIP_TRY(launch_sinusoid(times_dev, e->freqs_dev, sin_buf, n, e->D, s));
+  HIP_TRY(launch_small_linear(sin_buf, e->tm1_w, e->tm1_b, h1, n, e->Dt, e->D, /*gelu out*/ 1, s));
+  HIP_TRY(launch_small_linear(h1, e->tm3_w, e->tm3_b, h2, n, e->Dt, e->Dt, 0, s));
+  HIP_TRY(launch_small_linear(h2, e->tblk_w, e->tblk_b, out, n, e->nblk * e->D, e->Dt, /*silu in*/ 2, s));
+  return D3D_OK;
+}
+
+int attention(d3d_engine* e, const float* qkv, float* out, int B, bool temporal, hipStream_t s) {
+  if (!temporal) {
+    if (attn_spatial_fast_ok(e->J, e->D, e->H)) HIP_TRY(launch_attn_spatial_f32(qkv, out, B, e->T, e->J, e->D, e->H, s));
+    else HIP_TRY(launch_attn_generic(qkv, out, B, e->T, e->J, e->D, e->H, 0, s));
+  } else {
+    if (attn_temporal_fast_ok(e->T, e->D, e->H)) HIP_TRY(launch_attn_temporal_f32(qkv, out, B, e->T, e->J, e->D, e->H, s));
+    else HIP_TRY(launch_attn_generic(qkv, out, B, e->T, e->J, e->D, e->H, 1, s));
+  }
+  return D3D_OK;
+}
+
+// One denoiser forward up to (not including) the head: leaves the final Temporal_norm output in w.X.
+// tvec: (n, nblk, D) time-embedding table slice or nullptr; tvec_stride = 0 (all rows share entry 0) or nblk*D.
+int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, const float* tvec, int64_t tvec_stride,
+               int B, const Workspace& w, hipStream_t s) {
+  const int T = e->T, J = e->J, D = e->D;
+  const int M = B * T * J;
+  const double MD4 = (double)M * D * 4.0;
+  {
+    Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
+    HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.X, B, T, J, D, e->cfg.in_chans,
+                         y_bcast, s));
+  }
+  auto linear = [&](const float* A, const float* W, const float* bias, const float* R, float* C, int N, int K, int epi) -> hipError_t {
+    Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), s);
+    return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
+  };
+  auto lnorm = [&](const LnArgs& a) -> hipError_t {
+    Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + (a.y ? 1 : 0) + (a.h ? 1 : 0)), s);
+    return launch_layernorm(a, s);
+  };
+  {  // h = norm1_0(x)
+    LnArgs a{};
+    a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = e->blk[0].n1g; a.b1 = e->blk[0].n1b; a.eps1 = 1e-6f;
+    a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+    HIP_TRY(lnorm(a));
+  }
+  for (int k = 0; k < e->nblk; ++k) {
+    const BlockW& bw = e->blk[k];
+    const bool temporal = (k & 1) != 0;
+    HIP_TRY(linear(w.HN, bw.qkvw, bw.qkvb, nullptr, w.QKV, 3 * D, D, EPI_NONE));
+    {
+      const int N = temporal ? T : J;
+      Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
+      int rc = attention(e, w.QKV, w.HN, B, temporal, s);
+      if (rc) return rc;
+    }
+    HIP_TRY(linear(w.HN, bw.projw, bw.projb, w.X, w.X, D, D, EPI_RESIDUAL));
+    {  // h = norm2(x)
+      LnArgs a{};
+      a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
+      a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+      HIP_TRY(lnorm(a));
+    }
+    HIP_TRY(linear(w.HN, bw.fc1w, bw.fc1b, nullptr, w.HID, e->Dm, D, EPI_GELU));
+    HIP_TRY(linear(w.HID, bw.fc2w, bw.fc2b, w.X, w.X, D, e->Dm, EPI_RESIDUAL));
+    {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = next.norm1(x)
+      LnArgs a{};
+      a.x = w.X; a.y = w.X;
+      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = 1e-6f;
+      a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+      if (k == 0) { a.pos = e->tpos; a.pos_div = J; a.pos_mod = T; }
+      if (k + 1 < e->nblk) {
+        if (tvec) { a.tvec = tvec + (size_t)(k + 1) * D; a.tvec_stride = tvec_stride; }
+        a.h = w.HN; a.g2 = e->blk[k + 1].n1g; a.b2 = e->blk[k + 1].n1b; a.eps2 = 1e-6f;
+      }
+      HIP_TRY(lnorm(a));
+    }
+  }
+  return D3D_OK;
+}
+
+int head_rows(const d3d_engine* e, int B) { return e->cfg.seq2frame ? B * e->J : B * e->T * e->J; }
+
+// fills X / rows for the head (runs the seq2frame frame reduce first when needed)
+int prep_head(d3d_engine* e, HeadArgs& h, int B, const Workspace& w, hipStream_t s) {
+  h.g = e->hd_g; h.b = e->hd_b; h.eps = 1e-5f; h.Wh = e->hd_w; h.bh = e->hd_bias; h.D = e->D;
+  h.rows = head_rows(e, B);
+  if (e->cfg.seq2frame) {
+    Prof p(e, D3D_KC_OTHER, 2.0 * B * e->T * e->J * e->D, 4.0 * B * e->T * e->J * e->D, s);
+    HIP_TRY(launch_frame_reduce(w.X, e->wm_w, e->wm_b, w.RED, B, e->T, e->J, e->D, s));
+    h.X = w.RED;
+  } else {
+    h.X = w.X;
+  }
+  return D3D_OK;
+}
+
+int check_ready(const d3d_engine* e, int B, const void* ws, size_t ws_bytes) {
+  if (!e) return fail(D3D_EINVAL, "null engine");
+  if (!e->committed) return fail(D3D_ESTATE, "weights not committed (d3d_engine_commit_weights)");
+  if (B <= 0) return fail(D3D_EINVAL, "B must be positive");
+  if ((long long)B * e->T * e->J > 0x7fffffffLL / 4) return fail(D3D_EINVAL, "batch too large for 32-bit token index");
+  if (!ws) return fail(D3D_EINVAL, "null workspace");
+  if (ws_bytes < d3d_workspace_bytes(e, B)) return fail(D3D_ENOMEM, "workspace smaller than d3d_workspace_bytes(e, B)");
+  if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail(D3D_EINVAL, "workspace must be 256-byte aligned");
+  return D3D_OK;
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+const char* d3d_last_error(void) { return g_err.c_str(); }
+int d3d_version(void) { return 100; }
+
+int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out) {
+  // torch.linspace(-1, N-1, S+1) in fp32 (two-sided evaluation around the midpoint), .int() truncation, reversed
+  // (DIFF:270-272).  A one-sided or fp64 evaluation is off by one for ~200 of the 1000 possible S.
+  if (num_timesteps < 1 || sampling_timesteps < 1 || !out) return fail(D3D_EINVAL, "d3d_ddim_times: bad arguments");
+  const int steps = sampling_timesteps + 1;
+  const float start = -1.0f, end = (float)(num_timesteps - 1);
+  volatile float step = (end - start) / (float)(steps - 1);
+  const int half = steps / 2;
+  for (int i = 0; i < steps; ++i) {
+    volatile float prod, v;
+    if (i < half) {
+      prod = (float)i * step;
+      v = start + prod;
+    } else {
+      prod = (float)(steps - 1 - i) * step;
+      v = end - prod;
+    }
+    out[steps - 1 - i] = (int32_t)v;  // trunc toward zero
+  }
+  return D3D_OK;
+}
+
+int d3d_engine_create(const d3d_config* c, d3d_engine** out) {
+  if (!c || !out) return fail(D3D_EINVAL, "null argument");
+  if (c->num_frame < 1 || c->num_joints < 1 || c->in_chans < 1 || c->in_chans > 5 || c->embed_dim < 4 || c->depth < 1 ||
+      c->num_heads < 1 || c->mlp_hidden < 1)
+    return fail(D3D_EINVAL, "d3d_config: non-positive dimension");
+  if (c->embed_dim % c->num_heads) return fail(D3D_EINVAL, "embed_dim must be divisible by num_heads");
+  if (c->embed_dim % 32 || c->mlp_hidden % 32)
+    return fail(D3D_EUNSUP, "embed_dim and mlp_hidden must be multiples of 32 (MFMA k-tile)");
+  if (c->embed_dim > 1024) return fail(D3D_EUNSUP, "embed_dim > 1024 unsupported by the row kernels");
+  {
+    const int dh = c->embed_dim / c->num_heads;
+    if (dh != 4 && dh != 8 && dh != 16 && dh != 32 && dh != 64) return fail(D3D_EUNSUP, "head_dim must be 4,8,16,32 or 64");
+  }
+  if (c->precision != D3D_PREC_FP32) return fail(D3D_EUNSUP, "only D3D_PREC_FP32 is implemented in this build");
+  d3d_engine* e = new d3d_engine();
+  e->cfg = *c;
+  e->T = c->num_frame; e->J = c->num_joints; e->D = c->embed_dim; e->H = c->num_heads; e->Dm = c->mlp_hidden;
+  e->Dt = c->with_time_emb ? 2 * c->embed_dim : 0;
+  e->depth = c->depth; e->nblk = 2 * c->depth; e->cin = c->in_chans + 3;
+  build_slots(e);
+  *out = e;
+  return D3D_OK;
+}
+
+void d3d_engine_destroy(d3d_engine* e) { delete e; }
+
+int d3d_engine_num_weights(const d3d_engine* e) { return e ? (int)e->slots.size() : 0; }
+
+int d3d_engine_weight_info(const d3d_engine* e, int i, const char** name, int64_t* numel) {
+  if (!e || i < 0 || i >= (int)e->slots.size()) return fail(D3D_EINVAL, "weight index out of range");
+  if (name) *name = e->slots[i].name.c_str();
+  if (numel) *numel = e->slots[i].numel;
+  return D3D_OK;
+}
+
+int d3d_engine_set_weight(d3d_engine* e, const char* name, const float* host, int64_t numel) {
+  if (!e || !name || !host) return fail(D3D_EINVAL, "null argument");
+  auto it = e->index.find(name);
+  if (it == e->index.end()) return fail(D3D_EINVAL, std::string("unknown weight name: ") + name);
+  WeightSlot& s = e->slots[it->second];
+  if (numel != s.numel)
+    return fail(D3D_EINVAL, std::string("size mismatch for ") + name + ": got " + std::to_string(numel) + ", expected " +
+                                std::to_string(s.numel));
+  s.host.assign(host, host + numel);
+  s.set = true;
+  e->committed = false;
+  return D3D_OK;
+}
+
+int d3d_engine_set_time_freqs(d3d_engine* e, const float* host, int32_t n) {
+  if (!e || !host) return fail(D3D_EINVAL, "null argument");
+  if (n != e->D / 2) return fail(D3D_EINVAL, "time frequency table must have embed_dim/2 entries");
+  e->freqs_host.assign(host, host + n);
+  e->freqs_set = true;
+  e->committed = false;
+  return D3D_OK;
+}
+
+int d3d_engine_commit_weights(d3d_engine* e) {
+  if (!e) return fail(D3D_EINVAL, "null engine");
+  for (const auto& s : e->slots)
+    if (!s.set) return fail(D3D_ESTATE, "missing weight: " + s.name);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(D3D_EHIP, "no HIP device: libd3d_hip has no CPU path");
+  size_t off = 0;
+  for (auto& s : e->slots) {
+    s.dev_off = off;
+    off += align_up((size_t)s.numel, 64);
+  }
+  if (e->arena) { (void)hipFree(e->arena); e->arena = nullptr; }
+  e->arena_floats = off;
+  HIP_TRY(hipMalloc(&e->arena, off * sizeof(float)));
+  for (auto& s : e->slots)
+    HIP_TRY(hipMemcpy(e->arena + s.dev_off, s.host.data(), (size_t)s.numel * sizeof(float), hipMemcpyHostToDevice));
+
+  auto blockw = [&](const std::string& p) {
+    BlockW b{};
+    b.n1g = wptr(e, p + ".norm1.weight"); b.n1b = wptr(e, p + ".norm1.bias");
+    b.qkvw = wptr(e, p + ".attn.qkv.weight"); b.qkvb = wptr(e, p + ".attn.qkv.bias");
+    b.projw = wptr(e, p + ".attn.proj.weight"); b.projb = wptr(e, p + ".attn.proj.bias");
+    b.n2g = wptr(e, p + ".norm2.weight"); b.n2b = wptr(e, p + ".norm2.bias");
+    b.fc1w = wptr(e, p + ".mlp.fc1.weight"); b.fc1b = wptr(e, p + ".mlp.fc1.bias");
+    b.fc2w = wptr(e, p + ".mlp.fc2.weight"); b.fc2b = wptr(e, p + ".mlp.fc2.bias");
+    return b;
+  };
+  e->blk.clear();
+  for (int i = 0; i < e->depth; ++i) {  // execution order (S2S:225-245): STE_i then TTE_i
+    e->blk.push_back(blockw("STEblocks." + std::to_string(i)));
+    e->blk.push_back(blockw("TTEblocks." + std::to_string(i)));
+  }
+  e->fus_w = wptr(e, "fusion_layer.weight"); e->fus_b = wptr(e, "fusion_layer.bias");
+  e->spos = wptr(e, "Spatial_pos_embed"); e->tpos = wptr(e, "Temporal_pos_embed");
+  e->sn_g = wptr(e, "Spatial_norm.weight"); e->sn_b = wptr(e, "Spatial_norm.bias");
+  e->tn_g = wptr(e, "Temporal_norm.weight"); e->tn_b = wptr(e, "Temporal_norm.bias");
+  e->hd_g = wptr(e, "head.0.weight"); e->hd_b = wptr(e, "head.0.bias");
+  e->hd_w = wptr(e, "head.1.weight"); e->hd_bias = wptr(e, "head.1.bias");
+  e->wm_w = wptr(e, "weighted_mean.weight"); e->wm_b = wptr(e, "weighted_mean.bias");
+
+  if (e->Dt) {
+    e->tm1_w = wptr(e, "time_mlp.1.weight"); e->tm1_b = wptr(e, "time_mlp.1.bias");
+    e->tm3_w = wptr(e, "time_mlp.3.weight"); e->tm3_b = wptr(e, "time_mlp.3.bias");
+    // concatenate the 2*depth per-block Linear(Dt -> D) layers (S2S:104-107) into one (nblk*D, Dt) matrix
+    const size_t wn = (size_t)e->nblk * e->D * e->Dt, bn = (size_t)e->nblk * e->D;
+    (void)hipFree(e->tblk_w); (void)hipFree(e->tblk_b); e->tblk_w = e->tblk_b = nullptr;
+    HIP_TRY(hipMalloc(&e->tblk_w, wn * sizeof(float)));
+    HIP_TRY(hipMalloc(&e->tblk_b, bn * sizeof(float)));
+    for (int k = 0; k < e->nblk; ++k) {
+      const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2) + ".time_mlp.1";
+      HIP_TRY(hipMemcpy(e->tblk_w + (size_t)k * e->D * e->Dt, wptr(e, p + ".weight"), (size_t)e->D * e->Dt * sizeof(float),
+                        hipMemcpyDeviceToDevice));
+      HIP_TRY(hipMemcpy(e->tblk_b + (size_t)k * e->D, wptr(e, p + ".bias"), (size_t)e->D * sizeof(float),
+                        hipMemcpyDeviceToDevice));
+    }
+    // SinusoidalPosEmb frequencies (S2S:31-33): exp(k * -(ln 1e4 / (half-1))) with the product formed in fp32
+    const int half = e->D / 2;
+    if (!e->freqs_set) {
+      e->freqs_host.resize(half);
+      const float neg = (float)(-(std::log(10000.0) / (double)(half - 1)));
+      for (int k = 0; k < half; ++k) {
+        volatile float arg = (float)k * neg;
+        e->freqs_host[k] = (float)std::exp((double)arg);
+      }
+    }
+    (void)hipFree(e->freqs_dev); e->freqs_dev = nullptr;
+    HIP_TRY(hipMalloc(&e->freqs_dev, half * sizeof(float)));
+    HIP_TRY(hipMemcpy(e->freqs_dev, e->freqs_host.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  }
+  e->committed = true;
+  e->sched_set = false;
+  return D3D_OK;
+}
+
+int d3d_engine_set_schedule(d3d_engine* e, int32_t num_timesteps, const float* ac_host, const float* somac_host,
+                            int32_t sampling_timesteps, float eta, int32_t clip_denoised, void* stream) {
+  if (!e || !ac_host || !somac_host) return fail(D3D_EINVAL, "null argument");
+  if (!e->committed) return fail(D3D_ESTATE, "commit weights before setting the schedule");
+  if (num_timesteps < 1 || sampling_timesteps < 1) return fail(D3D_EINVAL, "timesteps must be positive");
+  if (sampling_timesteps > num_timesteps) return fail(D3D_EINVAL, "sampling_timesteps <= timesteps required (DIFF:145)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  e->num_timesteps = num_timesteps; e->S = sampling_timesteps; e->eta = eta; e->clip = clip_denoised ? 1 : 0;
+  e->ac.assign(ac_host, ac_host + num_timesteps);
+  e->somac.assign(somac_host, somac_host + num_timesteps);
+  e->times.resize(sampling_timesteps + 1);
+  int rc = d3d_ddim_times(num_timesteps, sampling_timesteps, e->times.data());
+  if (rc) return rc;
+  (void)hipFree(e->ac_dev); (void)hipFree(e->somac_dev); (void)hipFree(e->temb_sched);
+  e->ac_dev = e->somac_dev = e->temb_sched = nullptr;
+  HIP_TRY(hipMalloc(&e->ac_dev, num_timesteps * sizeof(float)));
+  HIP_TRY(hipMalloc(&e->somac_dev, num_timesteps * sizeof(float)));
+  HIP_TRY(hipMemcpy(e->ac_dev, ac_host, num_timesteps * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->somac_dev, somac_host, num_timesteps * sizeof(float), hipMemcpyHostToDevice));
+  if (e->Dt) {
+    const int S = sampling_timesteps;
+    std::vector<float> tf(S);
+    for (int i = 0; i < S; ++i) tf[i] = (float)e->times[i];
+    float *tdev = nullptr, *scratch = nullptr;
+    HIP_TRY(hipMalloc(&tdev, S * sizeof(float)));
+    HIP_TRY(hipMalloc(&scratch, (size_t)S * (e->D + 2 * (size_t)e->Dt) * sizeof(float)));
+    HIP_TRY(hipMalloc(&e->temb_sched, (size_t)S * e->nblk * e->D * sizeof(float)));
+    HIP_TRY(hipMemcpy(tdev, tf.data(), S * sizeof(float), hipMemcpyHostToDevice));
+    rc = compute_temb(e, tdev, S, e->temb_sched, scratch, s);
+    hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(tdev); (void)hipFree(scratch);
+    if (rc) return rc;
+    HIP_TRY(se);
+  }
+  e->sched_set = true;
+  return D3D_OK;
+}
+
+size_t d3d_workspace_bytes(const d3d_engine* e, int32_t B) {
+  if (!e || B <= 0) return 0;
+  return carve(e, B, nullptr).total_bytes + 256;
+}
+
+int d3d_denoise(d3d_engine* e, const float* x2d, const float* y, int32_t y_frames, const float* times_dev,
+                int32_t n_times, float* x0, int32_t B, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_ready(e, B, ws, ws_bytes);
+  if (rc) return rc;
+  if (!x2d || !y || !x0) return fail(D3D_EINVAL, "null tensor");
+  if (y_frames != 1 && y_frames != e->T) return fail(D3D_EINVAL, "y_frames must be 1 or num_frame");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Workspace w = carve(e, B, ws);
+  const float* tvec = nullptr;
+  int64_t stride = 0;
+  if (e->Dt) {
+    if (!times_dev) return fail(D3D_EINVAL, "times required when with_time_emb");
+    if (n_times != 1 && n_times != B) return fail(D3D_EINVAL, "n_times must be 1 or B");
+    rc = compute_temb(e, times_dev, n_times, w.TEMB, w.TSCR, s);
+    if (rc) return rc;
+    tvec = w.TEMB;
+    stride = (n_times == 1) ? 0 : (int64_t)e->nblk * e->D;
+  }
+  rc = run_blocks(e, x2d, y, (y_frames == 1 && e->T != 1) ? 1 : 0, tvec, stride, B, w, s);
+  if (rc) return rc;
+  HeadArgs h{};
+  rc = prep_head(e, h, B, w, s);
+  if (rc) return rc;
+  h.x0_raw = x0; h.mode = 0;
+  {
+    Prof p(e, D3D_KC_HEAD, 14.0 * h.rows * e->D, 4.0 * h.rows * e->D, s);
+    HIP_TRY(launch_head(h, s));
+  }
+  return D3D_OK;
+}
+
+int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, const float* step_noise, float* out,
+                    float* traj_rev, float* traj_x0, int32_t B, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_ready(e, B, ws, ws_bytes);
+  if (rc) return rc;
+  if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set (d3d_engine_set_schedule)");
+  if (!x2d || !init_noise || !out) return fail(D3D_EINVAL, "null tensor");
+  if (e->eta != 0.0f && !step_noise) return fail(D3D_EINVAL, "step_noise required when eta != 0");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Workspace w = carve(e, B, ws);
+  const int S = e->S;
+  const size_t yel = (size_t)head_rows(e, B) * 3;
+  for (int i = 0; i < S; ++i) {
+    const int t = e->times[i], tn = e->times[i + 1];
+    const float* y_cur = (i == 0) ? init_noise : ((i & 1) ? w.Y0 : w.Y1);
+    float* y_next = (i == S - 1) ? out : ((i & 1) ? w.Y1 : w.Y0);
+    const float* tvec = e->Dt ? e->temb_sched + (size_t)i * e->nblk * e->D : nullptr;
+    rc = run_blocks(e, x2d, y_cur, e->cfg.seq2frame ? 1 : 0, tvec, 0, B, w, s);
+    if (rc) return rc;
+    HeadArgs h{};
+    rc = prep_head(e, h, B, w, s);
+    if (rc) return rc;
+    h.clip = e->clip;
+    h.y_cur = y_cur; h.y_next = y_next;
+    h.traj_rev = traj_rev; h.traj_x0 = traj_x0; h.traj_rev_stride = S; h.traj_x0_stride = S; h.traj_idx = i;
+    if (tn < 0) {
+      h.mode = 2;
+    } else {
+      h.mode = 1;
+      h.alpha = e->ac[t]; h.alpha_next = e->ac[tn]; h.somac = e->somac[t]; h.eta = e->eta;
+      h.noise = (e->eta != 0.0f) ? step_noise + (size_t)i * yel : nullptr;
+    }
+    {
+      Prof p(e, D3D_KC_HEAD, 14.0 * h.rows * e->D, 4.0 * h.rows * e->D, s);
+      HIP_TRY(launch_head(h, s));
+    }
+  }
+  return D3D_OK;
+}
+
+int d3d_q_sample(d3d_engine* e, const float* x_start, const float* noise, const int32_t* t_dev, float* out, int32_t B,
+                 int64_t n, void* stream) {
+  if (!e || !x_start || !noise || !t_dev || !out) return fail(D3D_EINVAL, "null argument");
+  if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set");
+  if (!e->has_sqrt_ac) return fail(D3D_ESTATE, "sqrt_alphas_cumprod not supplied (d3d_engine_set_sqrt_alphas_cumprod)");
+  HIP_TRY(launch_q_sample(x_start, noise, t_dev, e->sqrt_ac_dev, e->somac_dev, out, B, n, reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
+int d3d_engine_set_sqrt_alphas_cumprod(d3d_engine* e, const float* host, int32_t n) {
+  if (!e || !host) return fail(D3D_EINVAL, "null argument");
+  if (!e->sched_set || n != e->num_timesteps) return fail(D3D_ESTATE, "set the schedule first; n must equal num_timesteps");
+  (void)hipFree(e->sqrt_ac_dev); e->sqrt_ac_dev = nullptr;
+  HIP_TRY(hipMalloc(&e->sqrt_ac_dev, n * sizeof(float)));
+  HIP_TRY(hipMemcpy(e->sqrt_ac_dev, host, n * sizeof(float), hipMemcpyHostToDevice));
+  e->has_sqrt_ac = true;
+  return D3D_OK;
+}
+
+int d3d_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, const uint8_t* mask, float scale,
+                  const int32_t* jl, const int32_t* jr, int32_t n_lr, float* merged, double* sums, int32_t B, int32_t T,
+                  int32_t J, void* stream) {
+  if (!pred || !gt || !sums || B <= 0 || T <= 0 || J <= 0) return fail(D3D_EINVAL, "bad argument");
+  if (pred_flip && n_lr > 0 && (!jl || !jr)) return fail(D3D_EINVAL, "joint lists required");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<int32_t> perm(J);
+  for (int j = 0; j < J; ++j) perm[j] = j;
+  for (int i = 0; i < n_lr; ++i) {  // RUN:584-585: pf[:, :, left+right] = pf[:, :, right+left]
+    if (jl[i] < 0 || jl[i] >= J || jr[i] < 0 || jr[i] >= J) return fail(D3D_EINVAL, "joint index out of range");
+    perm[jl[i]] = jr[i];
+    perm[jr[i]] = jl[i];
+  }
+  int32_t* perm_dev = nullptr;
+  HIP_TRY(hipMalloc(&perm_dev, J * sizeof(int32_t)));
+  hipError_t e1 = hipMemcpyAsync(perm_dev, perm.data(), J * sizeof(int32_t), hipMemcpyHostToDevice, s);
+  hipError_t e2 = (e1 == hipSuccess) ? launch_tta_mpjpe(pred, pred_flip, gt, mask, scale, perm_dev, merged, sums, B, T, J, s) : e1;
+  hipError_t e3 = hipStreamSynchronize(s);
+  (void)hipFree(perm_dev);
+  HIP_TRY(e2);
+  HIP_TRY(e3);
+  return D3D_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------------------
+int d3d_engine_set_profiling(d3d_engine* e, int32_t on) {
+  if (!e) return fail(D3D_EINVAL, "null engine");
+  e->profiling = on != 0;
+  return D3D_OK;
+}
+
+int d3d_engine_profile_reset(d3d_engine* e) {
+  if (!e) return fail(D3D_EINVAL, "null engine");
+  for (auto& r : e->recs) { e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b); }
+  e->recs.clear();
+  for (int c = 0; c < D3D_KC_COUNT; ++c) { e->prof_ms[c] = e->prof_flops[c] = e->prof_bytes[c] = 0; e->prof_launches[c] = 0; }
+  return D3D_OK;
+}
+
+int d3d_engine_profile_read(d3d_engine* e, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  if (!e || cls < 0 || cls >= D3D_KC_COUNT) return fail(D3D_EINVAL, "bad kernel class");
+  for (auto& r : e->recs) {  // resolve pending event pairs (blocks until they have completed)
+    HIP_TRY(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    e->prof_ms[r.cls] += ms; e->prof_flops[r.cls] += r.flops; e->prof_bytes[r.cls] += r.bytes; e->prof_launches[r.cls] += 1;
+    e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b);
+  }
+  e->recs.clear();
+  if (total_ms) *total_ms = e->prof_ms[cls];
+  if (launches) *launches = e->prof_launches[cls];
+  if (flops) *flops = e->prof_flops[cls];
+  if (bytes) *bytes = e->prof_bytes[cls];
+  return D3D_OK;
+}
+
+const char* d3d_kernel_class_name(int32_t cls) {
+  static const char* names[D3D_KC_COUNT] = {"linear", "attn_spatial", "attn_temporal", "layernorm", "embed", "head", "other"};
+  return (cls >= 0 && cls < D3D_KC_COUNT) ? names[cls] : "?";
+}
+
+// ---- single-op hooks ----------------------------------------------------------------------------------------------
+int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, float* out, float* scratch, void* stream) {
+  if (!e || !times_dev || !out || !scratch || n <= 0) return fail(D3D_EINVAL, "bad argument");
+  if (!e->committed) return fail(D3D_ESTATE, "weights not committed");
+  if (!e->Dt) return fail(D3D_ESTATE, "engine was built with with_time_emb = 0");
+  return compute_temb(e, times_dev, n, out, scratch, reinterpret_cast<hipStream_t>(stream));
+}
+
+int d3d_op_linear(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M, int32_t N,
+                  int32_t K, int32_t epi, int32_t precision, void* stream) {
+  if (precision != D3D_PREC_FP32) return fail(D3D_EUNSUP, "precision not implemented");
+  if (!A || !W || !C) return fail(D3D_EINVAL, "null tensor");
+  if (K % 32) return fail(D3D_EUNSUP, "K must be a multiple of 32");
+  HIP_TRY(launch_linear_f32(A, W, bias, R, C, M, N, K, epi, reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
+int d3d_op_layernorm(const float* x, const float* gamma, const float* beta, float* out, int32_t rows, int32_t D, float eps,
+                     void* stream) {
+  if (!x || !gamma || !beta || !out) return fail(D3D_EINVAL, "null tensor");
+  LnArgs a{};
+  a.x = x; a.y = out; a.g1 = gamma; a.b1 = beta; a.eps1 = eps; a.rows = rows; a.D = D; a.rows_per_batch = 1;
+  a.pos_div = 1; a.pos_mod = 1;
+  HIP_TRY(launch_layernorm(a, reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
+int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t J, int32_t D, int32_t H, int32_t temporal,
+                     int32_t precision, int32_t force_generic, void* stream) {
+  if (precision != D3D_PREC_FP32) return fail(D3D_EUNSUP, "precision not implemented");
+  if (!qkv || !out || B <= 0 || T <= 0 || J <= 0 || D <= 0 || H <= 0 || D % H) return fail(D3D_EINVAL, "bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!force_generic && !temporal && attn_spatial_fast_ok(J, D, H)) {
+    HIP_TRY(launch_attn_spatial_f32(qkv, out, B, T, J, D, H, s));
+  } else if (!force_generic && temporal && attn_temporal_fast_ok(T, D, H)) {
+    HIP_TRY(launch_attn_temporal_f32(qkv, out, B, T, J, D, H, s));
+  } else {
+    HIP_TRY(launch_attn_generic(qkv, out, B, T, J, D, H, temporal, s));
+  }
+  return D3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,383 @@
+// HBM-bound row kernels of the DDIM step (gfx950): input embedding, LayerNorm (pre/post/head), time-embedding table,
+// regression head + DDIM update, seq2frame frame reduce, q_sample, flip-TTA merge + MPJPE.
+// One 64-lane wave owns one token row (D floats as float4 per lane) so every reduction is a wave shuffle tree and
+// every HBM access is a 16-byte-per-lane coalesced stream.
+#include "d3d_kernels.h"
+
+namespace d3d {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int LN_MAXV = 4;  // float4 per lane -> D <= 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// In-register LayerNorm of one row spread over a wave.  v[i] holds columns 4*(lane + 64 i) .. +3 (valid if < D).
+template <int NV>
+__device__ __forceinline__ void ln_row(float4 (&v)[NV], int D, int lane, const float* __restrict__ g,
+                                       const float* __restrict__ b, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (4 * (lane + 64 * i) < D) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (4 * (lane + 64 * i) < D) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < D) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + c);
+      const float4 bb = *reinterpret_cast<const float4*>(b + c);
+      v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
+      v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
+      v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
+      v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
+    }
+  }
+}
+
+__device__ __forceinline__ void add4(float4& a, const float4 b) {
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (fused)
+template <int NV>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int D = a.D;
+  float4 v[NV];
+  const float* xr = a.x + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+  }
+  ln_row<NV>(v, D, lane, a.g1, a.b1, a.eps1);
+  if (a.pos) {  // S2S:238-242 (Temporal_pos_embed is added after Spatial_norm, before the block's time-emb add)
+    const float* pr = a.pos + (size_t)((row / a.pos_div) % a.pos_mod) * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) add4(v[i], *reinterpret_cast<const float4*>(pr + c));
+    }
+  }
+  if (a.tvec) {  // S2S:113-116 of the NEXT block: x = x + time_mlp_i(t)[:,None,None,:]
+    const float* tr = a.tvec + (size_t)(row / a.rows_per_batch) * a.tvec_stride;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) add4(v[i], *reinterpret_cast<const float4*>(tr + c));
+    }
+  }
+  if (a.y) {
+    float* yr = a.y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) *reinterpret_cast<float4*>(yr + c) = v[i];
+    }
+  }
+  if (a.h) {
+    if (a.y) ln_row<NV>(v, D, lane, a.g2, a.b2, a.eps2);
+    float* hr = a.h + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) *reinterpret_cast<float4*>(hr + c) = v[i];
+    }
+  }
+}
+
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
+  if (a.rows <= 0 || a.D <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
+  const int grid = (a.rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  if (a.D <= 256)
+    hipLaunchKernelGGL(k_layernorm<1>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else if (a.D <= 512)
+    hipLaunchKernelGGL(k_layernorm<2>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_layernorm<4>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ input embedding
+// One thread per (token, 4 columns).  x2d and y rows are broadcast-read (L1), X is a pure streaming write.
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x2d, const float* __restrict__ y,
+                                               const float* __restrict__ Wf, const float* __restrict__ bf,
+                                               const float* __restrict__ spos, const float* __restrict__ tvec,
+                                               int64_t tvec_stride, float* __restrict__ X, int B, int T, int J, int D,
+                                               int cin2, int y_bcast_T) {
+  const int D4 = D >> 2;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)B * T * J * D4;
+  if (gid >= total) return;
+  const int c = (int)(gid % D4) * 4;
+  const size_t m = gid / D4;
+  const int j = (int)(m % J);
+  const size_t bt = m / J;
+  const int b = (int)(bt / T);
+  float in[8];
+  const int cin = cin2 + 3;
+  for (int k = 0; k < cin2; ++k) in[k] = x2d[m * cin2 + k];
+  const size_t my = y_bcast_T ? ((size_t)b * J + j) : m;  // DIFF-S2F:281: y.repeat(1, f, 1, 1)
+  for (int k = 0; k < 3; ++k) in[cin2 + k] = y[my * 3 + k];
+  float o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* w = Wf + (size_t)(c + q) * cin;
+    float acc = 0.f;
+    for (int k = 0; k < cin; ++k) acc = fmaf(in[k], w[k], acc);
+    acc += bf[c + q];
+    acc += spos[(size_t)j * D + c + q];
+    if (tvec) acc += tvec[(size_t)b * tvec_stride + c + q];
+    o[q] = acc;
+  }
+  *reinterpret_cast<float4*>(X + m * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+hipError_t launch_embed(const float* x2d, const float* y, const float* Wf, const float* bf, const float* spos,
+                        const float* tvec, int64_t tvec_stride, float* X, int B, int T, int J, int D, int in_chans,
+                        int y_bcast_T, hipStream_t s) {
+  if ((D & 3) || in_chans < 1 || in_chans > 5) return hipErrorInvalidValue;
+  const size_t total = (size_t)B * T * J * (D >> 2);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(k_embed, dim3(grid), dim3(256), 0, s, x2d, y, Wf, bf, spos, tvec, tvec_stride, X, B, T, J, D,
+                     in_chans, y_bcast_T);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ time embedding
+// S2S:29-36: [sin(t f_k), cos(t f_k)], k < D/2.  t * f_k is the same fp32 product torch forms.
+__global__ void k_sinusoid(const float* __restrict__ times, const float* __restrict__ freqs, float* __restrict__ out,
+                           int n, int D) {
+  const int half = D >> 1;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * half) return;
+  const int i = gid / half, k = gid % half;
+  const float arg = __fmul_rn(times[i], freqs[k]);
+  out[(size_t)i * D + k] = sinf(arg);
+  out[(size_t)i * D + half + k] = cosf(arg);
+}
+
+hipError_t launch_sinusoid(const float* times, const float* freqs, float* out, int n, int D, hipStream_t s) {
+  const int total = n * (D >> 1);
+  hipLaunchKernelGGL(k_sinusoid, dim3((total + 255) / 256), dim3(256), 0, s, times, freqs, out, n, D);
+  return hipGetLastError();
+}
+
+// out[i, o] = post( sum_k pre(in[i,k]) W[o,k] + b[o] ); one wave per output element, K strided over lanes.
+// act: 0 none, 1 GELU on the output (time_mlp.2, S2S:172), 2 SiLU on the input (Block.time_mlp.0, S2S:105)
+__global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ in, const float* __restrict__ W,
+                                                      const float* __restrict__ b, float* __restrict__ out, int n, int N,
+                                                      int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (size_t)n * N) return;
+  const int i = (int)(w / N), o = (int)(w % N);
+  const float* x = in + (size_t)i * K;
+  const float* wr = W + (size_t)o * K;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float xv = x[k];
+    if (act == 2) xv = silu(xv);
+    acc = fmaf(xv, wr[k], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    acc += b[o];
+    if (act == 1) acc = gelu_erf(acc);
+    out[w] = acc;
+  }
+}
+
+hipError_t launch_small_linear(const float* in, const float* W, const float* b, float* out, int n, int N, int K,
+                               int act, hipStream_t s) {
+  const size_t waves = (size_t)n * N;
+  hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in, W, b, out, n, N, K, act);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ seq2frame reduce
+// S2F:261-263: Conv1d(T -> 1, k = 1) over view(b, f, J*D): out[b, j, :] = sum_t w[t] X[b,t,j,:] + bias
+__global__ __launch_bounds__(256) void k_frame_reduce(const float* __restrict__ X, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                      int T, int JD4) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)B * JD4) return;
+  const int b = (int)(gid / JD4), c = (int)(gid % JD4);
+  const float4* xp = reinterpret_cast<const float4*>(X) + (size_t)b * T * JD4 + c;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (int t = 0; t < T; ++t) {
+    const float wt = w[t];
+    const float4 v = xp[(size_t)t * JD4];
+    acc.x = fmaf(wt, v.x, acc.x); acc.y = fmaf(wt, v.y, acc.y); acc.z = fmaf(wt, v.z, acc.z); acc.w = fmaf(wt, v.w, acc.w);
+  }
+  const float bb = bias[0];
+  acc.x += bb; acc.y += bb; acc.z += bb; acc.w += bb;
+  reinterpret_cast<float4*>(out)[gid] = acc;
+}
+
+hipError_t launch_frame_reduce(const float* X, const float* w, const float* bias, float* out, int B, int T, int J, int D,
+                               hipStream_t s) {
+  if (D & 3) return hipErrorInvalidValue;
+  const int JD4 = J * D / 4;
+  const size_t total = (size_t)B * JD4;
+  hipLaunchKernelGGL(k_frame_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, w, bias, out, B, T, JD4);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ head + DDIM update
+// head = LayerNorm(eps 1e-5) + Linear(D -> 3) (S2S:217-220); clamp (DIFF:252,256); DDIM update (DIFF:287-297) with the
+// reference's `alpha * x_start` term (DIFF:296) and its fp32 operation order (no fma contraction: __f*_rn).
+template <int NV>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int D = a.D;
+  float4 v[NV];
+  const float* xr = a.X + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+  }
+  ln_row<NV>(v, D, lane, a.g, a.b, a.eps);
+  float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < D) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
+        o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o[k] = wave_sum(o[k]);
+  if (lane < 3) {
+    const int k = lane;
+    float x0 = (k == 0 ? o[0] : (k == 1 ? o[1] : o[2])) + a.bh[k];
+    const size_t idx = (size_t)row * 3 + k;
+    if (a.x0_raw) a.x0_raw[idx] = x0;
+    if (a.mode != 0) {
+      if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      if (a.traj_x0) a.traj_x0[idx * a.traj_x0_stride + a.traj_idx] = x0;
+      float yn;
+      if (a.mode == 2) {
+        yn = x0;  // DIFF:283-285: the last step returns the (clamped) x_start
+      } else {
+        const float al = a.alpha, an = a.alpha_next;
+        // sigma = eta * sqrt((1 - a/an) * (1 - an) / (1 - a));  c = sqrt(1 - an - sigma^2)
+        const float sigma = __fmul_rn(a.eta, __fsqrt_rn(__fdiv_rn(__fmul_rn(__fsub_rn(1.0f, __fdiv_rn(al, an)),
+                                                                             __fsub_rn(1.0f, an)),
+                                                                    __fsub_rn(1.0f, al))));
+        const float cc = __fsqrt_rn(__fsub_rn(__fsub_rn(1.0f, an), __fmul_rn(sigma, sigma)));
+        const float yc = a.y_cur[idx];
+        const float t1 = __fmul_rn(x0, __fsqrt_rn(an));
+        const float t4 = __fdiv_rn(__fsub_rn(yc, __fmul_rn(al, x0)), a.somac);
+        yn = __fadd_rn(t1, __fmul_rn(cc, t4));
+        const float nz = a.noise ? a.noise[idx] : 0.0f;
+        yn = __fadd_rn(yn, __fmul_rn(sigma, nz));
+      }
+      a.y_next[idx] = yn;
+      if (a.traj_rev) a.traj_rev[idx * a.traj_rev_stride + a.traj_idx] = yn;
+    }
+  }
+}
+
+hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
+  if (a.rows <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
+  const int grid = (a.rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  if (a.D <= 256)
+    hipLaunchKernelGGL(k_head<1>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else if (a.D <= 512)
+    hipLaunchKernelGGL(k_head<2>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_head<4>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ q_sample
+// DIFF:360-366 with extract (DIFF:21-24): per-row gather of the two fp32 tables by the integer timestep.
+__global__ __launch_bounds__(256) void k_q_sample(const float* __restrict__ x_start, const float* __restrict__ noise,
+                                                  const int32_t* __restrict__ t, const float* __restrict__ sqrt_ac,
+                                                  const float* __restrict__ somac, float* __restrict__ out, int B,
+                                                  int64_t n) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)B * n) return;
+  const int tb = t[gid / n];
+  out[gid] = __fadd_rn(__fmul_rn(sqrt_ac[tb], x_start[gid]), __fmul_rn(somac[tb], noise[gid]));
+}
+
+hipError_t launch_q_sample(const float* x_start, const float* noise, const int32_t* t, const float* sqrt_ac,
+                           const float* somac, float* out, int B, int64_t n, hipStream_t s) {
+  const int64_t total = (int64_t)B * n;
+  hipLaunchKernelGGL(k_q_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x_start, noise, t, sqrt_ac,
+                     somac, out, B, n);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ flip-TTA + MPJPE
+// RUN:583-590 + LOSS:15-22.  One thread per (b,t,j): merged = (pred + unflip(pred_flip)) / 2 * scale; err = ||.-gt||_2.
+// perm[j] = index of the joint whose flipped prediction lands on j (identity when there is no TTA).
+__global__ __launch_bounds__(256) void k_tta_mpjpe(const float* __restrict__ pred, const float* __restrict__ pred_flip,
+                                                   const float* __restrict__ gt, const uint8_t* __restrict__ mask,
+                                                   float scale, const int32_t* __restrict__ perm,
+                                                   float* __restrict__ merged, double* __restrict__ sums, int BT, int J) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  float err = 0.f, cnt = 0.f;
+  if (gid < BT * J) {
+    const int bt = gid / J, j = gid % J;
+    float p[3];
+    for (int k = 0; k < 3; ++k) p[k] = pred[(size_t)gid * 3 + k];
+    if (pred_flip) {
+      const size_t src = ((size_t)bt * J + perm[j]) * 3;
+      p[0] = __fdiv_rn(__fadd_rn(p[0], -pred_flip[src + 0]), 2.0f);
+      p[1] = __fdiv_rn(__fadd_rn(p[1], pred_flip[src + 1]), 2.0f);
+      p[2] = __fdiv_rn(__fadd_rn(p[2], pred_flip[src + 2]), 2.0f);
+    }
+    for (int k = 0; k < 3; ++k) p[k] = __fmul_rn(p[k], scale);
+    if (merged)
+      for (int k = 0; k < 3; ++k) merged[(size_t)gid * 3 + k] = p[k];
+    if (!mask || mask[bt]) {
+      const float dx = p[0] - gt[(size_t)gid * 3 + 0], dy = p[1] - gt[(size_t)gid * 3 + 1],
+                  dz = p[2] - gt[(size_t)gid * 3 + 2];
+      err = sqrtf(dx * dx + dy * dy + dz * dz);
+      cnt = 1.f;
+    }
+  }
+  err = wave_sum(err);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0 && cnt > 0.f) {
+    atomicAdd(&sums[0], (double)err);
+    atomicAdd(&sums[1], (double)cnt);
+  }
+}
+
+hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, const uint8_t* mask, float scale,
+                            const int32_t* perm_dev, float* merged, double* sums, int B, int T, int J, hipStream_t s) {
+  const int total = B * T * J;
+  hipLaunchKernelGGL(k_tta_mpjpe, dim3((total + 255) / 256), dim3(256), 0, s, pred, pred_flip, gt, mask, scale, perm_dev,
+                     merged, sums, B * T, J);
+  return hipGetLastError();
+}
+
+}  // namespace d3d

@@ -1,0 +1,254 @@
+"""Python handle on one libd3d_hip engine (one per device).  PyTorch is used only as plumbing: device buffers,
+the current HIP stream and host<->device copies.  All arithmetic happens inside the library's HIP kernels."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spec import DenoiserConfig, denoiser_param_spec
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    def __init__(self, cfg: DenoiserConfig, precision: str = "fp32", device=None):
+        if not torch.cuda.is_available():
+            raise _lib.D3DError("diff3dhpe_amd needs a HIP device: the engine has no CPU path")
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.precision = precision
+        c = _lib.Config(cfg.num_frame, cfg.num_joints, cfg.in_chans, cfg.embed_dim, cfg.depth, cfg.num_heads,
+                        cfg.mlp_hidden, int(cfg.with_time_emb), int(cfg.seq2frame), _lib.PRECISIONS[precision])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().d3d_engine_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_B = 0
+        self.sampling_timesteps = None
+        self.weights_version = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().d3d_engine_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---------------------------------------------------------------- weights / schedule
+    def expected_weights(self):
+        L = _lib.lib()
+        out = []
+        for i in range(L.d3d_engine_num_weights(self._h)):
+            name, n = C.c_char_p(), C.c_int64()
+            _lib.check(L.d3d_engine_weight_info(self._h, i, C.byref(name), C.byref(n)))
+            out.append((name.value.decode(), n.value))
+        return out
+
+    def load_weights(self, sd: Mapping[str, object]) -> None:
+        """sd: denoiser tensors keyed by reference state-dict names WITHOUT the 'model.' prefix."""
+        L = _lib.lib()
+        for name, numel in self.expected_weights():
+            if name not in sd:
+                raise KeyError(f"missing weight {name}")
+            v = sd[name]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            _lib.check(L.d3d_engine_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+        if self.cfg.with_time_emb:
+            half = self.cfg.embed_dim // 2
+            # SinusoidalPosEmb's frequency table exactly as the host framework forms it (S2S:31-33)
+            freqs = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(torch.float32).numpy()
+            _lib.check(L.d3d_engine_set_time_freqs(self._h, freqs.ctypes.data_as(C.c_void_p), half))
+        with torch.cuda.device(self.device):
+            _lib.check(L.d3d_engine_commit_weights(self._h))
+        self.sampling_timesteps = None
+
+    def set_schedule(self, alphas_cumprod: torch.Tensor, sqrt_one_minus_alphas_cumprod: torch.Tensor,
+                     sampling_timesteps: int, eta: float, clip_denoised: bool,
+                     sqrt_alphas_cumprod: Optional[torch.Tensor] = None) -> None:
+        ac = np.ascontiguousarray(alphas_cumprod.detach().cpu().numpy(), dtype=np.float32)
+        so = np.ascontiguousarray(sqrt_one_minus_alphas_cumprod.detach().cpu().numpy(), dtype=np.float32)
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device)
+            _lib.check(_lib.lib().d3d_engine_set_schedule(self._h, ac.size, ac.ctypes.data_as(C.c_void_p),
+                                                         so.ctypes.data_as(C.c_void_p), int(sampling_timesteps),
+                                                         float(eta), int(bool(clip_denoised)), C.c_void_p(st.cuda_stream)))
+            if sqrt_alphas_cumprod is not None:
+                sa = np.ascontiguousarray(sqrt_alphas_cumprod.detach().cpu().numpy(), dtype=np.float32)
+                _lib.check(_lib.lib().d3d_engine_set_sqrt_alphas_cumprod(self._h, sa.ctypes.data_as(C.c_void_p), sa.size))
+        self.sampling_timesteps = int(sampling_timesteps)
+        self.eta = float(eta)
+
+    # ---------------------------------------------------------------- compute
+    def _workspace(self, B: int) -> torch.Tensor:
+        if self._ws is None or B > self._ws_B:
+            nbytes = _lib.lib().d3d_workspace_bytes(self._h, B)
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_B = B
+        return self._ws
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _out_frames(self) -> int:
+        return 1 if self.cfg.seq2frame else self.cfg.num_frame
+
+    def denoise(self, x2d: torch.Tensor, y: torch.Tensor, time: Optional[torch.Tensor]) -> torch.Tensor:
+        """forward_denoise on cat([x2d, y], -1): x2d (B,T,J,in), y (B,T,J,3) or (B,1,J,3) (broadcast over T), time (B,) or (1,)."""
+        cfg = self.cfg
+        B = x2d.shape[0]
+        assert tuple(x2d.shape) == (B, cfg.num_frame, cfg.num_joints, cfg.in_chans), x2d.shape
+        assert y.shape[0] == B and y.shape[1] in (1, cfg.num_frame) and tuple(y.shape[2:]) == (cfg.num_joints, 3), y.shape
+        x2d, y = _f32c(x2d, self.device), _f32c(y, self.device)
+        n_t, tdev = 0, None
+        if cfg.with_time_emb:
+            tdev = _f32c(time.reshape(-1), self.device)
+            n_t = tdev.numel()
+        out = torch.empty((B, self._out_frames(), cfg.num_joints, 3), dtype=torch.float32, device=self.device)
+        ws = self._workspace(B)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_denoise(self._h, _ptr(x2d), _ptr(y), int(y.shape[1]), _ptr(tdev), n_t, _ptr(out), B, _ptr(ws),
+                                              ws.numel(), self._stream()))
+        return out
+
+    def ddim_sample(self, x2d: torch.Tensor, init_noise: torch.Tensor, step_noise: Optional[torch.Tensor] = None,
+                    trajectory: bool = False):
+        """The whole S-step DDIM loop. Returns y0, or (y0, x_reverse_diffusion, x_start_est) with trajectory=True."""
+        cfg = self.cfg
+        if self.sampling_timesteps is None:
+            raise _lib.D3DError("set_schedule() must be called before ddim_sample()")
+        B, S = x2d.shape[0], self.sampling_timesteps
+        Fo = self._out_frames()
+        assert tuple(x2d.shape) == (B, cfg.num_frame, cfg.num_joints, cfg.in_chans), x2d.shape
+        assert tuple(init_noise.shape) == (B, Fo, cfg.num_joints, 3), init_noise.shape
+        x2d, init_noise = _f32c(x2d, self.device), _f32c(init_noise, self.device)
+        if step_noise is not None:
+            assert tuple(step_noise.shape) == (S, B, Fo, cfg.num_joints, 3), step_noise.shape
+            step_noise = _f32c(step_noise, self.device)
+        out = torch.empty((B, Fo, cfg.num_joints, 3), dtype=torch.float32, device=self.device)
+        rev = x0s = None
+        if trajectory:
+            rev = torch.empty((B, Fo, cfg.num_joints, 3, S), dtype=torch.float32, device=self.device)
+            x0s = torch.empty_like(rev)
+        ws = self._workspace(B)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_ddim_sample(self._h, _ptr(x2d), _ptr(init_noise), _ptr(step_noise), _ptr(out),
+                                                  _ptr(rev), _ptr(x0s), B, _ptr(ws), ws.numel(), self._stream()))
+        return (out, rev, x0s) if trajectory else out
+
+    # ---------------------------------------------------------------- profiling (HIP events inside the library)
+    def set_profiling(self, on: bool) -> None:
+        _lib.check(_lib.lib().d3d_engine_set_profiling(self._h, int(on)))
+
+    def profile_reset(self) -> None:
+        _lib.check(_lib.lib().d3d_engine_profile_reset(self._h))
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        """Per kernel class: total event-timed ms, launches, algorithmic flops and bytes of the launches timed."""
+        L = _lib.lib()
+        out = {}
+        for c in range(_lib.KC_COUNT):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(L.d3d_engine_profile_read(self._h, c, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[L.d3d_kernel_class_name(c).decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+    def time_embedding(self, times: torch.Tensor) -> torch.Tensor:
+        """Per-block time vectors for the given timesteps: (n, 2*depth, D), execution order STE0, TTE0, STE1, ..."""
+        cfg = self.cfg
+        t = _f32c(times.reshape(-1), self.device)
+        n = t.numel()
+        out = torch.empty((n, 2 * cfg.depth, cfg.embed_dim), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(n * 5 * cfg.embed_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_op_time_embedding(self._h, _ptr(t), n, _ptr(out), _ptr(scratch), self._stream()))
+        return out
+
+    def q_sample(self, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        B = x_start.shape[0]
+        xs, nz = _f32c(x_start, self.device), _f32c(noise, self.device)
+        ti = t.detach().to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty_like(xs)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_q_sample(self._h, _ptr(xs), _ptr(nz), _ptr(ti), _ptr(out), B, xs.numel() // B,
+                                               self._stream()))
+        return out
+
+
+# ---------------------------------------------------------------------------------------- stand-alone op wrappers
+def op_linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+              epi: str = "none", precision: str = "fp32") -> torch.Tensor:
+    epi_id = {"none": 0, "gelu": 1, "residual": 2}[epi]
+    M, K = A.shape
+    N = W.shape[0]
+    dev = A.device
+    A, W = _f32c(A, dev), _f32c(W, dev)
+    bias = _f32c(bias, dev) if bias is not None else None
+    residual = _f32c(residual, dev) if residual is not None else None
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_op_linear(_ptr(A), _ptr(W), _ptr(bias), _ptr(residual), _ptr(out), M, N, K, epi_id,
+                                            _lib.PRECISIONS[precision], st))
+    return out
+
+
+def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    dev = x.device
+    D = x.shape[-1]
+    x2 = _f32c(x, dev).reshape(-1, D)
+    out = torch.empty_like(x2)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_op_layernorm(_ptr(x2), _ptr(_f32c(gamma, dev)), _ptr(_f32c(beta, dev)), _ptr(out),
+                                               x2.shape[0], D, float(eps), st))
+    return out.reshape(x.shape)
+
+
+def op_attention(qkv: torch.Tensor, B: int, T: int, J: int, H: int, temporal: bool, precision: str = "fp32",
+                 force_generic: bool = False) -> torch.Tensor:
+    """qkv: (B*T*J, 3*D) packed GEMM output -> (B*T*J, D)."""
+    dev = qkv.device
+    D = qkv.shape[-1] // 3
+    q = _f32c(qkv, dev).reshape(B * T * J, 3 * D)
+    out = torch.empty((B * T * J, D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_op_attention(_ptr(q), _ptr(out), B, T, J, D, H, int(temporal),
+                                               _lib.PRECISIONS[precision], int(force_generic), st))
+    return out
+
+
+def tta_mpjpe(pred: torch.Tensor, pred_flip: Optional[torch.Tensor], gt: torch.Tensor, target_mask: Optional[torch.Tensor],
+              scale: float, joints_left, joints_right, want_merged: bool = False):
+    """evaluate() tail on device (RUN:583-590, LOSS:15-22). Returns (sum_err, n_joints[, merged])."""
+    dev = pred.device
+    B, T, J, _ = pred.shape
+    p = _f32c(pred, dev)
+    pf = _f32c(pred_flip, dev) if pred_flip is not None else None
+    g = _f32c(gt, dev)
+    m = target_mask.detach().to(device=dev, dtype=torch.uint8).contiguous() if target_mask is not None else None
+    merged = torch.empty_like(p) if want_merged else None
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    jl = (C.c_int32 * len(joints_left))(*joints_left)
+    jr = (C.c_int32 * len(joints_right))(*joints_right)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_tta_mpjpe(_ptr(p), _ptr(pf), _ptr(g), _ptr(m), float(scale), jl, jr, len(joints_left),
+                                            _ptr(merged), _ptr(sums), B, T, J, st))
+    s = sums.cpu()
+    return (float(s[0]), int(s[1]), merged) if want_merged else (float(s[0]), int(s[1]))

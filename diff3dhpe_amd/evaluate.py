@@ -1,0 +1,81 @@
+"""evaluate()-equivalent harness (reference RUN:535-654) on top of the engine, for synthetic or user-supplied loaders.
+
+Per batch it reproduces the reference's data flow: two full DDIM samplings (normal + horizontally flipped 2D input,
+RUN:577-582), un-flip/average/de-normalise/mask (RUN:583-590) and the frame-weighted MPJPE running mean
+(RUN:602-606, LOSS:15-22) -- the merge and the error reduction run in one HIP kernel (d3d_tta_mpjpe).
+With torch.distributed initialised (one process per GPU) each rank samples its shard of the batch and the predicted
+sequences are all-gathered (RCCL) before the reduction.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, Iterable, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import parallel
+from .engine import tta_mpjpe
+
+H36M_JOINTS_LEFT = [4, 5, 6, 11, 12, 13]     # after remove_joints (reference common/h36m_dataset.py:20-21,288)
+H36M_JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]
+
+
+def flip_2d(x2d: torch.Tensor, joints_left: Sequence[int], joints_right: Sequence[int]) -> torch.Tensor:
+    """Horizontal-flip augmentation of a 2D window (what the reference dataset hands over as inputs_2d_flip)."""
+    f = x2d.clone()
+    f[..., 0] *= -1
+    f[:, :, list(joints_left) + list(joints_right)] = f[:, :, list(joints_right) + list(joints_left)]
+    return f
+
+
+@torch.no_grad()
+def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, scale: float = 1.0,
+             joints_left: Sequence[int] = H36M_JOINTS_LEFT, joints_right: Sequence[int] = H36M_JOINTS_RIGHT,
+             test_time_augmentation: bool = True, device: Optional[torch.device] = None, verbose: bool = True):
+    """batches yield dicts with inputs_2d (B,T,J,2), inputs_3d (B,T,J,3) [ground truth, metres], optional
+    inputs_2d_flip, target_mask (B,T) bool, init_noise / init_noise_flip.  Returns a dict with MPJPE (mm), frames, seconds."""
+    model_diffusion.eval()
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    tot_err, tot_cnt, secs, frames = 0.0, 0, 0.0, 0
+    for batch in batches:
+        x2d = batch["inputs_2d"]
+        gt = batch["inputs_3d"]
+        B = x2d.shape[0]
+        mask = batch.get("target_mask")
+        x2d_f = batch.get("inputs_2d_flip")
+        if test_time_augmentation and x2d_f is None:
+            x2d_f = flip_2d(x2d, joints_left, joints_right)
+        lo, hi = parallel.shard_bounds(B, rank, world)
+        sl = slice(lo, hi)
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        shape = gt[sl].shape
+        _, pred = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d[sl].to(dev), output_loss=False,
+                                  init_noise=None if batch.get("init_noise") is None else batch["init_noise"][sl])
+        pred_f = None
+        if test_time_augmentation:
+            _, pred_f = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d_f[sl].to(dev), output_loss=False,
+                                        init_noise=None if batch.get("init_noise_flip") is None else batch["init_noise_flip"][sl])
+        gsl = sl
+        if world > 1:   # the one exchange step: all-gather the predicted sequences; every rank then reduces the full batch
+            pred = parallel.all_gather_pred(pred, B)
+            if pred_f is not None:
+                pred_f = parallel.all_gather_pred(pred_f, B)
+            gsl = slice(0, B)
+        err, cnt = tta_mpjpe(pred, pred_f, gt[gsl].to(dev), None if mask is None else mask[gsl].to(dev), scale,
+                             list(joints_left), list(joints_right))
+        torch.cuda.synchronize(dev)
+        secs += time.time() - t0
+        tot_err += err
+        tot_cnt += cnt
+        frames += cnt // shape[2]
+    e1 = tot_err / max(tot_cnt, 1) * 1000.0
+    if verbose and rank == 0:
+        print('eval_frame:', frames)
+        print('inference_time:', secs / 60, 'min')
+        print('inference_speed:', frames / max(secs, 1e-9), 'frame/s')
+        print('Protocol #1 Error (MPJPE):', e1, 'mm')
+    return {"mpjpe_mm": e1, "frames": frames, "seconds": secs}

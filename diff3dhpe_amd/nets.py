@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference's denoiser classes and registry.
+
+Same constructor signature, same ``state_dict`` keys/shapes, same ``forward_denoise`` contract as
+``common/nets/model_conditional_diffusion_mixste_s2s_grand_linLift.py:139-257`` (seq2seq) and
+``..._s2f_grand_linLift.py:139-266`` (seq2frame), selected by name like ``common/nets/load_net.py:5-10`` -- but the
+modules below only *hold parameters*.  No layer here has a PyTorch forward: ``forward_denoise`` hands the tensors to
+the HIP engine (libd3d_hip.so) and fails loudly when there is no HIP device.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import Engine
+from .spec import DenoiserConfig, S2F_NAME, S2S_NAME, denoiser_param_spec
+
+
+class _Holder(nn.Module):
+    """Parameter container; calling it is a bug (the engine does the math)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("diff3dhpe_amd modules are parameter holders; use forward_denoise / GaussianDiffusion")
+
+
+class _AttnParams(_Holder):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _MlpParams(_Holder):
+    def __init__(self, dim: int, hidden: int):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _BlockParams(_Holder):
+    """Keys: norm1, attn.{qkv,proj}, norm2, time_mlp.1, mlp.{fc1,fc2} (reference Block, S2S:90-109)."""
+
+    def __init__(self, dim: int, hidden: int, time_dim: Optional[int]):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _AttnParams(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_dim, dim)) if time_dim else None
+        self.mlp = _MlpParams(dim, hidden)
+
+
+class _MixSTEDenoiser(nn.Module):
+    _seq2frame = False
+    precision = "fp32"   # engine arithmetic mode; class-level default, override per instance before first use
+
+    def __init__(self, num_frame=9, num_joints=17, in_chans=2, embed_dim=32, depth=4, num_heads=8, mlp_ratio=2.,
+                 qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None,
+                 with_time_emb=True, **kwargs):
+        super().__init__()
+        if not qkv_bias:
+            raise NotImplementedError("qkv_bias=False is not supported by the HIP engine (the reference runner always passes True, RUN:179)")
+        if qk_scale is not None:
+            raise NotImplementedError("qk_scale override is not supported (reference runner passes None, RUN:179)")
+        if norm_layer is not None:
+            raise NotImplementedError("custom norm_layer is not supported (reference default LayerNorm eps=1e-6, S2S:183)")
+        # drop_rate / attn_drop_rate / drop_path_rate only act in training mode (S2S:123-128), which is out of scope.
+        self.cfg = DenoiserConfig(num_frame=num_frame, num_joints=num_joints, in_chans=in_chans, embed_dim=embed_dim,
+                                  depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio, with_time_emb=bool(with_time_emb),
+                                  seq2frame=self._seq2frame)
+        D, Dm = embed_dim, self.cfg.mlp_hidden
+        time_dim = 2 * D if with_time_emb else None
+        # index 0 of the reference Sequential is SinusoidalPosEmb (no parameters); keep the indices 1 and 3
+        self.time_mlp = nn.Sequential(_Holder(), nn.Linear(D, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim)) \
+            if with_time_emb else None
+        self.fusion_layer = nn.Linear(3 + in_chans, D)
+        self.block_depth = depth
+        self.Spatial_pos_embed = nn.Parameter(torch.zeros(1, num_joints, D))
+        self.STEblocks = nn.ModuleList([_BlockParams(D, Dm, time_dim) for _ in range(depth)])
+        self.Spatial_norm = nn.LayerNorm(D, eps=1e-6)
+        self.Temporal_pos_embed = nn.Parameter(torch.zeros(1, num_frame, D))
+        self.TTEblocks = nn.ModuleList([_BlockParams(D, Dm, time_dim) for _ in range(depth)])
+        self.Temporal_norm = nn.LayerNorm(D, eps=1e-6)
+        if self._seq2frame:
+            self.weighted_mean = nn.Conv1d(in_channels=num_frame, out_channels=1, kernel_size=1)
+        self.head = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, 3))
+        # engines are shared (by reference) with DataParallel replicas, keyed by device index
+        self._engines: Dict[int, Engine] = {}
+        self._engine_sig: Dict[int, object] = {}
+        self._src_sig = None
+
+    # ------------------------------------------------------------------ engine management
+    def _tensor(self, name: str) -> torch.Tensor:
+        # attribute walk instead of state_dict(): DataParallel replicas carry plain tensors, not nn.Parameters
+        obj = self
+        for part in name.split("."):
+            obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+        return obj
+
+    def _named_tensors(self):
+        return {name: self._tensor(name) for name, _, _, _ in denoiser_param_spec(self.cfg)}
+
+    def _param_signature(self):
+        return tuple((t.data_ptr(), t._version) for t in self._named_tensors().values())
+
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel re-broadcasts the parameters on every call (RUN:217); remember the source tensors' identity
+        # so a replica's engine re-uploads weights only when the source module's weights actually changed.
+        replica = super()._replicate_for_data_parallel()
+        replica._src_sig = self._param_signature()
+        return replica
+
+    def engine_for(self, device: torch.device) -> Engine:
+        if device.type != "cuda":
+            raise _lib.D3DError("engine_for() needs a HIP device")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        eng = self._engines.get(idx)
+        if eng is None or eng.precision != self.precision:
+            eng = Engine(self.cfg, precision=self.precision, device=torch.device("cuda", idx))
+            self._engines[idx] = eng
+            self._engine_sig[idx] = None
+        sig = self._src_sig if self._src_sig is not None else self._param_signature()
+        if self._engine_sig.get(idx) != sig:
+            eng.load_weights(self._named_tensors())
+            self._engine_sig[idx] = sig
+        return eng
+
+    def _compute_device(self, *tensors) -> torch.device:
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                return t.device
+        p = self._tensor("fusion_layer.weight")
+        if p.is_cuda:
+            return p.device
+        if torch.cuda.is_available():   # CPU tensors in, HIP compute: still the engine, never a CPU fallback
+            return torch.device("cuda", torch.cuda.current_device())
+        raise _lib.D3DError("no HIP device available: diff3dhpe_amd has no CPU execution path")
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def forward_denoise(self, x: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
+        """x: (B,T,J,in_chans+3) = cat([2D pose, noisy 3D pose], -1); time: (B,) long|float -> (B,T,J,3) [(B,1,J,3) S2F]."""
+        dev = self._compute_device(x)
+        eng = self.engine_for(dev)
+        c = self.cfg.in_chans
+        out = eng.denoise(x[..., :c], x[..., c:], time if self.cfg.with_time_emb else None)
+        return out.to(x.device)
+
+    def forward(self, x, time):
+        return self.forward_denoise(x, time)
+
+
+class ConditionalDiffusionMixSTES2SGRANDLinLift(_MixSTEDenoiser):
+    _seq2frame = False
+
+
+class ConditionalDiffusionMixSTES2FGRANDLinLift(_MixSTEDenoiser):
+    _seq2frame = True
+
+
+def HPE_model(MODEL_NAME: str):
+    """Registry by class name (reference common/nets/load_net.py:5-10); unknown names raise KeyError like the reference."""
+    models = {
+        S2S_NAME: ConditionalDiffusionMixSTES2SGRANDLinLift,
+        S2F_NAME: ConditionalDiffusionMixSTES2FGRANDLinLift,
+    }
+    return models[MODEL_NAME]

@@ -83,6 +83,9 @@ int d3d_engine_set_schedule(d3d_engine* e, int32_t num_timesteps, const float* a
                             const float* sqrt_one_minus_alphas_cumprod_host, int32_t sampling_timesteps, float eta,
                             int32_t clip_denoised, void* stream);
 
+/* Optional fp32 buffer `sqrt_alphas_cumprod` (DIFF:155) -- needed only by d3d_q_sample.  Call after set_schedule. */
+int d3d_engine_set_sqrt_alphas_cumprod(d3d_engine* e, const float* host, int32_t n);
+
 /* Host-only, bit-exact restatement of `torch.linspace(-1, N-1, S+1).int()` reversed (DIFF:270-272): writes S+1 values. */
 int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out);
 
@@ -93,10 +96,11 @@ size_t d3d_workspace_bytes(const d3d_engine* e, int32_t B);
 
 /* forward_denoise (S2S:249-257 / S2F:253-266) on cat([x2d, y], -1) (DIFF:255).  times_dev: n_times fp32 timesteps on
  * the device, n_times == 1 (broadcast, the sampling case DIFF:254) or == B (per-row, the p_losses case DIFF:392-408).
- * Ignored when with_time_emb == 0.  y is (B,T,J,3), or (B,1,J,3) for seq2frame (DIFF-S2F:281 repeat is done in-kernel).
- * x0 receives the raw network output (no clamp). */
-int d3d_denoise(d3d_engine* e, const float* x2d_dev, const float* y_dev, const float* times_dev, int32_t n_times,
-                float* x0_dev, int32_t B, void* ws_dev, size_t ws_bytes, void* stream);
+ * Ignored when with_time_emb == 0.  y is (B,y_frames,J,3) with y_frames == T, or == 1 to have the kernel broadcast one
+ * frame over T (the seq2frame repeat of DIFF-S2F:281).  x0 receives the raw network output (no clamp):
+ * (B,T,J,3), or (B,1,J,3) for a seq2frame engine. */
+int d3d_denoise(d3d_engine* e, const float* x2d_dev, const float* y_dev, int32_t y_frames, const float* times_dev,
+                int32_t n_times, float* x0_dev, int32_t B, void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ddim_sample_loop (DIFF:262-300; DIFF-S2F:263-300).  init_noise replaces torch.randn(target_shape) (DIFF:275);
  * step_noise_dev (nullable; required when eta != 0) is (S, B,T',J,3): the per-step randn_like draws (DIFF:293).
@@ -119,7 +123,28 @@ int d3d_tta_mpjpe(const float* pred_dev, const float* pred_flip_dev, const float
                   float scale, const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr,
                   float* merged_dev, double* sums_dev, int32_t B, int32_t T, int32_t J, void* stream);
 
+/* ---- per-kernel-class timing (HIP events recorded on the launch stream around every kernel of d3d_denoise /
+ * d3d_ddim_sample while enabled; used by bench.py for the roofline figures).  flops / bytes are the ALGORITHMIC counts
+ * of the launches timed, total_ms the sum of their event-pair durations. ------------------------ */
+#define D3D_KC_LINEAR 0
+#define D3D_KC_ATTN_SPATIAL 1
+#define D3D_KC_ATTN_TEMPORAL 2
+#define D3D_KC_LAYERNORM 3
+#define D3D_KC_EMBED 4
+#define D3D_KC_HEAD 5
+#define D3D_KC_OTHER 6
+#define D3D_KC_COUNT 7
+int d3d_engine_set_profiling(d3d_engine* e, int32_t on);
+int d3d_engine_profile_reset(d3d_engine* e);
+int d3d_engine_profile_read(d3d_engine* e, int32_t kernel_class, double* total_ms, int64_t* launches, double* flops,
+                            double* bytes);
+const char* d3d_kernel_class_name(int32_t kernel_class);
+
 /* ---- single-op hooks: the same kernels the engine launches, exposed for the parity tests -------------------------- */
+/* Time-embedding table (S2S:29-36,169-174 trunk, then every Block.time_mlp S2S:104-107) for n fp32 timesteps on the
+ * device: out (n, 2*depth, D) in execution order STE0, TTE0, STE1, ...  scratch: n*(D + 4*D) floats. */
+int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, float* out_dev, float* scratch_dev,
+                          void* stream);
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); epi 0 none, 1 exact-erf GELU, 2 add residual R[M,N] (R may alias C). */
 int d3d_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
                   int32_t M, int32_t N, int32_t K, int32_t epi, int32_t precision, void* stream);
