@@ -2,6 +2,7 @@
 // Not part of the public ABI (that is include/d3d.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace d3d {
@@ -12,6 +13,12 @@ enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 // C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); all row-major fp32, K % 32 == 0.
 hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
                              int K, int epi, hipStream_t s);
+
+// ---- kernels_gemm_f16x3.hip --------------------------------------------------------------------------------------
+// Same contract, fp32-accurate product from 3 fp16 MFMAs; W given as two fp16 planes made by split_weight_f16x3().
+hipError_t launch_linear_f16x3(const float* A, const void* Wh, const void* Wl, const float* bias, const float* R, float* C,
+                               int M, int N, int K, int epi, hipStream_t s);
+void split_weight_f16x3(const float* w, size_t n, uint16_t* hi, uint16_t* lo);
 
 // ---- kernels_elem.hip -------------------------------------------------------------------------------------------
 // Row LayerNorm; optionally also writes a second LayerNorm of the first result (post-norm -> next block's norm1).

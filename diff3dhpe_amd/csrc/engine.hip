@@ -41,6 +41,9 @@ struct WeightSlot {
 
 struct BlockW {
   const float *n1g, *n1b, *qkvw, *qkvb, *projw, *projb, *n2g, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
+  // F16X3 mode: fp16 hi/lo planes of the four GEMM weights (same [N][K] layout)
+  const uint16_t *qkv_h = nullptr, *qkv_l = nullptr, *proj_h = nullptr, *proj_l = nullptr;
+  const uint16_t *fc1_h = nullptr, *fc1_l = nullptr, *fc2_h = nullptr, *fc2_l = nullptr;
 };
 
 }  // namespace
@@ -56,6 +59,7 @@ struct d3d_engine {
 
   float* arena = nullptr;  // all weights, device
   size_t arena_floats = 0;
+  uint16_t* arena16 = nullptr;  // F16X3: hi/lo planes of the GEMM weights
   std::vector<BlockW> blk;  // execution order: STE0, TTE0, STE1, ...
   const float *fus_w = nullptr, *fus_b = nullptr, *spos = nullptr, *tpos = nullptr;
   const float *sn_g = nullptr, *sn_b = nullptr, *tn_g = nullptr, *tn_b = nullptr;
@@ -86,7 +90,7 @@ struct d3d_engine {
   ~d3d_engine() {
     for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
-    (void)hipFree(arena); (void)hipFree(tblk_w); (void)hipFree(tblk_b); (void)hipFree(freqs_dev);
+    (void)hipFree(arena); (void)hipFree(arena16); (void)hipFree(tblk_w); (void)hipFree(tblk_b); (void)hipFree(freqs_dev);
     (void)hipFree(ac_dev); (void)hipFree(somac_dev); (void)hipFree(sqrt_ac_dev); (void)hipFree(temb_sched);
   }
 };
@@ -242,8 +246,11 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
     HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.X, B, T, J, D, e->cfg.in_chans,
                          y_bcast, s));
   }
-  auto linear = [&](const float* A, const float* W, const float* bias, const float* R, float* C, int N, int K, int epi) -> hipError_t {
+  const bool x3 = e->cfg.precision == D3D_PREC_F16X3;
+  auto linear = [&](const float* A, const float* W, const uint16_t* Wh, const uint16_t* Wl, const float* bias, const float* R,
+                    float* C, int N, int K, int epi) -> hipError_t {
     Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), s);
+    if (x3) return launch_linear_f16x3(A, Wh, Wl, bias, R, C, M, N, K, epi, s);
     return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
   };
   auto lnorm = [&](const LnArgs& a) -> hipError_t {
@@ -259,22 +266,22 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
-    HIP_TRY(linear(w.HN, bw.qkvw, bw.qkvb, nullptr, w.QKV, 3 * D, D, EPI_NONE));
+    HIP_TRY(linear(w.HN, bw.qkvw, bw.qkv_h, bw.qkv_l, bw.qkvb, nullptr, w.QKV, 3 * D, D, EPI_NONE));
     {
       const int N = temporal ? T : J;
       Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
       int rc = attention(e, w.QKV, w.HN, B, temporal, s);
       if (rc) return rc;
     }
-    HIP_TRY(linear(w.HN, bw.projw, bw.projb, w.X, w.X, D, D, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HN, bw.projw, bw.proj_h, bw.proj_l, bw.projb, w.X, w.X, D, D, EPI_RESIDUAL));
     {  // h = norm2(x)
       LnArgs a{};
       a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       HIP_TRY(lnorm(a));
     }
-    HIP_TRY(linear(w.HN, bw.fc1w, bw.fc1b, nullptr, w.HID, e->Dm, D, EPI_GELU));
-    HIP_TRY(linear(w.HID, bw.fc2w, bw.fc2b, w.X, w.X, D, e->Dm, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HN, bw.fc1w, bw.fc1_h, bw.fc1_l, bw.fc1b, nullptr, w.HID, e->Dm, D, EPI_GELU));
+    HIP_TRY(linear(w.HID, bw.fc2w, bw.fc2_h, bw.fc2_l, bw.fc2b, w.X, w.X, D, e->Dm, EPI_RESIDUAL));
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = next.norm1(x)
       LnArgs a{};
       a.x = w.X; a.y = w.X;
@@ -361,7 +368,8 @@ int d3d_engine_create(const d3d_config* c, d3d_engine** out) {
     const int dh = c->embed_dim / c->num_heads;
     if (dh != 4 && dh != 8 && dh != 16 && dh != 32 && dh != 64) return fail(D3D_EUNSUP, "head_dim must be 4,8,16,32 or 64");
   }
-  if (c->precision != D3D_PREC_FP32) return fail(D3D_EUNSUP, "only D3D_PREC_FP32 is implemented in this build");
+  if (c->precision != D3D_PREC_FP32 && c->precision != D3D_PREC_F16X3)
+    return fail(D3D_EUNSUP, "precision must be D3D_PREC_FP32 or D3D_PREC_F16X3 in this build");
   d3d_engine* e = new d3d_engine();
   e->cfg = *c;
   e->T = c->num_frame; e->J = c->num_joints; e->D = c->embed_dim; e->H = c->num_heads; e->Dm = c->mlp_hidden;
@@ -438,6 +446,29 @@ int d3d_engine_commit_weights(d3d_engine* e) {
   for (int i = 0; i < e->depth; ++i) {  // execution order (S2S:225-245): STE_i then TTE_i
     e->blk.push_back(blockw("STEblocks." + std::to_string(i)));
     e->blk.push_back(blockw("TTEblocks." + std::to_string(i)));
+  }
+  if (e->cfg.precision == D3D_PREC_F16X3) {
+    const size_t D = e->D, Dm = e->Dm;
+    const size_t per_blk = 2 * (3 * D * D + D * D + 2 * Dm * D);   // hi + lo of qkv, proj, fc1, fc2
+    std::vector<uint16_t> host(per_blk * e->nblk);
+    if (e->arena16) { (void)hipFree(e->arena16); e->arena16 = nullptr; }
+    HIP_TRY(hipMalloc(&e->arena16, host.size() * sizeof(uint16_t)));
+    size_t o = 0;
+    for (int k = 0; k < e->nblk; ++k) {
+      const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2);
+      auto plane = [&](const std::string& name, size_t n, const uint16_t*& hi, const uint16_t*& lo) {
+        const WeightSlot& ws = e->slots[e->index[name]];
+        split_weight_f16x3(ws.host.data(), n, host.data() + o, host.data() + o + n);
+        hi = e->arena16 + o; lo = e->arena16 + o + n;
+        o += 2 * n;
+      };
+      BlockW& b = e->blk[k];
+      plane(p + ".attn.qkv.weight", 3 * D * D, b.qkv_h, b.qkv_l);
+      plane(p + ".attn.proj.weight", D * D, b.proj_h, b.proj_l);
+      plane(p + ".mlp.fc1.weight", Dm * D, b.fc1_h, b.fc1_l);
+      plane(p + ".mlp.fc2.weight", D * Dm, b.fc2_h, b.fc2_l);
+    }
+    HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   e->fus_w = wptr(e, "fusion_layer.weight"); e->fus_b = wptr(e, "fusion_layer.bias");
   e->spos = wptr(e, "Spatial_pos_embed"); e->tpos = wptr(e, "Temporal_pos_embed");
@@ -684,10 +715,29 @@ int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, floa
 
 int d3d_op_linear(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M, int32_t N,
                   int32_t K, int32_t epi, int32_t precision, void* stream) {
-  if (precision != D3D_PREC_FP32) return fail(D3D_EUNSUP, "precision not implemented");
+  if (precision != D3D_PREC_FP32 && precision != D3D_PREC_F16X3) return fail(D3D_EUNSUP, "precision not implemented");
   if (!A || !W || !C) return fail(D3D_EINVAL, "null tensor");
   if (K % 32) return fail(D3D_EUNSUP, "K must be a multiple of 32");
-  HIP_TRY(launch_linear_f32(A, W, bias, R, C, M, N, K, epi, reinterpret_cast<hipStream_t>(stream)));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (precision == D3D_PREC_FP32) {
+    HIP_TRY(launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s));
+    return D3D_OK;
+  }
+  // test hook only: split the device weight on the host, upload the planes, run, and free (synchronous)
+  const size_t n = (size_t)N * K;
+  std::vector<float> wh(n);
+  std::vector<uint16_t> planes(2 * n);
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(wh.data(), W, n * sizeof(float), hipMemcpyDeviceToHost));
+  split_weight_f16x3(wh.data(), n, planes.data(), planes.data() + n);
+  uint16_t* dev = nullptr;
+  HIP_TRY(hipMalloc(&dev, planes.size() * sizeof(uint16_t)));
+  hipError_t e1 = hipMemcpy(dev, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+  hipError_t e2 = (e1 == hipSuccess) ? launch_linear_f16x3(A, dev, dev + n, bias, R, C, M, N, K, epi, s) : e1;
+  hipError_t e3 = hipStreamSynchronize(s);
+  (void)hipFree(dev);
+  HIP_TRY(e2);
+  HIP_TRY(e3);
   return D3D_OK;
 }
 

@@ -28,7 +28,7 @@ def hashed(name, shape, seed, scale=1.0):
     return torch.from_numpy((scale * hash_uniform(name, n, seed)).astype(np.float32).reshape(shape))
 
 
-def build_product(cfg, seed, sampling=9, eta=0.0, clip=True, device="cuda"):
+def build_product(cfg, seed, sampling=9, eta=0.0, clip=True, device="cuda", precision="fp32"):
     """HPE_model + GaussianDiffusion of the product with the seeded weights, on `device`."""
     import diff3dhpe_amd as d3d
     name = d3d.S2F_NAME if cfg.seq2frame else d3d.S2S_NAME
@@ -36,6 +36,7 @@ def build_product(cfg, seed, sampling=9, eta=0.0, clip=True, device="cuda"):
                               embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
                               qkv_bias=True, qk_scale=None, drop_path_rate=0.1, with_time_emb=cfg.with_time_emb)
     net.load_state_dict(torch_sd(cfg, seed), strict=True)
+    net.precision = precision
     diff = d3d.GaussianDiffusion(model=net, timesteps=1000, sampling_timesteps=sampling, loss_type="l2",
                                  clip_denoised=clip, beta_schedule="cosine", ddim_sampling_eta=eta, clipLoss=True).eval()
     if device != "cpu":

@@ -17,9 +17,11 @@ def _eng():
     return engine
 
 
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 96, 32), (1000, 1536, 512), (2066, 512, 1024), (17, 64, 64),
                                    (4131, 1024, 512), (129, 130, 96)])
-def test_linear_fp32_matches_fp64(M, N, K):
+def test_linear_matches_fp64(M, N, K, prec):
+    """Both GEMM paths must sit at fp32-rounding distance from the fp64 product (F16X3 = 3 fp16 MFMAs on hi/lo splits)."""
     E = _eng()
     A = hashed(f"A{M}", (M, K), 11, 2.0).cuda()
     W = hashed(f"W{N}", (N, K), 12, 1.0 / np.sqrt(K)).cuda()
@@ -27,29 +29,43 @@ def test_linear_fp32_matches_fp64(M, N, K):
     R = hashed(f"R{M}", (M, N), 14, 1.0).cuda()
     ref = A.double() @ W.double().t() + b.double()
     tol = 2e-6 * np.sqrt(K / 32)
-    assert maxabs(E.op_linear(A, W, b), ref.cpu()) < tol
-    assert maxabs(E.op_linear(A, W, None), (ref - b.double()).cpu()) < tol
-    assert maxabs(E.op_linear(A, W, b, epi="gelu"), F.gelu(ref).cpu()) < tol
-    assert maxabs(E.op_linear(A, W, b, residual=R, epi="residual"), (ref + R.double()).cpu()) < tol
+    assert maxabs(E.op_linear(A, W, b, precision=prec), ref.cpu()) < tol
+    assert maxabs(E.op_linear(A, W, None, precision=prec), (ref - b.double()).cpu()) < tol
+    assert maxabs(E.op_linear(A, W, b, epi="gelu", precision=prec), F.gelu(ref).cpu()) < tol
+    assert maxabs(E.op_linear(A, W, b, residual=R, epi="residual", precision=prec), (ref + R.double()).cpu()) < tol
 
 
-def test_linear_identity_with_asymmetric_weight():
+def test_linear_f16x3_dynamic_range():
+    """hi/lo split must survive small and large activations / weights (scales 2^3 and 2^12 keep lo a normal fp16)."""
+    E = _eng()
+    for a_scale, w_scale in ((1e-3, 0.05), (30.0, 0.05), (1.0, 1e-3), (200.0, 0.5)):
+        A = hashed("Adyn", (256, 512), 5, a_scale).cuda()
+        W = hashed("Wdyn", (256, 512), 6, w_scale).cuda()
+        ref = A.double() @ W.double().t()
+        got = E.op_linear(A, W, None, precision="f16x3")
+        scale = ref.abs().max().item()
+        assert maxabs(got, ref.cpu()) < 3e-6 * scale, (a_scale, w_scale)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_linear_identity_with_asymmetric_weight(prec):
     """A = I against an asymmetric W catches a transposed C/D map (cdna guide section 3)."""
     E = _eng()
     K = 64
     A = torch.eye(K, device="cuda")
-    W = (torch.arange(96 * K, dtype=torch.float32).reshape(96, K) % 251).cuda()
-    out = E.op_linear(A, W, None)
+    W = ((torch.arange(96 * K, dtype=torch.float32).reshape(96, K) % 13) * 0.25).cuda()
+    out = E.op_linear(A, W, None, precision=prec)
     assert torch.equal(out.cpu(), W.t().cpu())
 
 
-def test_linear_bit_reproducible_and_row_independent():
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_linear_bit_reproducible_and_row_independent(prec):
     E = _eng()
     A = hashed("Arep", (777, 512), 1, 2.0).cuda()
     W = hashed("Wrep", (512, 512), 2, 0.05).cuda()
-    o1, o2 = E.op_linear(A, W, None), E.op_linear(A, W, None)
+    o1, o2 = E.op_linear(A, W, None, precision=prec), E.op_linear(A, W, None, precision=prec)
     assert torch.equal(o1, o2)
-    assert torch.equal(E.op_linear(A[100:229].contiguous(), W, None), o1[100:229])   # tile position must not matter
+    assert torch.equal(E.op_linear(A[100:229].contiguous(), W, None, precision=prec), o1[100:229])   # tile position must not matter
 
 
 @pytest.mark.parametrize("rows,D,eps", [(5, 32, 1e-6), (1000, 512, 1e-6), (333, 512, 1e-5), (64, 1024, 1e-6), (3, 128, 1e-6)])

@@ -42,11 +42,15 @@ DENOISE = [("small_T81", cfg_small(81)), ("full_T27", cfg_full(27)), ("full_T81"
            ("notemb_T27", cfg_full(27, with_time_emb=False)), ("small_s2f_T27", cfg_small(27, seq2frame=True))]
 
 
+PRECS = ["fp32", "f16x3"]
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag,cfg", DENOISE, ids=[d[0] for d in DENOISE])
-def test_forward_denoise_golden(tag, cfg):
+def test_forward_denoise_golden(tag, cfg, prec):
     g = gold("denoise_" + tag)
     B = int(g["B"])
-    net, _ = build_product(cfg, int(g["seed"]))
+    net, _ = build_product(cfg, int(g["seed"]), precision=prec)
     inp = inputs(B, cfg.num_frame, int(g["input_seed"]))
     xcat = torch.cat([inp["x2d"], inp["noise"] * float(g["y_scale"])], dim=-1).cuda()
     worst = 0.0
@@ -56,7 +60,7 @@ def test_forward_denoise_golden(tag, cfg):
         worst = max(worst, maxabs(out, g[f"t{t}"]))
     out = net.forward_denoise(xcat, torch.from_numpy(g["tmixed_t"]).long().cuda())     # per-row timesteps
     worst = max(worst, maxabs(out, g["tmixed"]))
-    print(f"denoise {tag}: max-abs {worst:.3e}")
+    print(f"denoise {tag} [{prec}]: max-abs {worst:.3e}")
     assert worst <= GATE
 
 
@@ -67,11 +71,12 @@ DDIM = [("small_T81_S5", cfg_small(81), True, True), ("full_T81_S9", cfg_full(81
         ("small_T81_S5_noclip", cfg_small(81), True, False)]
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("tag,cfg,traj,clip", DDIM, ids=[d[0] for d in DDIM])
-def test_ddim_loop_golden(tag, cfg, traj, clip):
+def test_ddim_loop_golden(tag, cfg, traj, clip, prec):
     g = gold("ddim_" + tag)
     B, S = int(g["B"]), int(g["S"])
-    _, diff = build_product(cfg, int(g["seed"]), sampling=S, clip=clip)
+    _, diff = build_product(cfg, int(g["seed"]), sampling=S, clip=clip, precision=prec)
     inp = inputs(B, cfg.num_frame, int(g["input_seed"]))
     noise = inp["noise"][:, :1].contiguous() if cfg.seq2frame else inp["noise"]
     clean = torch.zeros_like(noise).cuda()
@@ -86,7 +91,7 @@ def test_ddim_loop_golden(tag, cfg, traj, clip):
         loss, y0 = diff(clean_3d_pose=clean, noisy_2d_pose=x2d, output_loss=False, init_noise=noise.cuda())
         assert loss is None
         e = maxabs(y0, g["y0"])
-    print(f"ddim {tag}: max-abs {e:.3e}")
+    print(f"ddim {tag} [{prec}]: max-abs {e:.3e}")
     assert y0.shape == g["y0"].shape and e <= GATE
     if clip:
         assert y0.abs().max().item() <= 1.0
@@ -145,13 +150,14 @@ def test_ddim_index_schedule_is_the_engines_schedule():
         assert diff.ddim_times()[0] == 999 and diff.ddim_times()[-1] == -1 and len(diff.ddim_times()) == S + 1
 
 
-def test_batch_independence_sharding_and_determinism():
+@pytest.mark.parametrize("prec", PRECS)
+def test_batch_independence_sharding_and_determinism(prec):
     """Domain properties at a size the oracle would take minutes for (T=243, D=512): a sequence's result does not
     depend on its batch neighbours (=> sharding a batch over ranks reproduces the 1-GPU result bit for bit), repeated
     runs are bit-identical, and clamped outputs stay in [-1, 1]."""
     from diff3dhpe_amd import parallel
     cfg = cfg_full(243)
-    _, diff = build_product(cfg, 8, sampling=3)
+    _, diff = build_product(cfg, 8, sampling=3, precision=prec)
     inp = inputs(6, 243, 77)
     x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
     z = torch.zeros_like(nz)
