@@ -20,6 +20,14 @@ hipError_t launch_linear_f16x3(const float* A, const void* Wh, const void* Wl, c
                                int M, int N, int K, int epi, hipStream_t s);
 void split_weight_f16x3(const float* w, size_t n, uint16_t* hi, uint16_t* lo);
 
+// ---- kernels_gemm_x3p.hip ---------------------------------------------------------------------------------------
+// F16X3 with pre-split operands: A planes (>= ceil(M/256)*256 rows allocated), W planes (>= ceil(N/256)*256 rows).
+// outsplit: write C as hi/lo planes of 8*c (for a following x3p GEMM) instead of fp32.  variant 0 = auto tile choice.
+hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias,
+                             const float* R, float* C, void* Ch, void* Cl, int M, int N, int K, int epi, int outsplit,
+                             int variant, hipStream_t s);
+hipError_t launch_split_x3(const float* x, void* hi, void* lo, size_t n, hipStream_t s);
+
 // ---- kernels_elem.hip -------------------------------------------------------------------------------------------
 // Row LayerNorm; optionally also writes a second LayerNorm of the first result (post-norm -> next block's norm1).
 //   y  = LN(x; g1,b1,eps1) [+ pos[(row / pos_div) % pos_mod] ] [+ tvec[(row / rows_per_batch) * tvec_stride]]
@@ -28,6 +36,8 @@ struct LnArgs {
   const float* x;
   float* y;          // may alias x; may be nullptr when only h is wanted (then h = LN(x; g1,b1))
   float* h;          // nullable
+  void* h_hi;        // nullable: when set (with h_lo), h is written as fp16 hi/lo planes of 8*h (F16X3 GEMM operand)
+  void* h_lo;        //           instead of fp32 (h itself may then be nullptr)
   const float* g1; const float* b1; float eps1;
   const float* g2; const float* b2; float eps2;
   const float* pos;  // nullable, (pos_mod, D)
@@ -80,9 +90,14 @@ hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const flo
 
 // ---- kernels_attn.hip -------------------------------------------------------------------------------------------
 // qkv: (B*T*J, 3*D) -> out (B*T*J, D), GRAND core  O = softmax(q k^T * dh^-0.5) v - v
-hipError_t launch_attn_spatial_f32(const float* qkv, float* out, int B, int T, int J, int D, int H, hipStream_t s);
-hipError_t launch_attn_temporal_f32(const float* qkv, float* out, int B, int T, int J, int D, int H, hipStream_t s);
-hipError_t launch_attn_generic(const float* qkv, float* out, int B, int T, int J, int D, int H, int temporal, hipStream_t s);
+// When out_hi/out_lo are non-null the result is written as fp16 hi/lo planes of 8*o (F16X3 GEMM operand) and `out`
+// is ignored.
+hipError_t launch_attn_spatial_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+                                   hipStream_t s);
+hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+                                    hipStream_t s);
+hipError_t launch_attn_generic(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+                               int temporal, hipStream_t s);
 bool attn_spatial_fast_ok(int J, int D, int H);
 bool attn_temporal_fast_ok(int T, int D, int H);
 

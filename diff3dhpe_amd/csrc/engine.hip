@@ -201,7 +201,8 @@ Workspace carve(const d3d_engine* e, int B, void* base) {
   };
   float* b = reinterpret_cast<float*>(base);
   Workspace w{};
-  size_t oX = take(M * D), oHN = take(M * D), oQKV = take(M * 3 * D), oHID = take(M * e->Dm);
+  const size_t Mp = (M + 255) / 256 * 256;   // F16X3 operand planes are read in whole 256-row tiles
+  size_t oX = take(M * D), oHN = take(Mp * D), oQKV = take(M * 3 * D), oHID = take(Mp * e->Dm);
   size_t oY0 = take(M * 3), oY1 = take(M * 3);
   size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
   size_t oRED = take((size_t)B * e->J * D), oTI = take((size_t)B + 64);
@@ -223,13 +224,13 @@ int compute_temb(d3d_engine* e, const float* times_dev, int n, float* out, float
   return D3D_OK;
 }
 
-int attention(d3d_engine* e, const float* qkv, float* out, int B, bool temporal, hipStream_t s) {
+int attention(d3d_engine* e, const float* qkv, float* out, void* out_hi, void* out_lo, int B, bool temporal, hipStream_t s) {
   if (!temporal) {
-    if (attn_spatial_fast_ok(e->J, e->D, e->H)) HIP_TRY(launch_attn_spatial_f32(qkv, out, B, e->T, e->J, e->D, e->H, s));
-    else HIP_TRY(launch_attn_generic(qkv, out, B, e->T, e->J, e->D, e->H, 0, s));
+    if (attn_spatial_fast_ok(e->J, e->D, e->H)) HIP_TRY(launch_attn_spatial_f32(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, s));
+    else HIP_TRY(launch_attn_generic(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, 0, s));
   } else {
-    if (attn_temporal_fast_ok(e->T, e->D, e->H)) HIP_TRY(launch_attn_temporal_f32(qkv, out, B, e->T, e->J, e->D, e->H, s));
-    else HIP_TRY(launch_attn_generic(qkv, out, B, e->T, e->J, e->D, e->H, 1, s));
+    if (attn_temporal_fast_ok(e->T, e->D, e->H)) HIP_TRY(launch_attn_temporal_f32(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, s));
+    else HIP_TRY(launch_attn_generic(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, 1, s));
   }
   return D3D_OK;
 }
@@ -247,14 +248,24 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
                          y_bcast, s));
   }
   const bool x3 = e->cfg.precision == D3D_PREC_F16X3;
-  auto linear = [&](const float* A, const float* W, const uint16_t* Wh, const uint16_t* Wl, const float* bias, const float* R,
-                    float* C, int N, int K, int epi) -> hipError_t {
+  // F16X3: every GEMM A-operand lives as two fp16 planes (hi, lo of 8*a) written by its producer; the plane pair of
+  // an (rows x cols) activation occupies the same bytes as the fp32 tensor would (rows padded to 256).
+  const size_t Mp = ((size_t)M + 255) / 256 * 256;
+  uint16_t* HNh = reinterpret_cast<uint16_t*>(w.HN);
+  uint16_t* HNl = HNh + Mp * D;
+  uint16_t* HIDh = reinterpret_cast<uint16_t*>(w.HID);
+  uint16_t* HIDl = HIDh + Mp * e->Dm;
+  // A: fp32 activation (FP32 mode) or its planes (F16X3 mode); `split_out`: write C as planes (fc1 -> fc2 hand-off)
+  auto linear = [&](const float* A, const uint16_t* Ah_, const uint16_t* Al_, const float* W, const uint16_t* Wh,
+                    const uint16_t* Wl, const float* bias, const float* R, float* C, uint16_t* Ch_, uint16_t* Cl_, int N, int K,
+                    int epi) -> hipError_t {
     Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), s);
-    if (x3) return launch_linear_f16x3(A, Wh, Wl, bias, R, C, M, N, K, epi, s);
+    if (x3) return launch_linear_x3p(Ah_, Al_, Wh, Wl, bias, R, C, Ch_, Cl_, M, N, K, epi, Ch_ != nullptr, 0, s);
     return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
   };
-  auto lnorm = [&](const LnArgs& a) -> hipError_t {
-    Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + (a.y ? 1 : 0) + (a.h ? 1 : 0)), s);
+  auto lnorm = [&](LnArgs a) -> hipError_t {
+    if (x3 && a.h) { a.h = nullptr; a.h_hi = HNh; a.h_lo = HNl; }   // normalised activations go out as GEMM operand planes
+    Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + (a.y ? 1 : 0) + ((a.h || a.h_hi) ? 1 : 0)), s);
     return launch_layernorm(a, s);
   };
   {  // h = norm1_0(x)
@@ -266,22 +277,23 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
-    HIP_TRY(linear(w.HN, bw.qkvw, bw.qkv_h, bw.qkv_l, bw.qkvb, nullptr, w.QKV, 3 * D, D, EPI_NONE));
+    HIP_TRY(linear(w.HN, HNh, HNl, bw.qkvw, bw.qkv_h, bw.qkv_l, bw.qkvb, nullptr, w.QKV, nullptr, nullptr, 3 * D, D, EPI_NONE));
     {
       const int N = temporal ? T : J;
       Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
-      int rc = attention(e, w.QKV, w.HN, B, temporal, s);
+      int rc = attention(e, w.QKV, w.HN, x3 ? HNh : nullptr, x3 ? HNl : nullptr, B, temporal, s);
       if (rc) return rc;
     }
-    HIP_TRY(linear(w.HN, bw.projw, bw.proj_h, bw.proj_l, bw.projb, w.X, w.X, D, D, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HN, HNh, HNl, bw.projw, bw.proj_h, bw.proj_l, bw.projb, w.X, w.X, nullptr, nullptr, D, D, EPI_RESIDUAL));
     {  // h = norm2(x)
       LnArgs a{};
       a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       HIP_TRY(lnorm(a));
     }
-    HIP_TRY(linear(w.HN, bw.fc1w, bw.fc1_h, bw.fc1_l, bw.fc1b, nullptr, w.HID, e->Dm, D, EPI_GELU));
-    HIP_TRY(linear(w.HID, bw.fc2w, bw.fc2_h, bw.fc2_l, bw.fc2b, w.X, w.X, D, e->Dm, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HN, HNh, HNl, bw.fc1w, bw.fc1_h, bw.fc1_l, bw.fc1b, nullptr, w.HID, x3 ? HIDh : nullptr, x3 ? HIDl : nullptr,
+                   e->Dm, D, EPI_GELU));
+    HIP_TRY(linear(w.HID, HIDh, HIDl, bw.fc2w, bw.fc2_h, bw.fc2_l, bw.fc2b, w.X, w.X, nullptr, nullptr, D, e->Dm, EPI_RESIDUAL));
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = next.norm1(x)
       LnArgs a{};
       a.x = w.X; a.y = w.X;
@@ -448,25 +460,29 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     e->blk.push_back(blockw("TTEblocks." + std::to_string(i)));
   }
   if (e->cfg.precision == D3D_PREC_F16X3) {
+    // fp16 hi/lo planes of the four GEMM weights of every block, rows padded to a multiple of 256 (zero rows) so the
+    // LDS-DMA of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
     const size_t D = e->D, Dm = e->Dm;
-    const size_t per_blk = 2 * (3 * D * D + D * D + 2 * Dm * D);   // hi + lo of qkv, proj, fc1, fc2
-    std::vector<uint16_t> host(per_blk * e->nblk);
+    auto pad256 = [](size_t n) { return (n + 255) / 256 * 256; };
+    const size_t per_blk = 2 * (pad256(3 * D) * D + pad256(D) * D + pad256(Dm) * D + pad256(D) * Dm);
+    std::vector<uint16_t> host(per_blk * e->nblk, 0);
     if (e->arena16) { (void)hipFree(e->arena16); e->arena16 = nullptr; }
     HIP_TRY(hipMalloc(&e->arena16, host.size() * sizeof(uint16_t)));
     size_t o = 0;
     for (int k = 0; k < e->nblk; ++k) {
       const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2);
-      auto plane = [&](const std::string& name, size_t n, const uint16_t*& hi, const uint16_t*& lo) {
+      auto plane = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& hi, const uint16_t*& lo) {
         const WeightSlot& ws = e->slots[e->index[name]];
-        split_weight_f16x3(ws.host.data(), n, host.data() + o, host.data() + o + n);
-        hi = e->arena16 + o; lo = e->arena16 + o + n;
-        o += 2 * n;
+        const size_t padded = pad256(rows) * cols;
+        split_weight_f16x3(ws.host.data(), rows * cols, host.data() + o, host.data() + o + padded);
+        hi = e->arena16 + o; lo = e->arena16 + o + padded;
+        o += 2 * padded;
       };
       BlockW& b = e->blk[k];
-      plane(p + ".attn.qkv.weight", 3 * D * D, b.qkv_h, b.qkv_l);
-      plane(p + ".attn.proj.weight", D * D, b.proj_h, b.proj_l);
-      plane(p + ".mlp.fc1.weight", Dm * D, b.fc1_h, b.fc1_l);
-      plane(p + ".mlp.fc2.weight", D * Dm, b.fc2_h, b.fc2_l);
+      plane(p + ".attn.qkv.weight", 3 * D, D, b.qkv_h, b.qkv_l);
+      plane(p + ".attn.proj.weight", D, D, b.proj_h, b.proj_l);
+      plane(p + ".mlp.fc1.weight", Dm, D, b.fc1_h, b.fc1_l);
+      plane(p + ".mlp.fc2.weight", D, Dm, b.fc2_h, b.fc2_l);
     }
     HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
@@ -713,31 +729,79 @@ int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, floa
   return compute_temb(e, times_dev, n, out, scratch, reinterpret_cast<hipStream_t>(stream));
 }
 
+namespace {
+// test/bench helper: device planes for an fp32 device matrix (rows padded to 256).  Weights are split on the host with
+// the same routine the engine uses at commit; activations on the device with the producers' split.
+struct TmpPlanes {
+  uint16_t* dev = nullptr;
+  size_t plane = 0;
+  ~TmpPlanes() { (void)hipFree(dev); }
+  const uint16_t* hi() const { return dev; }
+  const uint16_t* lo() const { return dev + plane; }
+};
+int make_planes(TmpPlanes& t, const float* src_dev, int rows, int cols, bool weight, hipStream_t s) {
+  const size_t rp = ((size_t)rows + 255) / 256 * 256;
+  t.plane = rp * cols;
+  HIP_TRY(hipMalloc(&t.dev, 2 * t.plane * sizeof(uint16_t)));
+  HIP_TRY(hipMemsetAsync(t.dev, 0, 2 * t.plane * sizeof(uint16_t), s));
+  if (weight) {
+    std::vector<float> h((size_t)rows * cols);
+    std::vector<uint16_t> pl(2 * h.size());
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(h.data(), src_dev, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    split_weight_f16x3(h.data(), h.size(), pl.data(), pl.data() + h.size());
+    HIP_TRY(hipMemcpy(t.dev, pl.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.dev + t.plane, pl.data() + h.size(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(launch_split_x3(src_dev, t.dev, t.dev + t.plane, (size_t)rows * cols, s));
+  }
+  return D3D_OK;
+}
+}  // namespace
+
 int d3d_op_linear(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M, int32_t N,
                   int32_t K, int32_t epi, int32_t precision, void* stream) {
+  return d3d_op_linear_bench(A, W, bias, R, C, M, N, K, epi, precision, 0, 1, nullptr, stream);
+}
+
+int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M, int32_t N,
+                        int32_t K, int32_t epi, int32_t precision, int32_t variant, int32_t reps, float* avg_ms, void* stream) {
   if (precision != D3D_PREC_FP32 && precision != D3D_PREC_F16X3) return fail(D3D_EUNSUP, "precision not implemented");
-  if (!A || !W || !C) return fail(D3D_EINVAL, "null tensor");
+  if (!A || !W || !C || reps < 1) return fail(D3D_EINVAL, "bad argument");
   if (K % 32) return fail(D3D_EUNSUP, "K must be a multiple of 32");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (precision == D3D_PREC_FP32) {
-    HIP_TRY(launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s));
-    return D3D_OK;
+  TmpPlanes ap, wp;
+  if (precision == D3D_PREC_F16X3 && (N % 4) != 0) variant = 9;   // the plane kernel stores 4 columns at a time
+  if (precision == D3D_PREC_F16X3) {
+    int rc = make_planes(wp, W, N, K, true, s);
+    if (rc) return rc;
+    if (variant != 9) {
+      rc = make_planes(ap, A, M, K, false, s);
+      if (rc) return rc;
+    }
   }
-  // test hook only: split the device weight on the host, upload the planes, run, and free (synchronous)
-  const size_t n = (size_t)N * K;
-  std::vector<float> wh(n);
-  std::vector<uint16_t> planes(2 * n);
+  auto once = [&]() -> hipError_t {
+    if (precision == D3D_PREC_FP32) return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
+    if (variant == 9) return launch_linear_f16x3(A, wp.hi(), wp.lo(), bias, R, C, M, N, K, epi, s);   // on-the-fly A split
+    return launch_linear_x3p(ap.hi(), ap.lo(), wp.hi(), wp.lo(), bias, R, C, nullptr, nullptr, M, N, K, epi, 0, variant, s);
+  };
+  HIP_TRY(once());
+  if (avg_ms) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    hipError_t le = hipSuccess;
+    for (int i = 0; i < reps && le == hipSuccess; ++i) le = once();
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(le);
+    *avg_ms = ms / reps;
+  }
   HIP_TRY(hipStreamSynchronize(s));
-  HIP_TRY(hipMemcpy(wh.data(), W, n * sizeof(float), hipMemcpyDeviceToHost));
-  split_weight_f16x3(wh.data(), n, planes.data(), planes.data() + n);
-  uint16_t* dev = nullptr;
-  HIP_TRY(hipMalloc(&dev, planes.size() * sizeof(uint16_t)));
-  hipError_t e1 = hipMemcpy(dev, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-  hipError_t e2 = (e1 == hipSuccess) ? launch_linear_f16x3(A, dev, dev + n, bias, R, C, M, N, K, epi, s) : e1;
-  hipError_t e3 = hipStreamSynchronize(s);
-  (void)hipFree(dev);
-  HIP_TRY(e2);
-  HIP_TRY(e3);
   return D3D_OK;
 }
 
@@ -757,11 +821,11 @@ int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t
   if (!qkv || !out || B <= 0 || T <= 0 || J <= 0 || D <= 0 || H <= 0 || D % H) return fail(D3D_EINVAL, "bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!force_generic && !temporal && attn_spatial_fast_ok(J, D, H)) {
-    HIP_TRY(launch_attn_spatial_f32(qkv, out, B, T, J, D, H, s));
+    HIP_TRY(launch_attn_spatial_f32(qkv, out, nullptr, nullptr, B, T, J, D, H, s));
   } else if (!force_generic && temporal && attn_temporal_fast_ok(T, D, H)) {
-    HIP_TRY(launch_attn_temporal_f32(qkv, out, B, T, J, D, H, s));
+    HIP_TRY(launch_attn_temporal_f32(qkv, out, nullptr, nullptr, B, T, J, D, H, s));
   } else {
-    HIP_TRY(launch_attn_generic(qkv, out, B, T, J, D, H, temporal, s));
+    HIP_TRY(launch_attn_generic(qkv, out, nullptr, nullptr, B, T, J, D, H, temporal, s));
   }
   return D3D_OK;
 }

@@ -17,12 +17,34 @@
 namespace d3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h4a __attribute__((ext_vector_type(4)));
+
+// fp32 -> (hi, lo) fp16 pair of 8*x: the operand format of the F16X3 GEMM (kernels_gemm_x3p.hip)
+__device__ __forceinline__ void split1_x3(float x, _Float16& hi, _Float16& lo) {
+  const float s = __builtin_amdgcn_fmed3f(x * 8.0f, -65504.0f, 65504.0f);
+  hi = (_Float16)s;
+  lo = (_Float16)(s - (float)hi);
+}
+__device__ __forceinline__ void store4_x3(_Float16* hp, _Float16* lp, float a, float b, float c, float d) {
+  const float f[4] = {a, b, c, d};
+  h4a hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    _Float16 x, y;
+    split1_x3(f[j], x, y);
+    hi[j] = x;
+    lo[j] = y;
+  }
+  *reinterpret_cast<h4a*>(hp) = hi;
+  *reinterpret_cast<h4a*>(lp) = lo;
+}
 
 // =============================================================================================== spatial (VALU)
 constexpr int SP_DH = 64;
 
 template <int NJ>
 __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restrict__ qkv, float* __restrict__ out,
+                                                          _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
                                                           int units, int H, int D) {
   constexpr int UPW = 64 / NJ;                   // (group, head) units per wave
   constexpr int UNIT_LD = NJ * SP_DH + 4;        // +16 B so the UPW broadcast addresses fall in different banks
@@ -104,21 +126,28 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
     }
   }
   if (valid) {
-    float* op = out + ((size_t)g * NJ + i) * D + h * SP_DH;
+    const size_t oo = ((size_t)g * NJ + i) * D + h * SP_DH;
+    if (out_hi) {
 #pragma unroll
-    for (int c = 0; c < SP_DH; c += 4) *reinterpret_cast<float4*>(op + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+      for (int c = 0; c < SP_DH; c += 4) store4_x3(out_hi + oo + c, out_lo + oo + c, o[c], o[c + 1], o[c + 2], o[c + 3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < SP_DH; c += 4) *reinterpret_cast<float4*>(out + oo + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    }
   }
 }
 
 bool attn_spatial_fast_ok(int J, int D, int H) { return J == 17 && H > 0 && D == H * SP_DH; }
 
-hipError_t launch_attn_spatial_f32(const float* qkv, float* out, int B, int T, int J, int D, int H, hipStream_t s) {
+hipError_t launch_attn_spatial_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+                                   hipStream_t s) {
   if (!attn_spatial_fast_ok(J, D, H)) return hipErrorInvalidValue;
   const long long units = (long long)B * T * H;
   constexpr int UPB = 4 * (64 / 17);
   const long long grid = (units + UPB - 1) / UPB;
   if (units > 0x7fffffffLL || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_attn_spatial_f32<17>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (int)units, H, D);
+  hipLaunchKernelGGL(k_attn_spatial_f32<17>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_hi,
+                     (_Float16*)out_lo, (int)units, H, D);
   return hipGetLastError();
 }
 
@@ -127,6 +156,7 @@ constexpr int TP_DH = 64, K_LD = 68, V_LD = 64;
 
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
                                                                 int T, int J, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TP = 32 * NKT;
@@ -231,20 +261,26 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __r
     }
 
   if (tq < T) {
-    float* op = out + (tok0 + (size_t)tq * J) * D + h * TP_DH;
+    const size_t oo = (tok0 + (size_t)tq * J) * D + h * TP_DH;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
-        *reinterpret_cast<float4*>(op + dt * 32 + 8 * g4 + 4 * hh) =
-            make_float4(oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const size_t o = oo + dt * 32 + 8 * g4 + 4 * hh;
+        if (out_hi)
+          store4_x3(out_hi + o, out_lo + o, oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
+        else
+          *reinterpret_cast<float4*>(out + o) =
+              make_float4(oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
+      }
   }
 }
 
 bool attn_temporal_fast_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * TP_DH; }
 
 template <int NKT>
-static hipError_t launch_temporal_nkt(const float* qkv, float* out, int B, int T, int J, int D, int H, hipStream_t s) {
+static hipError_t launch_temporal_nkt(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+                                      hipStream_t s) {
   const size_t lds_bytes = (size_t)32 * NKT * (K_LD + V_LD) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -255,27 +291,30 @@ static hipError_t launch_temporal_nkt(const float* qkv, float* out, int B, int T
   }
   const long long grid = (long long)B * J * H;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_attn_temporal_f32<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, qkv, out, T, J, H, D);
+  hipLaunchKernelGGL(k_attn_temporal_f32<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, qkv, out,
+                     (_Float16*)out_hi, (_Float16*)out_lo, T, J, H, D);
   return hipGetLastError();
 }
 
-hipError_t launch_attn_temporal_f32(const float* qkv, float* out, int B, int T, int J, int D, int H, hipStream_t s) {
+hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+                                    hipStream_t s) {
   if (!attn_temporal_fast_ok(T, D, H)) return hipErrorInvalidValue;
   switch ((T + 31) / 32) {
-    case 1: return launch_temporal_nkt<1>(qkv, out, B, T, J, D, H, s);
-    case 2: return launch_temporal_nkt<2>(qkv, out, B, T, J, D, H, s);
-    case 3: return launch_temporal_nkt<3>(qkv, out, B, T, J, D, H, s);
-    case 4: return launch_temporal_nkt<4>(qkv, out, B, T, J, D, H, s);
-    case 5: return launch_temporal_nkt<5>(qkv, out, B, T, J, D, H, s);
-    case 6: return launch_temporal_nkt<6>(qkv, out, B, T, J, D, H, s);
-    case 7: return launch_temporal_nkt<7>(qkv, out, B, T, J, D, H, s);
-    default: return launch_temporal_nkt<8>(qkv, out, B, T, J, D, H, s);
+    case 1: return launch_temporal_nkt<1>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    case 2: return launch_temporal_nkt<2>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    case 3: return launch_temporal_nkt<3>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    case 4: return launch_temporal_nkt<4>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    case 5: return launch_temporal_nkt<5>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    case 6: return launch_temporal_nkt<6>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    case 7: return launch_temporal_nkt<7>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    default: return launch_temporal_nkt<8>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
   }
 }
 
 // =============================================================================================== generic (any N, dh)
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_generic(const float* __restrict__ qkv, float* __restrict__ out,
+                                                      _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
                                                       long long rows, int N, int H, int D, int temporal, int T, int J) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= rows) return;
@@ -317,13 +356,16 @@ __global__ __launch_bounds__(256) void k_attn_generic(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < DH; ++c) o[c] = fmaf(p, vp[c], o[c]);
   }
-  float* op = out + token(i) * D + h * DH;
+  const size_t oo = token(i) * D + h * DH;
 #pragma unroll
-  for (int c = 0; c < DH; ++c) op[c] = o[c];
+  for (int c = 0; c < DH; ++c) {
+    if (out_hi) split1_x3(o[c], out_hi[oo + c], out_lo[oo + c]);
+    else out[oo + c] = o[c];
+  }
 }
 
-hipError_t launch_attn_generic(const float* qkv, float* out, int B, int T, int J, int D, int H, int temporal,
-                               hipStream_t s) {
+hipError_t launch_attn_generic(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+                               int temporal, hipStream_t s) {
   if (H <= 0 || D % H) return hipErrorInvalidValue;
   const int dh = D / H;
   const int N = temporal ? T : J;
@@ -333,8 +375,8 @@ hipError_t launch_attn_generic(const float* qkv, float* out, int B, int T, int J
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
 #define D3D_GEN(DH)                                                                                                    \
   case DH:                                                                                                             \
-    hipLaunchKernelGGL(k_attn_generic<DH>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, rows, N, H, D, temporal, T, \
-                       J);                                                                                             \
+    hipLaunchKernelGGL(k_attn_generic<DH>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_hi,           \
+                       (_Float16*)out_lo, rows, N, H, D, temporal, T, J);                                                                                             \
     break;
   switch (dh) {
     D3D_GEN(4) D3D_GEN(8) D3D_GEN(16) D3D_GEN(32) D3D_GEN(64)

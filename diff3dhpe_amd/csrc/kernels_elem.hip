@@ -6,6 +6,19 @@
 
 namespace d3d {
 
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+
+// fp32 -> (hi, lo) fp16 pair of 8*x: the operand format of the F16X3 GEMM (kernels_gemm_x3p.hip)
+__device__ __forceinline__ void split4_x3(const float4 v, h4v& hi, h4v& lo) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float s = __builtin_amdgcn_fmed3f(f[j] * 8.0f, -65504.0f, 65504.0f);
+    hi[j] = (_Float16)s;
+    lo[j] = (_Float16)(s - (float)hi[j]);
+  }
+}
+
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int LN_MAXV = 4;  // float4 per lane -> D <= 1024
 
@@ -92,13 +105,28 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
       if (c < D) *reinterpret_cast<float4*>(yr + c) = v[i];
     }
   }
-  if (a.h) {
+  if (a.h || a.h_hi) {
     if (a.y) ln_row<NV>(v, D, lane, a.g2, a.b2, a.eps2);
-    float* hr = a.h + (size_t)row * D;
+    if (a.h_hi) {
+      _Float16* hh = reinterpret_cast<_Float16*>(a.h_hi) + (size_t)row * D;
+      _Float16* hl = reinterpret_cast<_Float16*>(a.h_lo) + (size_t)row * D;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = 4 * (lane + 64 * i);
-      if (c < D) *reinterpret_cast<float4*>(hr + c) = v[i];
+      for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < D) {
+          h4v hi, lo;
+          split4_x3(v[i], hi, lo);
+          *reinterpret_cast<h4v*>(hh + c) = hi;
+          *reinterpret_cast<h4v*>(hl + c) = lo;
+        }
+      }
+    } else {
+      float* hr = a.h + (size_t)row * D;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < D) *reinterpret_cast<float4*>(hr + c) = v[i];
+      }
     }
   }
 }

@@ -24,6 +24,39 @@ constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Interior tiles take a branch-free epilogue: a per-element bounds branch makes hipcc wait vmcnt(0) (= for the previous
+// STORE, stores count in vmcnt on gfx950) before every store.
+template <int EPI, bool CHECK>
+__device__ __forceinline__ void f32_epilogue(f32x16 (&acc)[2][2], const float* __restrict__ bias, const float* R, float* C, int mw,
+                                             int nw, int M, int N) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nw + j * 32;
+    if (CHECK && n >= N) continue;
+    const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float rv[16];
+      if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = mw + i * 32 + (q & 3) + 8 * (q >> 2);
+          rv[q] = (!CHECK || m < M) ? R[(size_t)m * N + n] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = mw + i * 32 + (q & 3) + 8 * (q >> 2);
+        if (CHECK && m >= M) continue;
+        float v = acc[i][j][q] + bn;
+        if (EPI == EPI_GELU) v = gelu_erf(v);
+        if (EPI == EPI_RESIDUAL) v = rv[q] + v;
+        C[(size_t)m * N + n] = v;
+      }
+    }
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_linear_f32(const float* __restrict__ A, const float* __restrict__ W,
                                                         const float* __restrict__ bias, const float* R, float* C, int M,
@@ -104,25 +137,9 @@ __global__ __launch_bounds__(256, 2) void k_linear_f32(const float* __restrict__
   }
 
   // epilogue. C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + r;
-    if (n >= N) continue;
-    const float bn = bias ? bias[n] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (m < M) {
-          float v = acc[i][j][q] + bn;
-          if (EPI == EPI_GELU) v = gelu_erf(v);
-          if (EPI == EPI_RESIDUAL) v = R[(size_t)m * N + n] + v;
-          C[(size_t)m * N + n] = v;
-        }
-      }
-    }
-  }
+  const int mw = m0 + wm * 64 + 4 * h, nw = n0 + wn * 64 + r;
+  if (m0 + 128 <= M && n0 + 128 <= N) f32_epilogue<EPI, false>(acc, bias, R, C, mw, nw, M, N);
+  else f32_epilogue<EPI, true>(acc, bias, R, C, mw, nw, M, N);
 }
 
 hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,

@@ -43,6 +43,39 @@ __device__ __forceinline__ void split8(const float4 lo4, const float4 hi4, h8& v
   }
 }
 
+// Interior tiles take a branch-free epilogue: a per-element bounds branch makes hipcc wait vmcnt(0) (= for the previous
+// STORE, stores count in vmcnt on gfx950) before every store.
+template <int EPI, bool CHECK>
+__device__ __forceinline__ void x3_epilogue(f32x16 (&acc)[2][2], const float* __restrict__ bias, const float* R, float* C, int mw,
+                                             int nw, int M, int N) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nw + j * 32;
+    if (CHECK && n >= N) continue;
+    const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float rv[16];
+      if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = mw + i * 32 + (q & 3) + 8 * (q >> 2);
+          rv[q] = (!CHECK || m < M) ? R[(size_t)m * N + n] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = mw + i * 32 + (q & 3) + 8 * (q >> 2);
+        if (CHECK && m >= M) continue;
+        float v = acc[i][j][q] * OUT_SCALE + bn;
+        if (EPI == EPI_GELU) v = gelu_erf_x(v);
+        if (EPI == EPI_RESIDUAL) v = rv[q] + v;
+        C[(size_t)m * N + n] = v;
+      }
+    }
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_linear_f16x3(const float* __restrict__ A, const _Float16* __restrict__ Wh,
                                                           const _Float16* __restrict__ Wl, const float* __restrict__ bias,
@@ -147,25 +180,9 @@ __global__ __launch_bounds__(256, 2) void k_linear_f16x3(const float* __restrict
     __syncthreads();
   }
 
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + r;
-    if (n >= N) continue;
-    const float bn = bias ? bias[n] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (m < M) {
-          float v = acc[i][j][q] * OUT_SCALE + bn;
-          if (EPI == EPI_GELU) v = gelu_erf_x(v);
-          if (EPI == EPI_RESIDUAL) v = R[(size_t)m * N + n] + v;
-          C[(size_t)m * N + n] = v;
-        }
-      }
-    }
-  }
+  const int mw = m0 + wm * 64 + 4 * h, nw = n0 + wn * 64 + r;
+  if (m0 + 128 <= M && n0 + 128 <= N) x3_epilogue<EPI, false>(acc, bias, R, C, mw, nw, M, N);
+  else x3_epilogue<EPI, true>(acc, bias, R, C, mw, nw, M, N);
 }
 
 hipError_t launch_linear_f16x3(const float* A, const void* Wh, const void* Wl, const float* bias, const float* R, float* C,

@@ -207,6 +207,25 @@ def op_linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out
 
 
+def op_linear_bench(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, epi: str = "none", precision: str = "fp32",
+                    variant: int = 0, reps: int = 10):
+    """Returns (C, mean ms per launch) -- GEMM micro-benchmark through the C ABI (events on the launch stream)."""
+    epi_id = {"none": 0, "gelu": 1, "residual": 2}[epi]
+    M, K = A.shape
+    N = W.shape[0]
+    dev = A.device
+    A, W = _f32c(A, dev), _f32c(W, dev)
+    bias = _f32c(bias, dev) if bias is not None else None
+    residual = _f32c(residual, dev) if residual is not None else None
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ms = C.c_float(0.0)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_op_linear_bench(_ptr(A), _ptr(W), _ptr(bias), _ptr(residual), _ptr(out), M, N, K, epi_id,
+                                                  _lib.PRECISIONS[precision], variant, reps, C.byref(ms), st))
+    return out, ms.value
+
+
 def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     dev = x.device
     D = x.shape[-1]

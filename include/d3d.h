@@ -148,6 +148,12 @@ int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, floa
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); epi 0 none, 1 exact-erf GELU, 2 add residual R[M,N] (R may alias C). */
 int d3d_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
                   int32_t M, int32_t N, int32_t K, int32_t epi, int32_t precision, void* stream);
+/* d3d_op_linear with a choice of tile variant (F16X3: 0 auto, 1 128x128, 2 256x128, 3 256x256, 9 on-the-fly A split)
+ * and a timing leg: after one untimed call, `reps` back-to-back launches are timed with HIP events on `stream` and the
+ * mean written to *avg_ms (nullable).  Operand conversion for F16X3 happens once, outside the timed launches. */
+int d3d_op_linear_bench(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
+                        int32_t M, int32_t N, int32_t K, int32_t epi, int32_t precision, int32_t variant, int32_t reps,
+                        float* avg_ms, void* stream);
 /* Row LayerNorm over the last axis (S2S:95,101,236,245 eps 1e-6; S2S:218 eps 1e-5). */
 int d3d_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* out_dev, int32_t rows,
                      int32_t D, float eps, void* stream);
