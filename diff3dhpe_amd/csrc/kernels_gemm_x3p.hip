@@ -35,52 +35,64 @@ __device__ __forceinline__ float gelu_erf_p(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
 // Epilogue of one wave.  The MFMAs are issued with the WEIGHT fragment as the first operand, so an accumulator tile
-// holds C^T: column (lane&31) = token row m, registers = output columns n = 8*(reg>>2) + 4*(lane>>5) + (reg&3).  Every
-// lane therefore owns 4 consecutive n per register quad and stores/loads 16 bytes at a time (4x fewer store
-// instructions than the col-per-lane map: the store tail of a GEMM tile is issue-bound, not bandwidth-bound).
-// Addressing is (wave-uniform 64-bit tile base) + (32-bit per-lane offset); interior tiles take a branch-free path.
+// holds C^T: column (lane&31) = token row m, registers = output columns n = 8*(reg>>2) + 4*(lane>>5) + (reg&3).
+// Each 32-row strip of the wave tile is transposed through a wave-private LDS patch (ds_write_b128 of 4 consecutive
+// n per lane, 272-byte rows -> conflict-free) and read back row-major, 16 bytes per lane with 8*TNJ lanes per row,
+// so every global store / residual load instruction covers whole 128-byte lines (a store tail of partial lines or of
+// 4-byte-per-lane stores costs more than the transpose).  Addressing is (wave-uniform tile base) + 32-bit offsets.
 template <int TMI, int TNJ, int EPI, int OUTSPLIT, bool CHECK>
-__device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], const float* __restrict__ bias, const float* Rt, float* Ct,
-                                             _Float16* Cht, _Float16* Clt, int mrow, int ncol, int loff, int M, int N) {
-  // Rt/Ct/Cht/Clt: wave-uniform pointers to element (wave tile row 0, col 0); mrow = this lane's first global row (+32 i),
-  // ncol = this lane's first global column (+32 j + 8 g);  loff = (lane&31)*N + 4*(lane>>5)
+__device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], float* patch, const float* __restrict__ bias,
+                                             const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0,
+                                             int lane, int M, int N) {
+  constexpr int LD = 32 * TNJ + 4;          // floats per patch row
+  constexpr int LPR = 8 * TNJ;              // lanes per row on the read side (one float4 each)
+  constexpr int RPP = 64 / LPR;             // rows per pass
+  constexpr int NPASS = 32 / RPP;
+  const int r = lane & 31, h = lane >> 5;
+  const int rrow = lane / LPR, rc4 = lane % LPR;
+  const int n = nt0 + 4 * rc4;
+  const bool ncol_ok = !CHECK || n < N;
+  float4 b4 = make_float4(0, 0, 0, 0);
+  if (bias && ncol_ok) b4 = *reinterpret_cast<const float4*>(bias + n);
 #pragma unroll
   for (int i = 0; i < TMI; ++i) {
-    if (CHECK && mrow + 32 * i >= M) continue;
 #pragma unroll
-    for (int j = 0; j < TNJ; ++j) {
+    for (int j = 0; j < TNJ; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = ncol + 32 * j + 8 * g;
-        if (CHECK && n >= N) continue;
-        const int off = loff + 32 * i * N + 32 * j + 8 * g;
-        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        float v[4] = {acc[i][j][4 * g] * P_OUT_SCALE + b4.x, acc[i][j][4 * g + 1] * P_OUT_SCALE + b4.y,
-                      acc[i][j][4 * g + 2] * P_OUT_SCALE + b4.z, acc[i][j][4 * g + 3] * P_OUT_SCALE + b4.w};
-        if (EPI == EPI_GELU) {
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(patch + r * LD + 32 * j + 8 * g + 4 * h) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf_p(v[e]);
+    for (int p = 0; p < NPASS; ++p) {
+      const int row = rrow + RPP * p;
+      const float4 a4 = *reinterpret_cast<const float4*>(patch + row * LD + 4 * rc4);
+      const int m = mt0 + 32 * i + row;
+      if (CHECK && (m >= M || !ncol_ok)) continue;
+      const int off = (32 * i + row) * N + 4 * rc4;
+      float v[4] = {a4.x * P_OUT_SCALE + b4.x, a4.y * P_OUT_SCALE + b4.y, a4.z * P_OUT_SCALE + b4.z, a4.w * P_OUT_SCALE + b4.w};
+      if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_p(v[e]);
+      }
+      if (EPI == EPI_RESIDUAL) {
+        const float4 r4 = *reinterpret_cast<const float4*>(Rt + off);
+        v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
+      }
+      if (OUTSPLIT) {   // the consumer is another x3p GEMM: hand it hi/lo planes of 8*v
+        h4 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sc = __builtin_amdgcn_fmed3f(v[e] * P_A_SCALE, -65504.0f, 65504.0f);
+          hh[e] = (_Float16)sc;
+          ll[e] = (_Float16)(sc - (float)hh[e]);
         }
-        if (EPI == EPI_RESIDUAL) {
-          const float4 r4 = *reinterpret_cast<const float4*>(Rt + off);
-          v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
-        }
-        if (OUTSPLIT) {   // the consumer is another x3p GEMM: hand it hi/lo planes of 8*v
-          h4 hh, ll;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float sc = __builtin_amdgcn_fmed3f(v[e] * P_A_SCALE, -65504.0f, 65504.0f);
-            hh[e] = (_Float16)sc;
-            ll[e] = (_Float16)(sc - (float)hh[e]);
-          }
-          *reinterpret_cast<h4*>(Cht + off) = hh;
-          *reinterpret_cast<h4*>(Clt + off) = ll;
-        } else {
-          *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        *reinterpret_cast<h4*>(Cht + off) = hh;
+        *reinterpret_cast<h4*>(Clt + off) = ll;
+      } else {
+        *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);   // one row of tiles at a time keeps the live value set small
+    __builtin_amdgcn_sched_barrier(0);   // one strip at a time
   }
 }
 
@@ -223,15 +235,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
   if ((ablate & 4) && acc[0][0][0] != 12345.678f) return;
   const int mt0 = m0 + wm * (BM / WM), nt0 = n0 + wn * (BN / WN);          // wave-uniform
   const size_t tbase = (size_t)mt0 * N + nt0;
-  const int loff = r * N + 4 * h;
   const float* Rt = R ? R + tbase : nullptr;
   float* Ct = C ? C + tbase : nullptr;
   _Float16* Cht = Ch ? Ch + tbase : nullptr;
   _Float16* Clt = Cl ? Cl + tbase : nullptr;
+  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+  float* patch = reinterpret_cast<float*>(lds) + wave * (32 * (32 * TNJ + 4));
   if (m0 + BM <= M && n0 + BN <= N)
-    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, false>(acc, bias, Rt, Ct, Cht, Clt, mt0 + r, nt0 + 4 * h, loff, M, N);
+    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N);
   else
-    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, true>(acc, bias, Rt, Ct, Cht, Clt, mt0 + r, nt0 + 4 * h, loff, M, N);
+    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -295,8 +308,9 @@ hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, con
   const int ablate = variant >> 4;
   variant &= 15;
   if (variant == 0) {
+    // measured on MI355X at M = 264k (experiments/gemm_bench.py): 256x256 wins for every N in {512, 1024, 1536}
     if (M < 2048 || N < 256) variant = 1;
-    else if (N % 256 == 0 && N >= 1024) variant = 3;
+    else if (N % 256 == 0) variant = 3;
     else variant = 2;
   }
   switch (variant) {
