@@ -79,6 +79,16 @@ struct d3d_engine {
   float* temb_sched = nullptr;  // (S, nblk, D)
   bool has_sqrt_ac = false;
 
+  // hipGraph replay of the whole S-step loop (d3d_engine_set_graph_mode): one captured graph per (B, workspace)
+  struct GraphEntry { int B; void* ws; hipGraph_t graph; hipGraphExec_t exec; };
+  bool graph_mode = false;
+  std::vector<GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;
+  void drop_graphs() {
+    for (auto& g : graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    graphs.clear();
+  }
+
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
   struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
   bool profiling = false;
@@ -88,6 +98,8 @@ struct d3d_engine {
   int64_t prof_launches[D3D_KC_COUNT] = {0};
 
   ~d3d_engine() {
+    drop_graphs();
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
     for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     (void)hipFree(arena); (void)hipFree(arena16); (void)hipFree(tblk_w); (void)hipFree(tblk_b); (void)hipFree(freqs_dev);
@@ -186,7 +198,7 @@ struct Prof {
 
 // Workspace carve-up (float offsets).  AO (attention output) aliases HN: norm1(x) is dead once the qkv GEMM has run.
 struct Workspace {
-  float *X, *HN, *QKV, *HID, *Y0, *Y1, *TEMB, *TSCR, *RED, *TIMES;
+  float *X, *HN, *QKV, *HID, *Y0, *Y1, *TEMB, *TSCR, *RED, *TIMES, *XIN, *NIN, *OUTB;
   size_t total_bytes;
 };
 
@@ -206,8 +218,10 @@ Workspace carve(const d3d_engine* e, int B, void* base) {
   size_t oY0 = take(M * 3), oY1 = take(M * 3);
   size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
   size_t oRED = take((size_t)B * e->J * D), oTI = take((size_t)B + 64);
+  size_t oXI = take(M * e->cfg.in_chans), oNI = take(M * 3), oOB = take(M * 3);   // graph-mode staging copies
   w.X = b + oX; w.HN = b + oHN; w.QKV = b + oQKV; w.HID = b + oHID; w.Y0 = b + oY0; w.Y1 = b + oY1;
   w.TEMB = b + oTE; w.TSCR = b + oTS; w.RED = b + oRED; w.TIMES = b + oTI;
+  w.XIN = b + oXI; w.NIN = b + oNI; w.OUTB = b + oOB;
   w.total_bytes = off * sizeof(float);
   return w;
 }
@@ -525,6 +539,7 @@ int d3d_engine_commit_weights(d3d_engine* e) {
   }
   e->committed = true;
   e->sched_set = false;
+  e->drop_graphs();
   return D3D_OK;
 }
 
@@ -535,6 +550,7 @@ int d3d_engine_set_schedule(d3d_engine* e, int32_t num_timesteps, const float* a
   if (num_timesteps < 1 || sampling_timesteps < 1) return fail(D3D_EINVAL, "timesteps must be positive");
   if (sampling_timesteps > num_timesteps) return fail(D3D_EINVAL, "sampling_timesteps <= timesteps required (DIFF:145)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  e->drop_graphs();
   e->num_timesteps = num_timesteps; e->S = sampling_timesteps; e->eta = eta; e->clip = clip_denoised ? 1 : 0;
   e->ac.assign(ac_host, ac_host + num_timesteps);
   e->somac.assign(somac_host, somac_host + num_timesteps);
@@ -602,15 +618,10 @@ int d3d_denoise(d3d_engine* e, const float* x2d, const float* y, int32_t y_frame
   return D3D_OK;
 }
 
-int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, const float* step_noise, float* out,
-                    float* traj_rev, float* traj_x0, int32_t B, void* ws, size_t ws_bytes, void* stream) {
-  int rc = check_ready(e, B, ws, ws_bytes);
-  if (rc) return rc;
-  if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set (d3d_engine_set_schedule)");
-  if (!x2d || !init_noise || !out) return fail(D3D_EINVAL, "null tensor");
-  if (e->eta != 0.0f && !step_noise) return fail(D3D_EINVAL, "step_noise required when eta != 0");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  Workspace w = carve(e, B, ws);
+namespace {
+// The S-step loop of DIFF:262-300 as a launch sequence on `s` (also what gets captured into a hipGraph).
+int ddim_loop(d3d_engine* e, const float* x2d, const float* init_noise, const float* step_noise, float* out, float* traj_rev,
+              float* traj_x0, int B, const Workspace& w, hipStream_t s) {
   const int S = e->S;
   const size_t yel = (size_t)head_rows(e, B) * 3;
   for (int i = 0; i < S; ++i) {
@@ -618,7 +629,7 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
     const float* y_cur = (i == 0) ? init_noise : ((i & 1) ? w.Y0 : w.Y1);
     float* y_next = (i == S - 1) ? out : ((i & 1) ? w.Y1 : w.Y0);
     const float* tvec = e->Dt ? e->temb_sched + (size_t)i * e->nblk * e->D : nullptr;
-    rc = run_blocks(e, x2d, y_cur, e->cfg.seq2frame ? 1 : 0, tvec, 0, B, w, s);
+    int rc = run_blocks(e, x2d, y_cur, e->cfg.seq2frame ? 1 : 0, tvec, 0, B, w, s);
     if (rc) return rc;
     HeadArgs h{};
     rc = prep_head(e, h, B, w, s);
@@ -638,6 +649,57 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
       HIP_TRY(launch_head(h, s));
     }
   }
+  return D3D_OK;
+}
+}  // namespace
+
+int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, const float* step_noise, float* out,
+                    float* traj_rev, float* traj_x0, int32_t B, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_ready(e, B, ws, ws_bytes);
+  if (rc) return rc;
+  if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set (d3d_engine_set_schedule)");
+  if (!x2d || !init_noise || !out) return fail(D3D_EINVAL, "null tensor");
+  if (e->eta != 0.0f && !step_noise) return fail(D3D_EINVAL, "step_noise required when eta != 0");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Workspace w = carve(e, B, ws);
+  const bool use_graph = e->graph_mode && !traj_rev && !traj_x0 && e->eta == 0.0f && !e->profiling;
+  if (!use_graph) return ddim_loop(e, x2d, init_noise, step_noise, out, traj_rev, traj_x0, B, w, s);
+
+  // Graph replay: the captured launch sequence reads its inputs from / writes its result to fixed staging buffers
+  // inside the workspace, so one instantiated graph serves every call with the same (B, workspace).
+  const size_t xin_bytes = (size_t)B * e->T * e->J * e->cfg.in_chans * sizeof(float);
+  const size_t y_bytes = (size_t)head_rows(e, B) * 3 * sizeof(float);
+  hipGraphExec_t exec = nullptr;
+  for (auto& g : e->graphs)
+    if (g.B == B && g.ws == ws) exec = g.exec;
+  if (!exec) {
+    if (!e->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    {   // one eager pass first: kernels set their max-LDS attribute on first launch, which must not happen mid-capture
+      rc = ddim_loop(e, w.XIN, w.NIN, nullptr, w.OUTB, nullptr, nullptr, B, w, s);
+      if (rc) return rc;
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    rc = ddim_loop(e, w.XIN, w.NIN, nullptr, w.OUTB, nullptr, nullptr, B, w, e->cap_stream);
+    hipGraph_t graph = nullptr;
+    hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIP_TRY(ce);
+    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); HIP_TRY(ie); }
+    e->graphs.push_back({B, ws, graph, exec});
+  }
+  HIP_TRY(hipMemcpyAsync(w.XIN, x2d, xin_bytes, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(w.NIN, init_noise, y_bytes, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipGraphLaunch(exec, s));
+  HIP_TRY(hipMemcpyAsync(out, w.OUTB, y_bytes, hipMemcpyDeviceToDevice, s));
+  return D3D_OK;
+}
+
+int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on) {
+  if (!e) return fail(D3D_EINVAL, "null engine");
+  e->graph_mode = on != 0;
+  if (!e->graph_mode) e->drop_graphs();
   return D3D_OK;
 }
 

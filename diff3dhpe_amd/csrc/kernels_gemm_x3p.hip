@@ -308,10 +308,12 @@ hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, con
   const int ablate = variant >> 4;
   variant &= 15;
   if (variant == 0) {
-    // measured on MI355X at M = 264k (experiments/gemm_bench.py): 256x256 wins for every N in {512, 1024, 1536}
-    if (M < 2048 || N < 256) variant = 1;
-    else if (N % 256 == 0) variant = 3;
-    else variant = 2;
+    // Measured on MI355X (experiments/gemm_bench.py): at M = 264k the 256x256 tile wins for every N in {512,1024,1536}.
+    // Small batches need enough workgroups to fill 256 CUs for several rounds, so fall back to smaller tiles there.
+    auto wgs = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (N % 256 == 0 && wgs(256, 256) >= 1024) variant = 3;
+    else if (N % 128 == 0 && wgs(256, 128) >= 1024) variant = 2;
+    else variant = 1;
   }
   switch (variant) {
     case 1: return launch_tile<128, 128, 2, 2>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, s);

@@ -151,6 +151,10 @@ class Engine:
         return (out, rev, x0s) if trajectory else out
 
     # ---------------------------------------------------------------- profiling (HIP events inside the library)
+    def set_graph_mode(self, on: bool) -> None:
+        """Replay the whole DDIM loop as one hipGraph per (B, workspace) (eta == 0, no trajectory capture)."""
+        _lib.check(_lib.lib().d3d_engine_set_graph_mode(self._h, int(on)))
+
     def set_profiling(self, on: bool) -> None:
         _lib.check(_lib.lib().d3d_engine_set_profiling(self._h, int(on)))
 

@@ -110,6 +110,11 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d_dev, const float* init_noise
                     float* out_dev, float* traj_rev_dev, float* traj_x0_dev, int32_t B, void* ws_dev, size_t ws_bytes,
                     void* stream);
 
+/* hipGraph replay of d3d_ddim_sample: when enabled (and eta == 0, no trajectory capture, profiling off) the whole S-step
+ * launch sequence is captured once per (B, workspace pointer) and replayed with one hipGraphLaunch per call; inputs and
+ * the result go through staging buffers inside the workspace.  Weights / schedule changes drop the captured graphs. */
+int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
+
 /* q_sample (DIFF:360-366, extract DIFF:21-24): out = sqrt_ac[t_b] * x_start + sqrt(1-ac)[t_b] * noise, per row b.
  * n = elements per batch row. */
 int d3d_q_sample(d3d_engine* e, const float* x_start_dev, const float* noise_dev, const int32_t* t_dev, float* out_dev,

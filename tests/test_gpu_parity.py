@@ -206,3 +206,32 @@ def test_evaluate_harness_flip_tta():
     gtm = inp["gt3d"].view(-1, 17, 3)[mask.view(-1)].unsqueeze(1)
     assert abs(res["mpjpe_mm"] - orc.mpjpe(merged, gtm).item() * 1000) < 0.05
     assert res["frames"] == int(mask.sum())
+
+
+def test_hipgraph_replay_matches_eager_launches():
+    """cfg4 mechanics: the captured S-step graph must reproduce the eager launch sequence bit for bit, across replays,
+    batch sizes and a weight reload (which must drop the stale graphs)."""
+    cfg = cfg_full(27)
+    net, diff = build_product(cfg, 21, sampling=5, precision="f16x3")
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    z = lambda n: torch.zeros(n, 27, 17, 3, device="cuda")
+    outs = {}
+    for B in (3, 1):
+        inp = inputs(B, 27, 60 + B)
+        x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+        eng.set_graph_mode(False)
+        _, eager = diff(clean_3d_pose=z(B), noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+        eng.set_graph_mode(True)
+        for rep in range(3):
+            _, g = diff(clean_3d_pose=z(B), noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+            assert torch.equal(g, eager), (B, rep)
+        outs[B] = (x2d, nz, eager)
+    # new weights -> engines re-commit -> graphs dropped and re-captured with the new tensors
+    net.load_state_dict(torch_sd(cfg, 22))
+    eng2 = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    eng2.set_graph_mode(True)
+    x2d, nz, old = outs[3]
+    _, g_new = diff(clean_3d_pose=z(3), noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+    eng2.set_graph_mode(False)
+    _, e_new = diff(clean_3d_pose=z(3), noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+    assert torch.equal(g_new, e_new) and not torch.equal(g_new, old)
