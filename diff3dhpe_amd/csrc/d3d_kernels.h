@@ -23,9 +23,10 @@ void split_weight_f16x3(const float* w, size_t n, uint16_t* hi, uint16_t* lo);
 // ---- kernels_gemm_x3p.hip ---------------------------------------------------------------------------------------
 // F16X3 with pre-split operands: A planes (>= ceil(M/256)*256 rows allocated), W planes (>= ceil(N/256)*256 rows).
 // outsplit: write C as hi/lo planes of 8*c (for a following x3p GEMM) instead of fp32.  variant 0 = auto tile choice.
+// qcols: with outsplit, columns < qcols are written as planes of 1*c instead of 8*c (q third of a temporal qkv GEMM).
 hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias,
                              const float* R, float* C, void* Ch, void* Cl, int M, int N, int K, int epi, int outsplit,
-                             int variant, hipStream_t s);
+                             int qcols, int variant, hipStream_t s);
 hipError_t launch_split_x3(const float* x, void* hi, void* lo, size_t n, hipStream_t s);
 
 // ---- kernels_elem.hip -------------------------------------------------------------------------------------------
@@ -98,6 +99,12 @@ hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_hi, 
                                     hipStream_t s);
 hipError_t launch_attn_generic(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
                                int temporal, hipStream_t s);
+// ---- kernels_attn_x3.hip: temporal attention on fp16 MFMA with F16X3 accuracy; qkv and output as hi/lo planes
+hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int T, int J,
+                                   int D, int H, hipStream_t s);
+bool attn_temporal_x3_ok(int T, int D, int H);
+hipError_t launch_split_qkv(const float* x, void* hi, void* lo, size_t rows, int D, hipStream_t s);
+hipError_t launch_unsplit(const void* hi, const void* lo, float* x, size_t n, hipStream_t s);
 bool attn_spatial_fast_ok(int J, int D, int H);
 bool attn_temporal_fast_ok(int T, int D, int H);
 

@@ -270,11 +270,12 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   uint16_t* HIDh = reinterpret_cast<uint16_t*>(w.HID);
   uint16_t* HIDl = HIDh + Mp * e->Dm;
   // A: fp32 activation (FP32 mode) or its planes (F16X3 mode); `split_out`: write C as planes (fc1 -> fc2 hand-off)
+  int qcols_ = 0;
   auto linear = [&](const float* A, const uint16_t* Ah_, const uint16_t* Al_, const float* W, const uint16_t* Wh,
                     const uint16_t* Wl, const float* bias, const float* R, float* C, uint16_t* Ch_, uint16_t* Cl_, int N, int K,
                     int epi) -> hipError_t {
     Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), s);
-    if (x3) return launch_linear_x3p(Ah_, Al_, Wh, Wl, bias, R, C, Ch_, Cl_, M, N, K, epi, Ch_ != nullptr, 0, s);
+    if (x3) return launch_linear_x3p(Ah_, Al_, Wh, Wl, bias, R, C, Ch_, Cl_, M, N, K, epi, Ch_ != nullptr, qcols_, 0, s);
     return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
   };
   auto lnorm = [&](LnArgs a) -> hipError_t {
@@ -291,12 +292,23 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
-    HIP_TRY(linear(w.HN, HNh, HNl, bw.qkvw, bw.qkv_h, bw.qkv_l, bw.qkvb, nullptr, w.QKV, nullptr, nullptr, 3 * D, D, EPI_NONE));
+    // F16X3 temporal blocks: the qkv GEMM hands q/k/v to the fp16-MFMA attention kernel as hi/lo planes
+    const bool attn_x3 = x3 && temporal && attn_temporal_x3_ok(T, D, e->H);
+    uint16_t* QKVh = reinterpret_cast<uint16_t*>(w.QKV);
+    uint16_t* QKVl = QKVh + (size_t)M * 3 * D;
+    qcols_ = attn_x3 ? D : 0;
+    HIP_TRY(linear(w.HN, HNh, HNl, bw.qkvw, bw.qkv_h, bw.qkv_l, bw.qkvb, nullptr, w.QKV, attn_x3 ? QKVh : nullptr,
+                   attn_x3 ? QKVl : nullptr, 3 * D, D, EPI_NONE));
+    qcols_ = 0;
     {
       const int N = temporal ? T : J;
       Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
-      int rc = attention(e, w.QKV, w.HN, x3 ? HNh : nullptr, x3 ? HNl : nullptr, B, temporal, s);
-      if (rc) return rc;
+      if (attn_x3) {
+        HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, HNh, HNl, B, T, J, D, e->H, s));
+      } else {
+        int rc = attention(e, w.QKV, w.HN, x3 ? HNh : nullptr, x3 ? HNl : nullptr, B, temporal, s);
+        if (rc) return rc;
+      }
     }
     HIP_TRY(linear(w.HN, HNh, HNl, bw.projw, bw.proj_h, bw.proj_l, bw.projb, w.X, w.X, nullptr, nullptr, D, D, EPI_RESIDUAL));
     {  // h = norm2(x)
@@ -845,7 +857,7 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
   auto once = [&]() -> hipError_t {
     if (precision == D3D_PREC_FP32) return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
     if (variant == 9) return launch_linear_f16x3(A, wp.hi(), wp.lo(), bias, R, C, M, N, K, epi, s);   // on-the-fly A split
-    return launch_linear_x3p(ap.hi(), ap.lo(), wp.hi(), wp.lo(), bias, R, C, nullptr, nullptr, M, N, K, epi, 0, variant, s);
+    return launch_linear_x3p(ap.hi(), ap.lo(), wp.hi(), wp.lo(), bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s);
   };
   HIP_TRY(once());
   if (avg_ms) {
@@ -879,9 +891,23 @@ int d3d_op_layernorm(const float* x, const float* gamma, const float* beta, floa
 
 int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t J, int32_t D, int32_t H, int32_t temporal,
                      int32_t precision, int32_t force_generic, void* stream) {
-  if (precision != D3D_PREC_FP32) return fail(D3D_EUNSUP, "precision not implemented");
+  if (precision != D3D_PREC_FP32 && precision != D3D_PREC_F16X3) return fail(D3D_EUNSUP, "precision not implemented");
   if (!qkv || !out || B <= 0 || T <= 0 || J <= 0 || D <= 0 || H <= 0 || D % H) return fail(D3D_EINVAL, "bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (precision == D3D_PREC_F16X3 && temporal && !force_generic && attn_temporal_x3_ok(T, D, H)) {
+    // test hook: fp32 qkv -> planes (as the qkv GEMM epilogue writes them) -> fp16-MFMA attention -> planes -> fp32
+    const size_t rows = (size_t)B * T * J, nq = rows * 3 * D, no = rows * D;
+    uint16_t* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (2 * nq + 2 * no) * sizeof(uint16_t)));
+    hipError_t e1 = launch_split_qkv(qkv, tmp, tmp + nq, rows, D, s);
+    hipError_t e2 = (e1 == hipSuccess) ? launch_attn_temporal_x3(tmp, tmp + nq, tmp + 2 * nq, tmp + 2 * nq + no, B, T, J, D, H, s) : e1;
+    hipError_t e3 = (e2 == hipSuccess) ? launch_unsplit(tmp + 2 * nq, tmp + 2 * nq + no, out, no, s) : e2;
+    hipError_t e4 = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    HIP_TRY(e3);
+    HIP_TRY(e4);
+    return D3D_OK;
+  }
   if (!force_generic && !temporal && attn_spatial_fast_ok(J, D, H)) {
     HIP_TRY(launch_attn_spatial_f32(qkv, out, nullptr, nullptr, B, T, J, D, H, s));
   } else if (!force_generic && temporal && attn_temporal_fast_ok(T, D, H)) {

@@ -1,0 +1,258 @@
+// Temporal GRAND attention (S2S:75-83, groups = the T <= 256 frames of one joint) on the fp16 matrix pipe with
+// fp32-equivalent accuracy (the F16X3 scheme of kernels_gemm_x3p.hip applied to both attention products):
+//
+//   S^T = K Q^T / 8     3 x v_mfma_f32_32x32x16_f16 per 16-deep d-step on hi/lo planes of 8k and of q' = q/8
+//   e   = exp(S - max)  exact two-pass softmax numerator in fp32 registers (one query column per lane)
+//   O^T = V^T E^T       E split in-register into hi/lo of 1024 e (the accumulator tile IS the B operand of the next
+//                       MFMA after a pairwise fp16 conversion; its k-order permutation is matched on the V side)
+//   O   = O^T / (2^13 l) - v_query          (== (softmax - I) V)
+//
+// Inputs are the hi/lo fp16 planes the qkv GEMM epilogue writes for temporal blocks (q third pre-multiplied by
+// dh^-0.5 = 2^-3, exact); the output goes out as hi/lo planes for the proj GEMM.  One workgroup per (batch, joint,
+// head); K (row-major, 16-byte chunks XOR-swizzled by (row>>1)&7) and V^T (d-major, rows padded by 8 B) live in LDS
+// for the whole workgroup; each wave owns 32 queries.  12 + 12 MFMAs of 32 cycles replace 32 + 32 fp32 MFMAs of 64
+// cycles per 32x32 score tile: 5.3x less matrix-pipe time than k_attn_temporal_f32.
+#include "d3d_kernels.h"
+
+#include <math.h>
+
+namespace d3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int XDH = 64;
+
+__device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
+                                                               _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                               int T, int J, int H, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int TP = 32 * NKT;
+  constexpr int VT_LD = TP + 4;                       // halfs per V^T row (+8 B: 32 d-rows spread over all banks)
+  unsigned char* const sKh = lds;                     // [TP][128 B]
+  unsigned char* const sKl = lds + TP * 128;
+  _Float16* const sVh = reinterpret_cast<_Float16*>(lds + 2 * TP * 128);   // [64][VT_LD]
+  _Float16* const sVl = sVh + XDH * VT_LD;
+
+  const int unit = blockIdx.x;                        // (b*J + j)*H + hd
+  const int hd = unit % H;
+  const int bj = unit / H;
+  const int j = bj % J, b = bj / J;
+  const int D3 = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const size_t tok0 = (size_t)b * T * J + j;          // token(t) = tok0 + t*J
+
+  // ---- stage K (swizzled rows) and V^T (transposed) of this (batch, joint, head); pad rows are zero
+  for (int idx = tid; idx < TP * 8; idx += 64 * NKT) {
+    const int row = idx >> 3, c8 = idx & 7;
+    uint4 kh = make_uint4(0, 0, 0, 0), kl = kh, vh = kh, vl = kh;
+    if (row < T) {
+      const size_t o = (tok0 + (size_t)row * J) * D3 + hd * XDH + c8 * 8;
+      kh = *reinterpret_cast<const uint4*>(Ph + o + D);
+      kl = *reinterpret_cast<const uint4*>(Pl + o + D);
+      vh = *reinterpret_cast<const uint4*>(Ph + o + 2 * D);
+      vl = *reinterpret_cast<const uint4*>(Pl + o + 2 * D);
+    }
+    const int ko = kswz(row, c8);
+    *reinterpret_cast<uint4*>(sKh + ko) = kh;
+    *reinterpret_cast<uint4*>(sKl + ko) = kl;
+    const _Float16* vhp = reinterpret_cast<const _Float16*>(&vh);
+    const _Float16* vlp = reinterpret_cast<const _Float16*>(&vl);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sVh[(c8 * 8 + e) * VT_LD + row] = vhp[e];
+      sVl[(c8 * 8 + e) * VT_LD + row] = vlp[e];
+    }
+  }
+
+  // ---- this lane's query row as MFMA B fragments: d = 16 ks + 8 h .. +7
+  const int tq = 32 * wave + r;
+  h8 qh[4], ql[4];
+  {
+    const size_t o = (tok0 + (size_t)(tq < T ? tq : 0) * J) * D3 + hd * XDH + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (tq < T) {
+        qh[ks] = *reinterpret_cast<const h8*>(Ph + o + 16 * ks);
+        ql[ks] = *reinterpret_cast<const h8*>(Pl + o + 16 * ks);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qh[ks][e] = (_Float16)0.0f; ql[ks][e] = (_Float16)0.0f; }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S^T tiles: rows = keys kt*32 + (reg&3) + 8*(reg>>2) + 4*h, column = query tq; acc = 64 * s
+  f32x16 sacc[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sacc[kt][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ko = kswz(kt * 32 + r, 2 * ks + h);
+      const h8 kh = *reinterpret_cast<const h8*>(sKh + ko);
+      const h8 kl = *reinterpret_cast<const h8*>(sKl + ko);
+      sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc[kt], 0, 0, 0);
+      sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc[kt], 0, 0, 0);
+      sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc[kt], 0, 0, 0);
+    }
+  }
+
+  // ---- exact softmax numerator over the keys of this query column (fp32)
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      const float sv = (key < T) ? sacc[kt][q] * 0.015625f : -INFINITY;   // planes are 8k and 8q' (q' = q/8): acc = 64 s
+      sacc[kt][q] = sv;
+      m = fmaxf(m, sv);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float e = expf(sacc[kt][q] - m);
+      sacc[kt][q] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+
+  // ---- O^T[d][query] = sum_key V^T[d][key] * E^T[key][query].  k-step (kt, s) takes accumulator registers 8s..8s+7:
+  // element jj of lane half h is key kt*32 + 16 s + 8 (jj>>2) + 4 h + (jj&3); the V^T fragment is read in that order.
+  f32x16 oacc[2];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { oacc[0][q] = 0.f; oacc[1][q] = 0.f; }
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      h8 eh, el;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float ev = sacc[kt][8 * s + jj] * 1024.0f;          // e in [0,1] -> hi/lo of 2^10 e
+        const _Float16 hh = (_Float16)ev;
+        eh[jj] = hh;
+        el[jj] = (_Float16)(ev - (float)hh);
+      }
+      const int k0 = kt * 32 + 16 * s + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const _Float16* vh0 = sVh + (dt * 32 + r) * VT_LD + k0;
+        const _Float16* vl0 = sVl + (dt * 32 + r) * VT_LD + k0;
+        const h4 a0 = *reinterpret_cast<const h4*>(vh0), a1 = *reinterpret_cast<const h4*>(vh0 + 8);
+        const h4 c0 = *reinterpret_cast<const h4*>(vl0), c1 = *reinterpret_cast<const h4*>(vl0 + 8);
+        h8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; vl[e] = c0[e]; vl[4 + e] = c1[e]; }
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, eh, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, el, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, eh, oacc[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- O = O^T / (2^13 l) - v_query, written as hi/lo planes of 8*o for the proj GEMM
+  if (tq < T) {
+    const float inv = 1.0f / (8192.0f * l);
+    const size_t tokq = tok0 + (size_t)tq * J;
+    const size_t vo = tokq * D3 + 2 * D + hd * XDH;
+    const size_t oo = tokq * D + hd * XDH;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = dt * 32 + 8 * g4 + 4 * h;
+        const h4 vqh = *reinterpret_cast<const h4*>(Ph + vo + d);
+        const h4 vql = *reinterpret_cast<const h4*>(Pl + vo + d);
+        h4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
+          const float o = oacc[dt][4 * g4 + e] * inv - vq;
+          const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
+          oh[e] = (_Float16)sc;
+          ol[e] = (_Float16)(sc - (float)oh[e]);
+        }
+        *reinterpret_cast<h4*>(out_hi + oo + d) = oh;
+        *reinterpret_cast<h4*>(out_lo + oo + d) = ol;
+      }
+  }
+}
+
+bool attn_temporal_x3_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * XDH; }
+
+template <int NKT>
+static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16* oh, _Float16* ol, int B, int T, int J, int D,
+                                int H, hipStream_t s) {
+  const size_t lds_bytes = (size_t)2 * 32 * NKT * 128 + (size_t)2 * XDH * (32 * NKT + 4) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3<NKT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const long long grid = (long long)B * J * H;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_attn_temporal_x3<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, oh, ol, T, J, H, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int T, int J,
+                                   int D, int H, hipStream_t s) {
+  if (!attn_temporal_x3_ok(T, D, H) || !qkv_hi || !qkv_lo || !out_hi || !out_lo) return hipErrorInvalidValue;
+  const _Float16 *ph = (const _Float16*)qkv_hi, *pl = (const _Float16*)qkv_lo;
+  _Float16 *oh = (_Float16*)out_hi, *ol = (_Float16*)out_lo;
+  switch ((T + 31) / 32) {
+    case 1: return launch_x3_nkt<1>(ph, pl, oh, ol, B, T, J, D, H, s);
+    case 2: return launch_x3_nkt<2>(ph, pl, oh, ol, B, T, J, D, H, s);
+    case 3: return launch_x3_nkt<3>(ph, pl, oh, ol, B, T, J, D, H, s);
+    case 4: return launch_x3_nkt<4>(ph, pl, oh, ol, B, T, J, D, H, s);
+    case 5: return launch_x3_nkt<5>(ph, pl, oh, ol, B, T, J, D, H, s);
+    case 6: return launch_x3_nkt<6>(ph, pl, oh, ol, B, T, J, D, H, s);
+    case 7: return launch_x3_nkt<7>(ph, pl, oh, ol, B, T, J, D, H, s);
+    default: return launch_x3_nkt<8>(ph, pl, oh, ol, B, T, J, D, H, s);
+  }
+}
+
+// ---- helpers for the test hook: fp32 qkv -> planes (q third scaled by 2^-3), planes -> fp32
+__global__ __launch_bounds__(256) void k_split_qkv(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                   size_t n, int D3, int D) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int col = (int)(i % D3);
+  const float s = __builtin_amdgcn_fmed3f(x[i] * (col < D ? 1.0f : 8.0f), -65504.0f, 65504.0f);
+  const _Float16 hh = (_Float16)s;
+  hi[i] = hh;
+  lo[i] = (_Float16)(s - (float)hh);
+}
+
+__global__ __launch_bounds__(256) void k_unsplit(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
+                                                 float* __restrict__ x, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = ((float)hi[i] + (float)lo[i]) * 0.125f;
+}
+
+hipError_t launch_split_qkv(const float* x, void* hi, void* lo, size_t rows, int D, hipStream_t s) {
+  const size_t n = rows * 3 * (size_t)D;
+  hipLaunchKernelGGL(k_split_qkv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, n, 3 * D, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_unsplit(const void* hi, const void* lo, float* x, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_unsplit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const _Float16*)hi, (const _Float16*)lo, x, n);
+  return hipGetLastError();
+}
+
+}  // namespace d3d

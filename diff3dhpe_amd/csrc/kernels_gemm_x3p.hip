@@ -43,7 +43,7 @@ __device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ (
 template <int TMI, int TNJ, int EPI, int OUTSPLIT, bool CHECK>
 __device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], float* patch, const float* __restrict__ bias,
                                              const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0,
-                                             int lane, int M, int N) {
+                                             int lane, int M, int N, int qcols) {
   constexpr int LD = 32 * TNJ + 4;          // floats per patch row
   constexpr int LPR = 8 * TNJ;              // lanes per row on the read side (one float4 each)
   constexpr int RPP = 64 / LPR;             // rows per pass
@@ -78,11 +78,12 @@ __device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], float* pat
         const float4 r4 = *reinterpret_cast<const float4*>(Rt + off);
         v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
       }
-      if (OUTSPLIT) {   // the consumer is another x3p GEMM: hand it hi/lo planes of 8*v
-        h4 hh, ll;
+      if (OUTSPLIT) {   // the consumer is an F16X3 kernel: hand it hi/lo planes of 8*v (q columns of a qkv GEMM for the
+        h4 hh, ll;      // temporal attention carry the dh^-0.5 = 2^-3 attention scale, i.e. planes of 1*v)
+        const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float sc = __builtin_amdgcn_fmed3f(v[e] * P_A_SCALE, -65504.0f, 65504.0f);
+          const float sc = __builtin_amdgcn_fmed3f(v[e] * osc, -65504.0f, 65504.0f);
           hh[e] = (_Float16)sc;
           ll[e] = (_Float16)(sc - (float)hh[e]);
         }
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
                                                              const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
                                                              const float* __restrict__ bias, const float* R, float* C,
                                                              _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
-                                                             int ntiles, int ablate) {
+                                                             int ntiles, int ablate, int qcols) {
   // ablate (timing experiments only): 4 = no epilogue stores
   constexpr int NW = WM * WN;
   constexpr int TMI = BM / WM / 32, TNJ = BN / WN / 32;
@@ -242,15 +243,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
   __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
   float* patch = reinterpret_cast<float*>(lds) + wave * (32 * (32 * TNJ + 4));
   if (m0 + BM <= M && n0 + BN <= N)
-    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N);
+    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
   else
-    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N);
+    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
 }
 
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_tile(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl,
                               const float* bias, const float* R, float* C, _Float16* Ch, _Float16* Cl, int M, int N, int K,
-                              int epi, int outsplit, int ablate, hipStream_t s) {
+                              int epi, int outsplit, int ablate, int qcols, hipStream_t s) {
   const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
   const size_t lds_bytes = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
@@ -265,7 +266,7 @@ static hipError_t launch_tile(const _Float16* Ah, const _Float16* Al, const _Flo
       attr_done = true;                                                                                                   \
     }                                                                                                                     \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WM * WN), lds_bytes, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K,    \
-                       mtiles, ntiles, ablate);                                                                           \
+                       mtiles, ntiles, ablate, qcols);                                                                    \
   } while (0)
   if (outsplit) {
     if (epi == EPI_GELU) D3D_X3P_LAUNCH(EPI_GELU, 1);
@@ -292,14 +293,14 @@ static hipError_t launch_abl(const _Float16* Ah, const _Float16* Al, const _Floa
   hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (ae != hipSuccess) return ae;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ah, Al, Wh, Wl, bias, nullptr, C, nullptr, nullptr, M, N, K,
-                     mtiles, ntiles, ablate);
+                     mtiles, ntiles, ablate, 0);
   return hipGetLastError();
 }
 
 // variant: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256
 hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias,
                              const float* R, float* C, void* Ch, void* Cl, int M, int N, int K, int epi, int outsplit,
-                             int variant, hipStream_t s) {
+                             int qcols, int variant, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % PBK) != 0 || (N % 4) != 0) return hipErrorInvalidValue;
   if (epi == EPI_RESIDUAL && R == nullptr) return hipErrorInvalidValue;
   if (outsplit ? (!Ch || !Cl) : !C) return hipErrorInvalidValue;
@@ -316,9 +317,9 @@ hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, con
     else variant = 1;
   }
   switch (variant) {
-    case 1: return launch_tile<128, 128, 2, 2>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, s);
-    case 2: return launch_tile<256, 128, 4, 2>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, s);
-    case 3: return launch_tile<256, 256, 2, 4>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, s);
+    case 1: return launch_tile<128, 128, 2, 2>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
+    case 2: return launch_tile<256, 128, 4, 2>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
+    case 3: return launch_tile<256, 256, 2, 4>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 4: return launch_abl<1>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);   // timing experiments (wrong results)
     case 5: return launch_abl<2>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);
     case 6: return launch_abl<3>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);

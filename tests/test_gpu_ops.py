@@ -109,6 +109,9 @@ def test_attention_core(B, T, J, D, H, temporal, generic):
     out = E.op_attention(qkv, B, T, J, H, temporal, force_generic=generic)
     ref = _attn_ref(qkv, B, T, J, H, temporal)
     assert maxabs(out, ref.cpu()) < 5e-6
+    if temporal and not generic:   # the fp16-MFMA (F16X3) temporal kernel: planes in, planes out, fp32-level accuracy
+        out3 = E.op_attention(qkv, B, T, J, H, True, precision="f16x3")
+        assert maxabs(out3, ref.cpu()) < 5e-6
 
 
 def test_attention_fast_kernels_agree_with_generic_on_sharp_softmax():
@@ -126,6 +129,9 @@ def test_attention_fast_kernels_agree_with_generic_on_sharp_softmax():
         assert torch.isfinite(a).all() and torch.isfinite(b).all()
         assert maxabs(a, ref.cpu()) < 2e-3 and maxabs(b, ref.cpu()) < 2e-3
         assert maxabs(a, b.cpu()) < 2e-3
+        if temporal:
+            c = E.op_attention(qkv, B, T, J, 8, True, precision="f16x3")
+            assert torch.isfinite(c).all() and maxabs(c, ref.cpu()) < 2e-3
 
 
 GOLD_ATTN = [("spatial_D512", 512, 17, 2), ("spatial_D32", 32, 17, 4), ("temporal_D512_T27", 512, 27, 1),
