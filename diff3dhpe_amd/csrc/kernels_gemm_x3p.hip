@@ -37,14 +37,14 @@ __device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ (
 // Epilogue of one wave.  The MFMAs are issued with the WEIGHT fragment as the first operand, so an accumulator tile
 // holds C^T: column (lane&31) = token row m, registers = output columns n = 8*(reg>>2) + 4*(lane>>5) + (reg&3).
 // Each 32-row strip of the wave tile is transposed through a wave-private LDS patch (ds_write_b128 of 4 consecutive
-// n per lane, 272-byte rows -> conflict-free) and read back row-major, 16 bytes per lane with 8*TNJ lanes per row,
+// n per lane, chunk index XOR (row&7) -> conflict-free) and read back row-major, 16 bytes per lane with 8*TNJ lanes per row,
 // so every global store / residual load instruction covers whole 128-byte lines (a store tail of partial lines or of
 // 4-byte-per-lane stores costs more than the transpose).  Addressing is (wave-uniform tile base) + 32-bit offsets.
 template <int TMI, int TNJ, int EPI, int OUTSPLIT, bool CHECK>
 __device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], float* patch, const float* __restrict__ bias,
                                              const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0,
                                              int lane, int M, int N, int qcols) {
-  constexpr int LD = 32 * TNJ + 4;          // floats per patch row
+  constexpr int LD = 32 * TNJ;              // floats per patch row; 16-byte chunks XOR-swizzled by (row & 7)
   constexpr int LPR = 8 * TNJ;              // lanes per row on the read side (one float4 each)
   constexpr int RPP = 64 / LPR;             // rows per pass
   constexpr int NPASS = 32 / RPP;
@@ -60,12 +60,12 @@ __device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], float* pat
     for (int j = 0; j < TNJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(patch + r * LD + 32 * j + 8 * g + 4 * h) =
+        *reinterpret_cast<float4*>(patch + r * LD + (((8 * j + 2 * g + h) ^ (r & 7)) << 2)) =
             make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int row = rrow + RPP * p;
-      const float4 a4 = *reinterpret_cast<const float4*>(patch + row * LD + 4 * rc4);
+      const float4 a4 = *reinterpret_cast<const float4*>(patch + row * LD + ((rc4 ^ (row & 7)) << 2));
       const int m = mt0 + 32 * i + row;
       if (CHECK && (m >= M || !ncol_ok)) continue;
       const int off = (32 * i + row) * N + 4 * rc4;
@@ -97,7 +97,16 @@ __device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], float* pat
   }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int OUTSPLIT, int ABL = 0>
+// Byte offset of logical 16-byte chunk c of tile row `row` in a plane whose rows are BK fp16 wide.  The XOR spreads the
+// rows a ds_read_b128 16-lane group touches over 16 distinct 4-bank slots (64-B rows: 4 rows per 256-B bank row ->
+// XOR (row>>2)&3; 32-B rows: 8 rows per bank row -> XOR (row>>3)&1).
+template <int BK>
+__device__ __forceinline__ int swzk(int row, int c) {
+  if (BK == 32) return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+  return row * 32 + ((c ^ ((row >> 3) & 1)) << 4);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int OUTSPLIT, int ABL = 0, int BK = 32>
 __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
                                                              const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
                                                              const float* __restrict__ bias, const float* R, float* C,
@@ -106,10 +115,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
   // ablate (timing experiments only): 4 = no epilogue stores
   constexpr int NW = WM * WN;
   constexpr int TMI = BM / WM / 32, TNJ = BN / WN / 32;
-  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;             // bytes
+  constexpr int RB = BK * 2;                                       // bytes per plane row in a k-tile
+  constexpr int CPR = RB / 16;                                     // 16-byte chunks per row
+  constexpr int RPI = 1024 / RB;                                   // rows per 1-KiB DMA instruction
+  constexpr int KS = BK / 16;                                      // MFMA k-steps per k-tile
+  constexpr int A_PLANE = BM * RB, B_PLANE = BN * RB;              // bytes
   constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
-  constexpr int A_INSTR = BM / 16, B_INSTR = BN / 16;              // 1-KiB DMA instructions per plane
+  constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;            // DMA instructions per plane
   static_assert(NW % 4 == 0 && A_INSTR % (NW / 4) == 0 && B_INSTR % (NW / 4) == 0, "planes must split evenly over the waves");
+  static_assert(2 * STAGE >= NW * 32 * (32 * TNJ) * 4, "epilogue patches must fit in the operand stages");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int bid = blockIdx.x;
@@ -126,22 +140,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
   const int r = lane & 31, h = lane >> 5;
 
   // ---- DMA plan (branch-free): wave w streams plane (w & 3) in {A_hi, A_lo, W_hi, W_lo}; the NW/4 waves that share
-  // a plane split its 16-row groups.  A lane moves row (16 g + lane/4), LDS slot lane%4, and fetches the source chunk
-  // slot ^ ((row>>2)&3): the swizzle lives on the SOURCE address, the LDS image stays lane-linear.
+  // a plane split its RPI-row groups.  A lane moves row (RPI g + lane/CPR), LDS slot lane%CPR, and fetches the source
+  // chunk given by the swizzle: the XOR lives on the SOURCE address, the LDS image stays lane-linear.
   // Contract: the A planes hold >= mtiles*BM rows and the W planes >= ntiles*BN rows (padding rows are never stored).
   constexpr int WPP = NW / 4;                                      // waves per plane
   const int plane = wave & 3, part = wave >> 2;
   const bool isA = plane < 2;
   const int n_it = (isA ? A_INSTR : B_INSTR) / WPP;                 // wave-uniform trip count
   const int g0 = part * n_it;
-  const int lrow = lane >> 2, lslot = lane & 3;
+  const int lrow = lane / CPR, lslot = lane % CPR;
   const _Float16* src;
   {
     const _Float16* pb = (plane == 0) ? Ah : (plane == 1) ? Al : (plane == 2) ? Wh : Wl;
-    const int row0 = (isA ? m0 : n0) + g0 * 16 + lrow;
-    src = pb + (size_t)row0 * K + ((lslot ^ ((lrow >> 2) & 3)) << 3);
+    const int row0 = (isA ? m0 : n0) + g0 * RPI + lrow;
+    src = pb + (size_t)row0 * K + (swzk<BK>(lrow, lslot) - lrow * RB) / 2;   // swizzled chunk of this lane's row, in halfs
   }
-  const size_t it_stride = (size_t)16 * K;                          // elements between successive 16-row groups
+  const size_t it_stride = (size_t)RPI * K;                         // elements between successive row groups
   const int dst0 = (isA ? plane * A_PLANE : 2 * A_PLANE + (plane - 2) * B_PLANE) + g0 * 1024 + lane * 16;
   constexpr int MAX_IT = (A_INSTR > B_INSTR ? A_INSTR : B_INSTR) / WPP;
 
@@ -165,18 +179,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
   const int arow0 = wm * (BM / WM) + r, brow0 = wn * (BN / WN) + r;
-  const int nk = K / PBK;
-  constexpr int NG = 2 * TMI;                                  // MFMA groups per k-tile: (k-step, m-tile)
+  const int nk = K / BK;
+  constexpr int NG = KS * TMI;                                 // MFMA groups per k-tile: (k-step, m-tile)
   constexpr int PPG = (MAX_IT + NG - 1) / NG;                  // DMA pieces issued per group
   D3D_STAGE_ALL(0, 0);
   // One k-tile: software pipeline over the NG groups -- the fragments of group g+1 are read from LDS, and one slice of
   // the NEXT k-tile's DMA is issued, BEFORE the 3*TNJ MFMAs of group g, so LDS latency and DMA issue hide under MFMAs.
   // The body is branch-free (the last k-tile, which has nothing to prefetch, is peeled) so that it stays one scheduling
   // region and hipcc emits counted lgkmcnt waits instead of lgkmcnt(0) at block boundaries.
+#define D3D_FRAG_C(KSI) ((BK == 32) ? (2 * (KSI) + h) : h) /* lane half h feeds k = 16 ks + 8 h .. +7 of the MFMA */
 #define D3D_KTILE(KT, PREFETCH)                                                                                          \
   do {                                                                                                                   \
     if (ABL != 3) __syncthreads(); /* own DMA drained (vmcnt(0)) + everyone done reading the other stage */             \
-    const int nst = ((KT) + 1) & 1, nk0 = ((KT) + 1) * PBK;                                                              \
+    const int nst = ((KT) + 1) & 1, nk0 = ((KT) + 1) * BK;                                                               \
     const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                  \
     const unsigned char* sAh = sb;                                                                                       \
     const unsigned char* sAl = sb + A_PLANE;                                                                             \
@@ -184,12 +199,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
     const unsigned char* sBl = sb + 2 * A_PLANE + B_PLANE;                                                               \
     h8 bh[2][TNJ], bl[2][TNJ], ah[2], al[2];                                                                             \
     _Pragma("unroll") for (int j = 0; j < TNJ; ++j) {                                                                    \
-      const int ob = swz64(brow0 + 32 * j, h);                                                                           \
+      const int ob = swzk<BK>(brow0 + 32 * j, D3D_FRAG_C(0));                                                            \
       bh[0][j] = *reinterpret_cast<const h8*>(sBh + ob);                                                                 \
       bl[0][j] = *reinterpret_cast<const h8*>(sBl + ob);                                                                 \
     }                                                                                                                    \
     {                                                                                                                    \
-      const int oa = swz64(arow0, h);                                                                                    \
+      const int oa = swzk<BK>(arow0, D3D_FRAG_C(0));                                                                     \
       ah[0] = *reinterpret_cast<const h8*>(sAh + oa);                                                                    \
       al[0] = *reinterpret_cast<const h8*>(sAl + oa);                                                                    \
     }                                                                                                                    \
@@ -197,12 +212,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
       const int ks = g / TMI, i = g % TMI;                                                                               \
       if (g + 1 < NG && (ABL != 2 || (KT) == 0)) {                                                                       \
         const int ks2 = (g + 1) / TMI, i2 = (g + 1) % TMI;                                                               \
-        const int oa = swz64(arow0 + 32 * i2, 2 * ks2 + h);                                                              \
+        const int oa = swzk<BK>(arow0 + 32 * i2, D3D_FRAG_C(ks2));                                                       \
         ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sAh + oa);                                                        \
         al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sAl + oa);                                                        \
         if (i2 == 0) {                                                                                                   \
           _Pragma("unroll") for (int j = 0; j < TNJ; ++j) {                                                              \
-            const int ob = swz64(brow0 + 32 * j, 2 * ks2 + h);                                                           \
+            const int ob = swzk<BK>(brow0 + 32 * j, D3D_FRAG_C(ks2));                                                    \
             bh[ks2 & 1][j] = *reinterpret_cast<const h8*>(sBh + ob);                                                     \
             bl[ks2 & 1][j] = *reinterpret_cast<const h8*>(sBl + ob);                                                     \
           }                                                                                                              \
@@ -228,11 +243,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
   for (; kt + 1 < nk; ++kt) D3D_KTILE(kt, true);
   D3D_KTILE(kt, false);
 #undef D3D_KTILE
+#undef D3D_FRAG_C
 
 #undef D3D_STAGE_ONE
 #undef D3D_STAGE_ALL
-  // epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Interior tiles take the branch-free
-  // path (a per-element bounds branch makes hipcc wait vmcnt(0) -- i.e. for the previous STORE -- before every store).
   if ((ablate & 4) && acc[0][0][0] != 12345.678f) return;
   const int mt0 = m0 + wm * (BM / WM), nt0 = n0 + wn * (BN / WN);          // wave-uniform
   const size_t tbase = (size_t)mt0 * N + nt0;
@@ -241,23 +255,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
   _Float16* Cht = Ch ? Ch + tbase : nullptr;
   _Float16* Clt = Cl ? Cl + tbase : nullptr;
   __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
-  float* patch = reinterpret_cast<float*>(lds) + wave * (32 * (32 * TNJ + 4));
+  float* patch = reinterpret_cast<float*>(lds) + wave * (32 * 32 * TNJ);
   if (m0 + BM <= M && n0 + BN <= N)
     x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
   else
     x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 static hipError_t launch_tile(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl,
                               const float* bias, const float* R, float* C, _Float16* Ch, _Float16* Cl, int M, int N, int K,
                               int epi, int outsplit, int ablate, int qcols, hipStream_t s) {
   const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  const size_t lds_bytes = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
+  const size_t lds_bytes = 2 * (size_t)(2 * BM * BK * 2 + 2 * BN * BK * 2);
 #define D3D_X3P_LAUNCH(EPI_, OS_)                                                                                         \
   do {                                                                                                                    \
-    auto kfn = k_linear_x3p<BM, BN, WM, WN, EPI_, OS_>;                                                                   \
+    auto kfn = k_linear_x3p<BM, BN, WM, WN, EPI_, OS_, 0, BK>;                                                                 \
     static bool attr_done = false;                                                                                        \
     if (!attr_done) {                                                                                                     \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -320,6 +334,8 @@ hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, con
     case 1: return launch_tile<128, 128, 2, 2>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 2: return launch_tile<256, 128, 4, 2>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 3: return launch_tile<256, 256, 2, 4>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
+    case 7: return launch_tile<256, 128, 2, 2, 16>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
+    case 8: return launch_tile<256, 256, 2, 4, 16>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 4: return launch_abl<1>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);   // timing experiments (wrong results)
     case 5: return launch_abl<2>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);
     case 6: return launch_abl<3>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);

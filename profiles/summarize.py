@@ -17,7 +17,27 @@ import sys
 from collections import defaultdict
 
 
+_DEMANGLE = {}
+
+
+def demangle(name: str) -> str:
+    if not name.startswith("_Z"):
+        return name
+    if name not in _DEMANGLE:
+        out = name
+        for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+            try:
+                import subprocess
+                out = subprocess.run([tool, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+                break
+            except Exception:
+                continue
+        _DEMANGLE[name] = out
+    return _DEMANGLE[name]
+
+
 def short(name: str) -> str:
+    name = demangle(name)
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("d3d::", "")
     return name.strip()[:70]
