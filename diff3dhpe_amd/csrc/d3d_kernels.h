@@ -89,6 +89,9 @@ hipError_t launch_q_sample(const float* x_start, const float* noise, const int32
 hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, const uint8_t* mask, float scale,
                             const int32_t* perm_dev, float* merged, double* sums, int B, int T, int J, hipStream_t s);
 
+hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const int32_t* perm_dev, int n, int T, int J, int C,
+                                int flip, hipStream_t s);
+
 // ---- kernels_attn.hip -------------------------------------------------------------------------------------------
 // qkv: (B*T*J, 3*D) -> out (B*T*J, D), GRAND core  O = softmax(q k^T * dh^-0.5) v - v
 // When out_hi/out_lo are non-null the result is written as fp16 hi/lo planes of 8*o (F16X3 GEMM operand) and `out`

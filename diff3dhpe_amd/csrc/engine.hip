@@ -758,6 +758,32 @@ int d3d_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, co
   return D3D_OK;
 }
 
+int d3d_num_windows(int32_t n_frames, int32_t T) { return (n_frames < 1 || T < 1) ? 0 : (n_frames + T - 1) / T; }
+
+int d3d_window_gather(const float* seq, int32_t n_frames, int32_t T, int32_t J, int32_t C, int32_t flip, const int32_t* jl,
+                      const int32_t* jr, int32_t n_lr, float* out, uint8_t* mask, void* stream) {
+  if (!seq || !out || n_frames < 1 || T < 1 || J < 1 || C < 1) return fail(D3D_EINVAL, "bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int32_t* perm_dev = nullptr;
+  if (flip) {
+    std::vector<int32_t> perm(J);
+    for (int j = 0; j < J; ++j) perm[j] = j;
+    for (int i = 0; i < n_lr; ++i) {  // GEN:274-275: batch[:, left+right] = batch[:, right+left]
+      if (!jl || !jr || jl[i] < 0 || jl[i] >= J || jr[i] < 0 || jr[i] >= J) return fail(D3D_EINVAL, "joint index out of range");
+      perm[jl[i]] = jr[i];
+      perm[jr[i]] = jl[i];
+    }
+    HIP_TRY(hipMalloc(&perm_dev, J * sizeof(int32_t)));
+    hipError_t ce = hipMemcpyAsync(perm_dev, perm.data(), J * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (ce != hipSuccess) { (void)hipFree(perm_dev); HIP_TRY(ce); }
+    (void)hipStreamSynchronize(s);   // perm is a host temporary
+  }
+  hipError_t le = launch_window_gather(seq, out, mask, perm_dev, n_frames, T, J, C, flip ? 1 : 0, s);
+  if (perm_dev) { (void)hipStreamSynchronize(s); (void)hipFree(perm_dev); }
+  HIP_TRY(le);
+  return D3D_OK;
+}
+
 // ---- profiling ------------------------------------------------------------------------------------------------------
 int d3d_engine_set_profiling(d3d_engine* e, int32_t on) {
   if (!e) return fail(D3D_EINVAL, "null engine");

@@ -18,6 +18,7 @@ namespace d3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h4a __attribute__((ext_vector_type(4)));
+typedef _Float16 h8a __attribute__((ext_vector_type(8)));
 
 // fp32 -> (hi, lo) fp16 pair of 8*x: the operand format of the F16X3 GEMM (kernels_gemm_x3p.hip)
 __device__ __forceinline__ void split1_x3(float x, _Float16& hi, _Float16& lo) {
@@ -127,9 +128,20 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
   }
   if (valid) {
     const size_t oo = ((size_t)g * NJ + i) * D + h * SP_DH;
-    if (out_hi) {
+    if (out_hi) {   // 16-byte stores: 8 fp16 per plane per instruction
 #pragma unroll
-      for (int c = 0; c < SP_DH; c += 4) store4_x3(out_hi + oo + c, out_lo + oo + c, o[c], o[c + 1], o[c + 2], o[c + 3]);
+      for (int c = 0; c < SP_DH; c += 8) {
+        h8a hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          _Float16 x, y;
+          split1_x3(o[c + e], x, y);
+          hi[e] = x;
+          lo[e] = y;
+        }
+        *reinterpret_cast<h8a*>(out_hi + oo + c) = hi;
+        *reinterpret_cast<h8a*>(out_lo + oo + c) = lo;
+      }
     } else {
 #pragma unroll
       for (int c = 0; c < SP_DH; c += 4) *reinterpret_cast<float4*>(out + oo + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);

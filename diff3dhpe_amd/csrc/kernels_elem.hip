@@ -144,48 +144,73 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ input embedding
-// One thread per (token, 4 columns).  x2d and y rows are broadcast-read (L1), X is a pure streaming write.
+// X[m, c] = sum_k in[m,k] Wf[c,k] + bf[c] + spos[j,c] (+ tvec[b,c]);  in = cat(x2d[m], y[m or (b,j)]) (DIFF:255 / S2S:250).
+// A thread owns 4 columns and keeps their CIN weights + bias in registers; the block walks a run of tokens, so the
+// kernel is a pure streaming write of X (the 5 input scalars of a token are wave-uniform broadcast loads).
+template <int CIN2>
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ x2d, const float* __restrict__ y,
                                                const float* __restrict__ Wf, const float* __restrict__ bf,
                                                const float* __restrict__ spos, const float* __restrict__ tvec,
-                                               int64_t tvec_stride, float* __restrict__ X, int B, int T, int J, int D,
-                                               int cin2, int y_bcast_T) {
+                                               int64_t tvec_stride, float* __restrict__ X, int M, int T, int J, int D,
+                                               int y_bcast_T, int tokens_per_block) {
+  constexpr int CIN = CIN2 + 3;
   const int D4 = D >> 2;
-  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t total = (size_t)B * T * J * D4;
-  if (gid >= total) return;
-  const int c = (int)(gid % D4) * 4;
-  const size_t m = gid / D4;
-  const int j = (int)(m % J);
-  const size_t bt = m / J;
-  const int b = (int)(bt / T);
-  float in[8];
-  const int cin = cin2 + 3;
-  for (int k = 0; k < cin2; ++k) in[k] = x2d[m * cin2 + k];
-  const size_t my = y_bcast_T ? ((size_t)b * J + j) : m;  // DIFF-S2F:281: y.repeat(1, f, 1, 1)
-  for (int k = 0; k < 3; ++k) in[cin2 + k] = y[my * 3 + k];
-  float o[4];
+  const int cgroups = (D4 + 255) / 256;                 // column groups of 256 threads x 4 columns
+  const int cg = blockIdx.x % cgroups;
+  const int c = (cg * 256 + threadIdx.x) * 4;
+  if (c >= D) return;
+  float w[4][CIN], bias[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float* w = Wf + (size_t)(c + q) * cin;
-    float acc = 0.f;
-    for (int k = 0; k < cin; ++k) acc = fmaf(in[k], w[k], acc);
-    acc += bf[c + q];
-    acc += spos[(size_t)j * D + c + q];
-    if (tvec) acc += tvec[(size_t)b * tvec_stride + c + q];
-    o[q] = acc;
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) w[q][k] = Wf[(size_t)(c + q) * CIN + k];
+    bias[q] = bf[c + q];
   }
-  *reinterpret_cast<float4*>(X + m * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+  const int m_begin = (blockIdx.x / cgroups) * tokens_per_block;
+  const int m_end = min(M, m_begin + tokens_per_block);
+  for (int m = m_begin; m < m_end; ++m) {
+    const int j = m % J;
+    const int b = m / (T * J);
+    float in[CIN];
+#pragma unroll
+    for (int k = 0; k < CIN2; ++k) in[k] = x2d[(size_t)m * CIN2 + k];
+    const size_t my = y_bcast_T ? ((size_t)b * J + j) : (size_t)m;  // DIFF-S2F:281: y.repeat(1, f, 1, 1)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) in[CIN2 + k] = y[my * 3 + k];
+    const float4 sp = *reinterpret_cast<const float4*>(spos + (size_t)j * D + c);
+    float4 tv = make_float4(0, 0, 0, 0);
+    if (tvec) tv = *reinterpret_cast<const float4*>(tvec + (size_t)b * tvec_stride + c);
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < CIN; ++k) acc = fmaf(in[k], w[q][k], acc);
+      o[q] = acc + bias[q];
+    }
+    o[0] += sp.x; o[1] += sp.y; o[2] += sp.z; o[3] += sp.w;
+    if (tvec) { o[0] += tv.x; o[1] += tv.y; o[2] += tv.z; o[3] += tv.w; }
+    *reinterpret_cast<float4*>(X + (size_t)m * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
 }
 
 hipError_t launch_embed(const float* x2d, const float* y, const float* Wf, const float* bf, const float* spos,
                         const float* tvec, int64_t tvec_stride, float* X, int B, int T, int J, int D, int in_chans,
                         int y_bcast_T, hipStream_t s) {
   if ((D & 3) || in_chans < 1 || in_chans > 5) return hipErrorInvalidValue;
-  const size_t total = (size_t)B * T * J * (D >> 2);
-  const unsigned grid = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(k_embed, dim3(grid), dim3(256), 0, s, x2d, y, Wf, bf, spos, tvec, tvec_stride, X, B, T, J, D,
-                     in_chans, y_bcast_T);
+  const int M = B * T * J;
+  const int cgroups = ((D >> 2) + 255) / 256;
+  const int tpb = 32;
+  const unsigned grid = (unsigned)(((M + tpb - 1) / tpb) * cgroups);
+#define D3D_EMBED(C2)                                                                                                   \
+  case C2:                                                                                                              \
+    hipLaunchKernelGGL(k_embed<C2>, dim3(grid), dim3(256), 0, s, x2d, y, Wf, bf, spos, tvec, tvec_stride, X, M, T, J, D, \
+                       y_bcast_T, tpb);                                                                                 \
+    break;
+  switch (in_chans) {
+    D3D_EMBED(1) D3D_EMBED(2) D3D_EMBED(3) D3D_EMBED(4) D3D_EMBED(5)
+  }
+#undef D3D_EMBED
   return hipGetLastError();
 }
 
@@ -405,6 +430,41 @@ hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const flo
   const int total = B * T * J;
   hipLaunchKernelGGL(k_tta_mpjpe, dim3((total + 255) / 256), dim3(256), 0, s, pred, pred_flip, gt, mask, scale, perm_dev,
                      merged, sums, B * T, J);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ eval windows
+// ChunkedGenerator(out_all=True, pad=0) for one sequence (GEN:27-48, 247-276): non-overlapping T-frame windows, the last
+// one shifted back to end at the last frame, frames it shares with its predecessor masked out; sequences shorter than T
+// are edge-padded.  Optionally the horizontally flipped copy (x -> -x on channel 0, left/right joints swapped).
+__global__ __launch_bounds__(256) void k_window_gather(const float* __restrict__ seq, float* __restrict__ out,
+                                                       uint8_t* __restrict__ mask, const int32_t* __restrict__ perm, int n,
+                                                       int T, int J, int C, int nc, int flip) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)nc * T * J;
+  if (gid >= total) return;
+  const int j = (int)(gid % J);
+  const int t = (int)((gid / J) % T);
+  const int c = (int)(gid / ((long long)J * T));
+  int f = (c < nc - 1 ? c * T : n - T) + t;
+  f = f < 0 ? 0 : (f > n - 1 ? n - 1 : f);
+  const int js = flip ? perm[j] : j;
+  const float* sp = seq + ((size_t)f * J + js) * C;
+  float* op = out + (size_t)gid * C;
+  for (int k = 0; k < C; ++k) op[k] = (flip && k == 0) ? -sp[k] : sp[k];
+  if (mask && j == 0) {
+    const int n_unused = nc * T - n;
+    mask[(size_t)c * T + t] = (n >= T && c == nc - 1 && t < n_unused) ? 0 : 1;
+  }
+}
+
+hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const int32_t* perm_dev, int n, int T, int J, int C,
+                                int flip, hipStream_t s) {
+  if (n < 1 || T < 1 || J < 1 || C < 1) return hipErrorInvalidValue;
+  const int nc = (n + T - 1) / T;
+  const long long total = (long long)nc * T * J;
+  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, seq, out, mask, perm_dev, n, T, J, C,
+                     nc, flip);
   return hipGetLastError();
 }
 

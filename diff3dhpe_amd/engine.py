@@ -275,3 +275,19 @@ def tta_mpjpe(pred: torch.Tensor, pred_flip: Optional[torch.Tensor], gt: torch.T
                                             _ptr(merged), _ptr(sums), B, T, J, st))
     s = sums.cpu()
     return (float(s[0]), int(s[1]), merged) if want_merged else (float(s[0]), int(s[1]))
+
+
+def window_gather(seq: torch.Tensor, T: int, flip: bool = False, joints_left=(), joints_right=(), want_mask: bool = True):
+    """(n, J, C) device tensor -> (windows, T, J, C) evaluation windows [+ (windows, T) bool target mask] (GEN:27-48, 247-276)."""
+    dev = seq.device
+    n, J, Cc = seq.shape
+    sq = _f32c(seq, dev)
+    nc = _lib.lib().d3d_num_windows(n, T)
+    out = torch.empty((nc, T, J, Cc), dtype=torch.float32, device=dev)
+    mask = torch.empty((nc, T), dtype=torch.uint8, device=dev) if want_mask else None
+    jl = (C.c_int32 * len(joints_left))(*joints_left)
+    jr = (C.c_int32 * len(joints_right))(*joints_right)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_window_gather(_ptr(sq), n, T, J, Cc, int(flip), jl, jr, len(joints_left), _ptr(out), _ptr(mask), st))
+    return (out, mask.bool()) if want_mask else out

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import parallel
-from .engine import tta_mpjpe
+from .engine import tta_mpjpe, window_gather
 
 H36M_JOINTS_LEFT = [4, 5, 6, 11, 12, 13]     # after remove_joints (reference common/h36m_dataset.py:20-21,288)
 H36M_JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]
@@ -79,3 +79,35 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
         print('inference_speed:', frames / max(secs, 1e-9), 'frame/s')
         print('Protocol #1 Error (MPJPE):', e1, 'mm')
     return {"mpjpe_mm": e1, "frames": frames, "seconds": secs}
+
+
+@torch.no_grad()
+def evaluate_sequence(model_diffusion, poses_2d: torch.Tensor, poses_3d: torch.Tensor, *, num_frames: int, scale: float = 1.0,
+                      joints_left: Sequence[int] = H36M_JOINTS_LEFT, joints_right: Sequence[int] = H36M_JOINTS_RIGHT,
+                      kps_left: Optional[Sequence[int]] = None, kps_right: Optional[Sequence[int]] = None,
+                      test_time_augmentation: bool = True, batch_size: int = 512, device: Optional[torch.device] = None,
+                      init_noise=None, init_noise_flip=None):
+    """A whole video 2D-in -> MPJPE-out without host round trips: the window table, edge
+    padding, target mask and the flipped 2D copy (GEN:27-48, 247-276; LOAD:243-261) are built on the device, every
+    window goes through the DDIM loop (twice with TTA), and merge + masked MPJPE run in one kernel (RUN:583-606).
+    poses_2d (n, J, 2) normalised screen coordinates, poses_3d (n, J, 3) ground truth divided by `scale` upstream or
+    in metres with scale = 1."""
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    kl = list(kps_left if kps_left is not None else joints_left)
+    kr = list(kps_right if kps_right is not None else joints_right)
+    x2d, mask = window_gather(poses_2d.to(dev), num_frames)
+    gt = window_gather(poses_3d.to(dev), num_frames, want_mask=False)
+    x2d_f = window_gather(poses_2d.to(dev), num_frames, True, kl, kr, want_mask=False) if test_time_augmentation else None
+    batches = []
+    for lo in range(0, x2d.shape[0], batch_size):
+        sl = slice(lo, lo + batch_size)
+        b = {"inputs_2d": x2d[sl], "inputs_3d": gt[sl], "target_mask": mask[sl]}
+        if x2d_f is not None:
+            b["inputs_2d_flip"] = x2d_f[sl]
+        if init_noise is not None:
+            b["init_noise"] = init_noise[sl]
+        if init_noise_flip is not None:
+            b["init_noise_flip"] = init_noise_flip[sl]
+        batches.append(b)
+    return evaluate(model_diffusion, batches, scale=scale, joints_left=joints_left, joints_right=joints_right,
+                    test_time_augmentation=test_time_augmentation, device=dev, verbose=False)

@@ -128,6 +128,15 @@ int d3d_tta_mpjpe(const float* pred_dev, const float* pred_flip_dev, const float
                   float scale, const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr,
                   float* merged_dev, double* sums_dev, int32_t B, int32_t T, int32_t J, void* stream);
 
+/* Evaluation windows of one whole sequence, on the device: ChunkedGenerator(out_all=True, pad=0) (common/nosiy_generators.py:27-48
+ * window table, :247-276 slicing, edge padding, target_mask, horizontal flip).  seq (n_frames, J, C) -> out
+ * (d3d_num_windows, T, J, C); mask (nullable) (windows, T) uint8, 0 for the frames of the shifted last window that its
+ * predecessor already covers.  flip != 0 writes the flipped copy (channel 0 negated, left/right joints swapped). */
+int d3d_num_windows(int32_t n_frames, int32_t T);
+int d3d_window_gather(const float* seq_dev, int32_t n_frames, int32_t T, int32_t J, int32_t C, int32_t flip,
+                      const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr, float* out_dev,
+                      uint8_t* mask_dev, void* stream);
+
 /* ---- per-kernel-class timing (HIP events recorded on the launch stream around every kernel of d3d_denoise /
  * d3d_ddim_sample while enabled; used by bench.py for the roofline figures).  flops / bytes are the ALGORITHMIC counts
  * of the launches timed, total_ms the sum of their event-pair durations. ------------------------ */

@@ -279,3 +279,34 @@ def merge_flip_tta(pred: Tensor, pred_flip: Tensor, scale: float, target_mask: T
     J = p.shape[2]
     p = p.reshape(-1, J, 3)
     return p[target_mask.reshape(-1) == True, :, :].unsqueeze(1)  # noqa: E712
+
+
+# --------------------------------------------------------------------------- eval windows of a whole sequence (GEN:27-48, 247-271)
+
+def chunk_index(n_frames: int, T: int):
+    """Window table of ChunkedGenerator(out_all=True, pad=0) for one sequence: non-overlapping T-frame chunks, the last
+    chunk shifted back to end at the last frame; returns (start_index (nc,), target_mask (nc, T) bool).
+    GEN:31-44 builds the bounds; GEN:263-271 masks the frames of the last chunk that the previous chunk already covered.
+    A sequence shorter than T is edge-padded on the left (GEN:255-260) and fully unmasked (LOAD:270-271)."""
+    import numpy as np
+    nc = (n_frames + T - 1) // T
+    starts = np.arange(nc) * T
+    starts[-1] = n_frames - T
+    mask = np.ones((nc, T), dtype=bool)
+    n_unused = nc * T - n_frames          # == start_3d - start_target_3d of the last chunk
+    if n_frames >= T and n_unused > 0:
+        mask[-1, :n_unused] = False
+    return starts, mask
+
+
+def gather_windows(seq: Tensor, T: int, flip: bool = False, left=None, right=None):
+    """(n, J, C) -> (nc, T, J, C) windows (edge-clamped), optionally the horizontally flipped copy (GEN:273-276)."""
+    import numpy as np
+    n = seq.shape[0]
+    starts, mask = chunk_index(n, T)
+    idx = np.clip(starts[:, None] + np.arange(T)[None, :], 0, n - 1)
+    w = seq[torch.from_numpy(idx)].clone()
+    if flip:
+        w[..., 0] *= -1
+        w[:, :, list(left) + list(right)] = w[:, :, list(right) + list(left)]
+    return w, torch.from_numpy(mask)

@@ -349,9 +349,43 @@ def gen_evalmath():
          joints_left=np.asarray(jl, np.int32), joints_right=np.asarray(jr, np.int32), merged=merged.numpy(), mpjpe=np.float32(err.item()))
 
 
+def gen_chunks():
+    """Window tables straight from the reference ChunkedGenerator (out_all=True), incl. the flipped 2D copy."""
+    from common.nosiy_generators import ChunkedGenerator
+    out = {}
+    kl, kr = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    cases = [(700, 243), (243, 243), (486, 243), (487, 243), (100, 27), (81, 27), (20, 27), (1, 9)]
+    for n, T in cases:
+        rng = np.random.RandomState(n * 1000 + T)
+        p2 = rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32)
+        p3 = rng.uniform(-1, 1, (n, 17, 3)).astype(np.float32)
+        key = ("S9", "Walk", 0)
+        gen = ChunkedGenerator(1, None, {key: p3}, {key: p2}, {key: np.arange(n)}, chunk_length=T, pad=0, kps_left=kl, kps_right=kr,
+                               joints_left=kl, joints_right=kr, out_all=True)
+        wins, flips, masks, gts = [], [], [], []
+        for (seq, s3, e3, st3, et3, fl, rv) in gen.pairs:
+            _, g3, w2, m, *_ = gen.get_batch_seq2seq(tuple(seq), int(s3), int(e3), int(st3), False, False)
+            _, _, w2f, _, *_ = gen.get_batch_seq2seq(tuple(seq), int(s3), int(e3), int(st3), True, False)
+            if m is None:
+                m = np.full(T, True, dtype=bool)
+            wins.append(w2); flips.append(w2f); masks.append(m); gts.append(g3)
+        w, m = orc.gather_windows(torch.from_numpy(p2), T)
+        wf, _ = orc.gather_windows(torch.from_numpy(p2), T, True, kl, kr)
+        g, _ = orc.gather_windows(torch.from_numpy(p3), T)
+        assert np.array_equal(w.numpy(), np.stack(wins)) and np.array_equal(wf.numpy(), np.stack(flips)), (n, T)
+        assert np.array_equal(m.numpy(), np.stack(masks)) and np.array_equal(g.numpy(), np.stack(gts)), (n, T)
+        tag = f"n{n}_T{T}"
+        out[tag + "/mask"] = np.stack(masks)
+        out[tag + "/starts"] = np.asarray([int(p[1]) for p in gen.pairs], np.int32)
+        out[tag + "/win_checksum"] = np.float64(np.stack(wins).astype(np.float64).sum())
+        out[tag + "/flip_checksum"] = np.float64((np.stack(flips).astype(np.float64) * np.arange(1, 35).reshape(17, 2)).sum())
+        print(f"  chunks n={n} T={T}: {len(gen.pairs)} windows, oracle == reference")
+    save("chunks", **out)
+
+
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
-    "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath,
+    "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
 }
 
 if __name__ == "__main__":

@@ -235,3 +235,46 @@ def test_hipgraph_replay_matches_eager_launches():
     eng2.set_graph_mode(False)
     _, e_new = diff(clean_3d_pose=z(3), noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
     assert torch.equal(g_new, e_new) and not torch.equal(g_new, old)
+
+
+def test_sequence_windows_on_device_bit_exact():
+    """d3d_window_gather (index work) must be bit-exact with the oracle's window table for ragged / short / exact lengths."""
+    from diff3dhpe_amd.engine import window_gather
+    from oracle import d3d_oracle as orc
+    kl, kr = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    g = gold("chunks")
+    for n, T in [(700, 243), (243, 243), (486, 243), (487, 243), (100, 27), (81, 27), (20, 27), (1, 9)]:
+        rng = np.random.RandomState(n * 1000 + T)
+        p2 = torch.from_numpy(rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32))
+        p3 = torch.from_numpy(rng.uniform(-1, 1, (n, 17, 3)).astype(np.float32))
+        w, m = window_gather(p2.cuda(), T)
+        wf = window_gather(p2.cuda(), T, True, kl, kr, want_mask=False)
+        w3 = window_gather(p3.cuda(), T, want_mask=False)
+        ow, om = orc.gather_windows(p2, T)
+        owf, _ = orc.gather_windows(p2, T, True, kl, kr)
+        ow3, _ = orc.gather_windows(p3, T)
+        assert torch.equal(w.cpu(), ow) and torch.equal(wf.cpu(), owf) and torch.equal(w3.cpu(), ow3), (n, T)
+        assert torch.equal(m.cpu(), om) and np.array_equal(m.cpu().numpy(), g[f"n{n}_T{T}/mask"]), (n, T)
+
+
+def test_evaluate_sequence_end_to_end():
+    """A 70-frame video through windows -> DDIM (flip TTA) -> merge -> masked MPJPE, against the oracle doing the same."""
+    from diff3dhpe_amd.evaluate import evaluate_sequence, H36M_JOINTS_LEFT as JL, H36M_JOINTS_RIGHT as JR
+    from oracle import d3d_oracle as orc
+    cfg = cfg_small(27)
+    _, diff = build_product(cfg, 14, sampling=3)
+    n = 70
+    rng = np.random.RandomState(5)
+    p2 = torch.from_numpy(np.clip(rng.normal(0, 0.4, (n, 17, 2)), -1, 1).astype(np.float32))
+    p3 = torch.from_numpy(rng.uniform(-1, 1, (n, 17, 3)).astype(np.float32))
+    nz = hashed("seqnoise", (3, 27, 17, 3), 2)
+    nzf = hashed("seqnoise_f", (3, 27, 17, 3), 3)
+    res = evaluate_sequence(diff, p2, p3, num_frames=27, scale=2.0, init_noise=nz, init_noise_flip=nzf)
+    sd, tabs = torch_sd(cfg, 14), orc.diffusion_tables("cosine", 1000)
+    kw = dict(num_timesteps=1000, sampling_timesteps=3, depth=cfg.depth)
+    w, m = orc.gather_windows(p2, 27)
+    wf, _ = orc.gather_windows(p2, 27, True, JL, JR)
+    g3, _ = orc.gather_windows(p3, 27)
+    merged = orc.merge_flip_tta(orc.ddim_sample_loop(sd, tabs, w, nz, **kw), orc.ddim_sample_loop(sd, tabs, wf, nzf, **kw), 2.0, m)
+    gtm = g3.reshape(-1, 17, 3)[m.reshape(-1)].unsqueeze(1)
+    assert res["frames"] == n and abs(res["mpjpe_mm"] - orc.mpjpe(merged, gtm).item() * 1000) < 0.05

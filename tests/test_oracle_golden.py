@@ -187,3 +187,19 @@ def test_ddim_long_chain_T243_S50():
     tabs = orc.diffusion_tables("cosine", 1000)
     out = orc.ddim_sample_loop(sd, tabs, inp["x2d"], inp["noise"], num_timesteps=1000, sampling_timesteps=50, depth=8)
     assert np.abs(out.numpy() - g["y0"]).max() <= 5e-6
+
+
+def test_sequence_window_table():
+    """chunk_index / gather_windows against the reference ChunkedGenerator's tables (captured in chunks.npz)."""
+    g = gold("chunks")
+    kl, kr = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    for n, T in [(700, 243), (243, 243), (486, 243), (487, 243), (100, 27), (81, 27), (20, 27), (1, 9)]:
+        tag = f"n{n}_T{T}"
+        starts, mask = orc.chunk_index(n, T)
+        assert np.array_equal(starts, g[tag + "/starts"]) and np.array_equal(mask, g[tag + "/mask"]), tag
+        rng = np.random.RandomState(n * 1000 + T)
+        p2 = torch.from_numpy(rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32))
+        w, _ = orc.gather_windows(p2, T)
+        wf, _ = orc.gather_windows(p2, T, True, kl, kr)
+        assert float(w.double().sum()) == float(g[tag + "/win_checksum"])
+        assert float((wf.double() * torch.arange(1, 35, dtype=torch.float64).reshape(17, 2)).sum()) == float(g[tag + "/flip_checksum"])
