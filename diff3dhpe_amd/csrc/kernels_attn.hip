@@ -61,21 +61,37 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
   const bool valid = (slot_raw < UPW) && (unit < units);
   const int D3 = 3 * D;
 
-  auto stage = [&](int which) {  // which: 1 = K, 2 = V
-    for (int idx = lane; idx < UPW * ROWS4; idx += 64) {
+  // Staging is split into "issue all global loads" / "write LDS" so the NIT loads of a unit group are in flight together
+  // (a load->store loop serialises NIT HBM round trips per phase, which dominated this kernel), and V is fetched into
+  // registers while the scores are being computed.
+  constexpr int NIT = (UPW * ROWS4 + 63) / 64;
+  auto gload = [&](int which, float4 (&tmp)[NIT]) {  // which: 1 = K, 2 = V
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = lane + 64 * it;
       const int s = idx / ROWS4, rem = idx % ROWS4;
       const int j = rem / (SP_DH / 4), c4 = rem % (SP_DH / 4);
       const int u = base + s;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (u < units) {
-        const int g = u / H, h = u % H;
-        v = *reinterpret_cast<const float4*>(qkv + ((size_t)g * NJ + j) * D3 + which * D + h * SP_DH + c4 * 4);
+      tmp[it] = make_float4(0, 0, 0, 0);
+      if (idx < UPW * ROWS4 && u < units) {
+        const int gg = u / H, hh = u % H;
+        tmp[it] = *reinterpret_cast<const float4*>(qkv + ((size_t)gg * NJ + j) * D3 + which * D + hh * SP_DH + c4 * 4);
       }
-      *reinterpret_cast<float4*>(&kv[s * UNIT_LD + j * SP_DH + c4 * 4]) = v;
+    }
+  };
+  auto lstore = [&](const float4 (&tmp)[NIT]) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = lane + 64 * it;
+      if (idx < UPW * ROWS4) {
+        const int s = idx / ROWS4, rem = idx % ROWS4;
+        *reinterpret_cast<float4*>(&kv[s * UNIT_LD + rem * 4]) = tmp[it];
+      }
     }
   };
 
-  stage(1);
+  float4 stg[NIT];
+  gload(1, stg);
   float q[SP_DH];
   const int g = valid ? unit / H : 0, h = valid ? unit % H : 0;
   {
@@ -86,7 +102,9 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
       q[c] = v.x * 0.125f; q[c + 1] = v.y * 0.125f; q[c + 2] = v.z * 0.125f; q[c + 3] = v.w * 0.125f;  // exact (2^-3)
     }
   }
+  lstore(stg);
   __syncthreads();
+  gload(2, stg);   // V in flight while the scores are computed from K
 
   float p[NJ];
   const float* ku = kv + slot * UNIT_LD;
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
   for (int j = 0; j < NJ; ++j) { p[j] = p[j] / l; if (j == i) p[j] -= 1.0f; }  // attn - I (S2S:82-83)
 
   __syncthreads();
-  stage(2);
+  lstore(stg);
   __syncthreads();
 
   float o[SP_DH];

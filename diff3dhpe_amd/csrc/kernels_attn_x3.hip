@@ -105,24 +105,29 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
     }
   }
 
-  // ---- exact softmax numerator over the keys of this query column (fp32)
+  // ---- exact (max-subtracted) softmax numerator over the keys of this query column, fp32.  acc = 64 s; the scale and
+  // log2(e) are folded into one fma feeding v_exp_f32: e = 2^((acc - max) * log2(e)/64).  Only the last key tile can hold
+  // padding keys (>= T), so only it pays for the mask.
   float m = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      const float sv = (key < T) ? sacc[kt][q] * 0.015625f : -INFINITY;   // planes are 8k and 8q' (q' = q/8): acc = 64 s
-      sacc[kt][q] = sv;
-      m = fmaxf(m, sv);
+      if (kt == NKT - 1) {
+        const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (key >= T) sacc[kt][q] = -INFINITY;
+      }
+      m = fmaxf(m, sacc[kt][q]);
     }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
+  constexpr float C_EXP = 1.4426950408889634f / 64.0f;
+  const float mb = m * C_EXP;
   float l = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float e = expf(sacc[kt][q] - m);
+      const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][q], C_EXP, -mb));
       sacc[kt][q] = e;
       l += e;
     }
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, el, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, eh, oacc[dt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the V^T reads / conversions of later k-steps from being hoisted (VGPR pressure)
     }
   }
 

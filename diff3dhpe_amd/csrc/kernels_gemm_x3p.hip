@@ -181,7 +181,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
   const int arow0 = wm * (BM / WM) + r, brow0 = wn * (BN / WN) + r;
   const int nk = K / BK;
   constexpr int NG = KS * TMI;                                 // MFMA groups per k-tile: (k-step, m-tile)
-  constexpr int PPG = (MAX_IT + NG - 1) / NG;                  // DMA pieces issued per group
+  constexpr int DMA_NG = (ABL == 4) ? (NG / 2) : (ABL == 5) ? (NG / 4) : NG;   // groups the next k-tile's DMA is spread over
+  constexpr int PPG = (MAX_IT + DMA_NG - 1) / DMA_NG;          // DMA pieces issued per group
   D3D_STAGE_ALL(0, 0);
   // One k-tile: software pipeline over the NG groups -- the fragments of group g+1 are read from LDS, and one slice of
   // the NEXT k-tile's DMA is issued, BEFORE the 3*TNJ MFMAs of group g, so LDS latency and DMA issue hide under MFMAs.
@@ -336,6 +337,8 @@ hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, con
     case 3: return launch_tile<256, 256, 2, 4>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 7: return launch_tile<256, 128, 2, 2, 16>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 8: return launch_tile<256, 256, 2, 4, 16>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
+    case 10: return launch_abl<4>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);  // DMA issued in the first half of the groups
+    case 11: return launch_abl<5>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);  // ... first quarter
     case 4: return launch_abl<1>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);   // timing experiments (wrong results)
     case 5: return launch_abl<2>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);
     case 6: return launch_abl<3>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);
