@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 # dense MFMA peaks (MI355X_MICROARCH.md): fp32 157.3, fp16/bf16 2500 TFLOP/s.  F16X3 issues 3 fp16 MFMAs per
 # algorithmic product, so its ceiling in ALGORITHMIC (fp32-equivalent) flops is 2500/3.
 PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0 / 3.0, "bf16": 2500.0}
-DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3(f32-equivalent)", "bf16": "bf16"}
+DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3", "bf16": "bf16"}   # f16x3: fp16 hi/lo operand pairs, 3 MFMAs per product, fp32 accumulate
 
 
 def flops_per_seq_step(T, D=512, J=17):
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--sampling", type=int, default=9)
     ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"],
                     help="f16x3: fp32-accurate GEMMs from 3 fp16 MFMAs (default; passes the same 1e-4 parity gate); fp32: fp32 MFMA")
+    ap.add_argument("--seq2frame", action="store_true", help="BASELINE configs[4]: ...S2F... model, (B,1,J,3) targets")
+    ap.add_argument("--no-time-emb", action="store_true", help="with_time_emb=False (3DHP command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -116,9 +118,10 @@ def main():
 
     T, S, Bl = a.frames, a.sampling, a.batch
     Bg = Bl * world
-    cfg = DenoiserConfig(num_frame=T, embed_dim=512, depth=8)
-    net = d3d.HPE_model(d3d.S2S_NAME)(num_frame=T, num_joints=17, in_chans=2, embed_dim=512, depth=8, num_heads=8,
-                                      mlp_ratio=2., qkv_bias=True, qk_scale=None, drop_path_rate=0.1, with_time_emb=True)
+    cfg = DenoiserConfig(num_frame=T, embed_dim=512, depth=8, seq2frame=a.seq2frame, with_time_emb=not a.no_time_emb)
+    net = d3d.HPE_model(d3d.S2F_NAME if a.seq2frame else d3d.S2S_NAME)(
+        num_frame=T, num_joints=17, in_chans=2, embed_dim=512, depth=8, num_heads=8, mlp_ratio=2., qkv_bias=True,
+        qk_scale=None, drop_path_rate=0.1, with_time_emb=not a.no_time_emb)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 0).items()})
     net.precision = a.precision
     diff = d3d.GaussianDiffusion(model=net, timesteps=1000, sampling_timesteps=S, loss_type="l2", clip_denoised=True,
@@ -130,6 +133,8 @@ def main():
     x2d = torch.from_numpy(inp["x2d"][lo:hi]).to(dev)
     noise = torch.from_numpy(inp["noise"][lo:hi]).to(dev)
     gt = torch.from_numpy(inp["gt3d"]).to(dev)
+    if a.seq2frame:   # one target frame per window (DIFF-S2F): noise / ground truth of the centre frame
+        noise, gt = noise[:, :1].contiguous(), gt[:, T // 2:T // 2 + 1].contiguous()
     eng = diff._engine(dev)
 
     def step():
@@ -192,8 +197,10 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[a.precision],
             "data": "synthetic",
-            "config": {"workload": f"H36M-CPN-shape 2D windows T={T} J=17, MixSTE D=512 depth=8 random-init, {S} DDIM steps, "
-                                   f"B={Bl}/GPU (BASELINE configs[2] per-GPU shard), eta=0, clip_denoised",
+            "config": {"workload": f"H36M-CPN-shape 2D windows T={T} J=17, MixSTE{'-S2F' if a.seq2frame else ''} D=512 depth=8 "
+                                   f"random-init, {S} DDIM steps, B={Bl}/GPU"
+                                   + (" (BASELINE configs[2] per-GPU shard)" if (T, S, Bl) == (243, 9, 64) and not a.seq2frame else "")
+                                   + ", eta=0, clip_denoised",
                        "global_batch": Bg, "frames": T, "sampling_timesteps": S, "parallelism": f"dp{world}",
                        "precision": a.precision},
             "whole_step_tflops": round(whole, 2),
