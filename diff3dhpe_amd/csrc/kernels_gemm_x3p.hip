@@ -297,6 +297,216 @@ static hipError_t launch_tile(const _Float16* Ah, const _Float16* Al, const _Flo
   return hipGetLastError();
 }
 
+// ---- 16x16x32 form ("x3q") -------------------------------------------------------------------------------------------
+// Same algorithm and staging as k_linear_x3p<256,256,2,4,...,32>, but the products are issued as
+// v_mfma_f32_16x16x32_f16: one MFMA spans the whole 32-deep k-tile.  Measured on MI355X with random fp16 operands
+// (experiments/mfma_ceiling.hip) the chip sustains 1.97 PFLOP/s on this shape against 1.54 PFLOP/s on 32x32x16 (it holds
+// a higher clock), so the MFMA-bound part of the GEMM gets ~1.28x faster at identical cycle counts.
+// Wave tile 128(m) x 64(n) = 8 x 4 tiles of 16x16 (128 accumulator VGPRs); weight fragment first, so a tile holds C^T:
+// lane -> token m = lane&15, registers -> n = 4*(lane>>4) + reg.  Fragment read: lane (r16 = lane&15, q = lane>>4) takes
+// 16-byte chunk q of row r16; the chunk XOR [0,3,2,1][(row>>2)&3] makes every ds_read_b128 16-lane group of this map
+// (and of the 32x32x16 map) hit 16 distinct 4-bank slots.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int swzq(int row, int c) { return row * 64 + ((c ^ ((0 - (row >> 2)) & 3)) << 4); }
+
+template <int EPI, int OUTSPLIT, bool CHECK>
+__device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[8][4], float* patch, const float* __restrict__ bias, const float* Rt,
+                                             float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0, int lane, int M, int N,
+                                             int qcols) {
+  // patch: wave-private 16 rows x 64 floats, 16-byte chunks XOR-swizzled by (row & 7)
+  const int m16 = lane & 15, q4 = lane >> 4;
+  const int rrow = lane >> 4, rc4 = lane & 15;         // read side: 16 lanes per row, 4 rows per pass
+  const int n = nt0 + 4 * rc4;
+  const bool ncol_ok = !CHECK || n < N;
+  float4 b4 = make_float4(0, 0, 0, 0);
+  if (bias && ncol_ok) b4 = *reinterpret_cast<const float4*>(bias + n);
+  const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(patch + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = rrow + 4 * p;
+      const float4 a4 = *reinterpret_cast<const float4*>(patch + row * 64 + ((rc4 ^ (row & 7)) << 2));
+      const int m = mt0 + 16 * i + row;
+      if (CHECK && (m >= M || !ncol_ok)) continue;
+      const int off = (16 * i + row) * N + 4 * rc4;
+      float v[4] = {a4.x * P_OUT_SCALE + b4.x, a4.y * P_OUT_SCALE + b4.y, a4.z * P_OUT_SCALE + b4.z, a4.w * P_OUT_SCALE + b4.w};
+      if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_p(v[e]);
+      }
+      if (EPI == EPI_RESIDUAL) {
+        const float4 r4 = *reinterpret_cast<const float4*>(Rt + off);
+        v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
+      }
+      if (OUTSPLIT) {
+        h4 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sc = __builtin_amdgcn_fmed3f(v[e] * osc, -65504.0f, 65504.0f);
+          hh[e] = (_Float16)sc;
+          ll[e] = (_Float16)(sc - (float)hh[e]);
+        }
+        *reinterpret_cast<h4*>(Cht + off) = hh;
+        *reinterpret_cast<h4*>(Clt + off) = ll;
+      } else {
+        *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int EPI, int OUTSPLIT>
+__global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al,
+                                                    const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
+                                                    const float* __restrict__ bias, const float* R, float* C, _Float16* Ch,
+                                                    _Float16* Cl, int M, int N, int K, int mtiles, int ntiles, int qcols) {
+  constexpr int BM = 256, BN = 256, WN = 4, BK = 32;
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
+  constexpr int N_IT = 8;                 // 1-KiB DMA pieces per wave per k-tile (16 per plane, 2 waves per plane)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mt = (slot / ntiles) * 8 + xcd;
+  const int nt = slot % ntiles;
+  if (mt >= mtiles) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  const int plane = wave & 3, part = wave >> 2;
+  const bool isA = plane < 2;
+  const int g0 = part * N_IT;
+  const int lrow = lane >> 2, lslot = lane & 3;
+  const _Float16* src;
+  {
+    const _Float16* pb = (plane == 0) ? Ah : (plane == 1) ? Al : (plane == 2) ? Wh : Wl;
+    const int row0 = (isA ? m0 : n0) + g0 * 16 + lrow;
+    src = pb + (size_t)row0 * K + ((lslot ^ ((0 - (lrow >> 2)) & 3)) << 3);
+  }
+  const size_t it_stride = (size_t)16 * K;
+  const int dst0 = (isA ? plane * A_PLANE : 2 * A_PLANE + (plane - 2) * B_PLANE) + g0 * 1024 + lane * 16;
+
+#define D3D_QSTAGE_ONE(ST, K0, IT)                                                                                      \
+  __builtin_amdgcn_global_load_lds(src + (K0) + (IT) * it_stride,                                                        \
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)(lds + (ST) * STAGE + dst0 + (IT) * 1024), \
+                                   16, 0, 0)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
+
+  const int arow0 = wm * 128 + r16, brow0 = wn * 64 + r16;
+  const int nk = K / BK;
+#pragma unroll
+  for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(0, 0, it);
+
+  // one k-tile = 8 groups (one 16-row m-tile each): the A fragments of group g+1 are read, and one DMA piece of the next
+  // k-tile is issued, before the 12 MFMAs of group g; the 8 W fragments are read once at the top of the k-tile.
+#define D3D_QKTILE(KT, PREFETCH)                                                                                         \
+  do {                                                                                                                   \
+    __syncthreads();                                                                                                     \
+    const int nst = ((KT) + 1) & 1, nk0 = ((KT) + 1) * BK;                                                               \
+    const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                  \
+    const unsigned char* sAh = sb;                                                                                       \
+    const unsigned char* sAl = sb + A_PLANE;                                                                             \
+    const unsigned char* sBh = sb + 2 * A_PLANE;                                                                         \
+    const unsigned char* sBl = sb + 2 * A_PLANE + B_PLANE;                                                               \
+    h8 bh[4], bl[4], ah[2], al[2];                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+      const int ob = swzq(brow0 + 16 * j, q);                                                                            \
+      bh[j] = *reinterpret_cast<const h8*>(sBh + ob);                                                                    \
+      bl[j] = *reinterpret_cast<const h8*>(sBl + ob);                                                                    \
+    }                                                                                                                    \
+    {                                                                                                                    \
+      const int oa = swzq(arow0, q);                                                                                     \
+      ah[0] = *reinterpret_cast<const h8*>(sAh + oa);                                                                    \
+      al[0] = *reinterpret_cast<const h8*>(sAl + oa);                                                                    \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                      \
+      if (g + 1 < 8) {                                                                                                   \
+        const int oa = swzq(arow0 + 16 * (g + 1), q);                                                                    \
+        ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sAh + oa);                                                        \
+        al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sAl + oa);                                                        \
+      }                                                                                                                  \
+      if (PREFETCH) D3D_QSTAGE_ONE(nst, nk0, g);                                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                        \
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
+      }                                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }                                                                                                                    \
+  } while (0)
+
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true);
+  D3D_QKTILE(kt, false);
+#undef D3D_QKTILE
+#undef D3D_QSTAGE_ONE
+
+  const int mt0 = m0 + wm * 128, nt0 = n0 + wn * 64;          // wave-uniform
+  const size_t tbase = (size_t)mt0 * N + nt0;
+  const float* Rt = R ? R + tbase : nullptr;
+  float* Ct = C ? C + tbase : nullptr;
+  _Float16* Cht = Ch ? Ch + tbase : nullptr;
+  _Float16* Clt = Cl ? Cl + tbase : nullptr;
+  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+  float* patch = reinterpret_cast<float*>(lds) + wave * (16 * 64);
+  if (m0 + BM <= M && n0 + BN <= N)
+    x3q_epilogue<EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
+  else
+    x3q_epilogue<EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
+}
+
+static hipError_t launch_x3q(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl, const float* bias,
+                             const float* R, float* C, _Float16* Ch, _Float16* Cl, int M, int N, int K, int epi, int outsplit,
+                             int qcols, hipStream_t s) {
+  const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
+  const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
+  const size_t lds_bytes = 2 * (size_t)(4 * 256 * 64);
+#define D3D_X3Q_LAUNCH(EPI_, OS_)                                                                                         \
+  do {                                                                                                                    \
+    auto kfn = k_linear_x3q<EPI_, OS_>;                                                                                   \
+    static bool attr_done = false;                                                                                        \
+    if (!attr_done) {                                                                                                     \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds_bytes);                                                                \
+      if (ae != hipSuccess) return ae;                                                                                    \
+      attr_done = true;                                                                                                   \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ah, Al, Wh, Wl, bias, R, C, Ch, Cl, M, N, K, mtiles,     \
+                       ntiles, qcols);                                                                                    \
+  } while (0)
+  if (outsplit) {
+    if (epi == EPI_GELU) D3D_X3Q_LAUNCH(EPI_GELU, 1);
+    else if (epi == EPI_NONE) D3D_X3Q_LAUNCH(EPI_NONE, 1);
+    else return hipErrorInvalidValue;
+  } else {
+    if (epi == EPI_NONE) D3D_X3Q_LAUNCH(EPI_NONE, 0);
+    else if (epi == EPI_GELU) D3D_X3Q_LAUNCH(EPI_GELU, 0);
+    else if (epi == EPI_RESIDUAL) D3D_X3Q_LAUNCH(EPI_RESIDUAL, 0);
+    else return hipErrorInvalidValue;
+  }
+#undef D3D_X3Q_LAUNCH
+  return hipGetLastError();
+}
+
 template <int ABL>
 static hipError_t launch_abl(const _Float16* Ah, const _Float16* Al, const _Float16* Wh, const _Float16* Wl, const float* bias,
                              float* C, int M, int N, int K, int ablate, hipStream_t s) {
@@ -327,7 +537,7 @@ hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, con
     // Measured on MI355X (experiments/gemm_bench.py): at M = 264k the 256x256 tile wins for every N in {512,1024,1536}.
     // Small batches need enough workgroups to fill 256 CUs for several rounds, so fall back to smaller tiles there.
     auto wgs = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (N % 256 == 0 && wgs(256, 256) >= 1024) variant = 3;
+    if (N % 256 == 0 && wgs(256, 256) >= 1024) variant = 13;   // 256x256 tile on v_mfma_f32_16x16x32_f16 (3-8 % over the 32x32x16 form)
     else if (N % 128 == 0 && wgs(256, 128) >= 1024) variant = 2;
     else variant = 1;
   }
@@ -337,6 +547,7 @@ hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, con
     case 3: return launch_tile<256, 256, 2, 4>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 7: return launch_tile<256, 128, 2, 2, 16>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 8: return launch_tile<256, 256, 2, 4, 16>(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
+    case 13: return launch_x3q(ah, al, wh, wl, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);   // 16x16x32 MFMA form
     case 10: return launch_abl<4>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);  // DMA issued in the first half of the groups
     case 11: return launch_abl<5>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);  // ... first quarter
     case 4: return launch_abl<1>(ah, al, wh, wl, bias, C, M, N, K, ablate, s);   // timing experiments (wrong results)
