@@ -314,7 +314,8 @@ template <int EPI, int OUTSPLIT, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[8][4], float* patch, const float* __restrict__ bias, const float* Rt,
                                              float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0, int lane, int M, int N,
                                              int qcols) {
-  // patch: wave-private 16 rows x 64 floats, 16-byte chunks XOR-swizzled by (row & 7)
+  // patch: two wave-private 16 rows x 64 floats (alternating, so the LDS round trip of one m-tile overlaps the stores
+  // of the previous one), 16-byte chunks XOR-swizzled by (row & 7)
   const int m16 = lane & 15, q4 = lane >> 4;
   const int rrow = lane >> 4, rc4 = lane & 15;         // read side: 16 lanes per row, 4 rows per pass
   const int n = nt0 + 4 * rc4;
@@ -326,12 +327,12 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[8][4], float* patch, c
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<float4*>(patch + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
+      *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = rrow + 4 * p;
-      const float4 a4 = *reinterpret_cast<const float4*>(patch + row * 64 + ((rc4 ^ (row & 7)) << 2));
+      const float4 a4 = *reinterpret_cast<const float4*>(patch + (i & 1) * 1024 + row * 64 + ((rc4 ^ (row & 7)) << 2));
       const int m = mt0 + 16 * i + row;
       if (CHECK && (m >= M || !ncol_ok)) continue;
       const int off = (16 * i + row) * N + 4 * rc4;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[8][4], float* patch, c
         *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two m-tiles (two patches) in flight at a time
   }
 }
 
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__
   _Float16* Cht = Ch ? Ch + tbase : nullptr;
   _Float16* Clt = Cl ? Cl + tbase : nullptr;
   __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
-  float* patch = reinterpret_cast<float*>(lds) + wave * (16 * 64);
+  float* patch = reinterpret_cast<float*>(lds) + wave * (2 * 16 * 64);
   if (m0 + BM <= M && n0 + BN <= N)
     x3q_epilogue<EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
   else
