@@ -278,3 +278,41 @@ def test_evaluate_sequence_end_to_end():
     merged = orc.merge_flip_tta(orc.ddim_sample_loop(sd, tabs, w, nz, **kw), orc.ddim_sample_loop(sd, tabs, wf, nzf, **kw), 2.0, m)
     gtm = g3.reshape(-1, 17, 3)[m.reshape(-1)].unsqueeze(1)
     assert res["frames"] == n and abs(res["mpjpe_mm"] - orc.mpjpe(merged, gtm).item() * 1000) < 0.05
+
+
+def test_c_abi_error_behaviour_on_device():
+    """Error codes of the compute entry points (no exception crosses the ABI; nothing silently falls back)."""
+    import ctypes as C
+    from diff3dhpe_amd import _lib
+    from diff3dhpe_amd.engine import Engine
+    L = _lib.lib()
+    cfg = cfg_small(9)
+    eng = Engine(cfg, precision="f16x3")
+    x2d = torch.zeros(2, 9, 17, 2, device="cuda")
+    y = torch.zeros(2, 9, 17, 3, device="cuda")
+    out = torch.empty_like(y)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    # weights not committed yet
+    assert L.d3d_ddim_sample(eng._h, p(x2d), p(y), None, p(out), None, None, 2, p(ws), ws.numel(), None) == -2
+    eng.load_weights(torch_sd(cfg, 1))
+    # schedule not set
+    need = L.d3d_workspace_bytes(eng._h, 2)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    assert L.d3d_ddim_sample(eng._h, p(x2d), p(y), None, p(out), None, None, 2, p(ws), ws.numel(), None) == -2
+    assert b"schedule" in L.d3d_last_error()
+    tabs = build_product(cfg, 1, sampling=3)[1]
+    eng.set_schedule(tabs.alphas_cumprod, tabs.sqrt_one_minus_alphas_cumprod, 3, 0.5, True)
+    # eta != 0 without step noise, too-small workspace, null tensors, bad batch
+    assert L.d3d_ddim_sample(eng._h, p(x2d), p(y), None, p(out), None, None, 2, p(ws), ws.numel(), None) == -1
+    assert L.d3d_ddim_sample(eng._h, p(x2d), p(y), p(y), p(out), None, None, 2, p(ws), need // 2, None) == -4
+    assert L.d3d_ddim_sample(eng._h, None, p(y), p(y), p(out), None, None, 2, p(ws), ws.numel(), None) == -1
+    assert L.d3d_ddim_sample(eng._h, p(x2d), p(y), p(y), p(out), None, None, 0, p(ws), ws.numel(), None) == -1
+    assert L.d3d_denoise(eng._h, p(x2d), p(y), 5, None, 0, p(out), 2, p(ws), ws.numel(), None) == -1      # y_frames must be 1 or T
+    assert L.d3d_denoise(eng._h, p(x2d), p(y), 9, None, 0, p(out), 2, p(ws), ws.numel(), None) == -1      # times required
+    with pytest.raises(_lib.D3DError):
+        Engine(cfg, precision="f16x3").ddim_sample(x2d, y)       # python wrapper: set_schedule() first
+    # a healthy call still works afterwards
+    eng.set_schedule(tabs.alphas_cumprod, tabs.sqrt_one_minus_alphas_cumprod, 3, 0.0, True)
+    res = eng.ddim_sample(x2d, y)
+    assert torch.isfinite(res).all()
