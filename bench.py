@@ -108,10 +108,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # D3D_BENCH_ONE_DEVICE=1 + D3D_DIST_BACKEND=gloo: functional test of the N>1 code path with all ranks on cuda:0
+    backend = os.environ.get("D3D_DIST_BACKEND", "nccl")
+    if os.environ.get("D3D_BENCH_ONE_DEVICE"):
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -160,7 +167,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
     prof = eng.profile_read()

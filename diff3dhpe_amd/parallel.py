@@ -30,6 +30,9 @@ def all_gather_pred(pred_local: torch.Tensor, B_total: int) -> torch.Tensor:
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return pred_local
     world, rank = dist.get_world_size(), dist.get_rank()
+    if pred_local.is_cuda and dist.get_backend() == "gloo":
+        # functional-test mode only (several ranks sharing one GPU cannot form an RCCL communicator): stage through the host
+        return all_gather_pred(pred_local.cpu(), B_total).to(pred_local.device)
     sizes = [shard_bounds(B_total, r, world)[1] - shard_bounds(B_total, r, world)[0] for r in range(world)]
     tail = tuple(pred_local.shape[1:])
     if len(set(sizes)) == 1:
@@ -48,6 +51,8 @@ def reduce_sums(sum_err: float, count: int, device) -> Tuple[float, int]:
     """Sum (error, joint count) pairs over ranks -- the frame-weighted running mean of RUN:602-606."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return sum_err, count
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([sum_err, float(count)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t[0]), int(round(float(t[1])))

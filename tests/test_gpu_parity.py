@@ -316,3 +316,27 @@ def test_c_abi_error_behaviour_on_device():
     eng.set_schedule(tabs.alphas_cumprod, tabs.sqrt_one_minus_alphas_cumprod, 3, 0.0, True)
     res = eng.ddim_sample(x2d, y)
     assert torch.isfinite(res).all()
+
+
+def test_bench_two_ranks_on_one_device():
+    """The N>1 code path of bench.py (sharding, all-gather of predictions, max-over-ranks timing, rank-0 JSON) run as two
+    torch.distributed ranks that share cuda:0 through gloo (RCCL cannot form a communicator on one device).  The gathered
+    MPJPE must equal the 1-rank value for the same global batch (per-sample noise is a slice of the global tensor)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo")
+    common = ["--steps", "1", "--warmup", "0", "--frames", "27", "--sampling", "3", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "3"] + common,
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "6"] + common,
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and line2["config"]["global_batch"] == 6 and line1["config"]["global_batch"] == 6
+    assert line2["mpjpe_vs_synthetic_gt"] == line1["mpjpe_vs_synthetic_gt"]
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in line2
