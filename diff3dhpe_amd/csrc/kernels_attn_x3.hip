@@ -9,8 +9,9 @@
 //
 // Inputs are the hi/lo fp16 planes the qkv GEMM epilogue writes for temporal blocks (q third pre-multiplied by
 // dh^-0.5 = 2^-3, exact); the output goes out as hi/lo planes for the proj GEMM.  One workgroup per (batch, joint,
-// head); K (row-major, 16-byte chunks XOR-swizzled by (row>>1)&7) and V^T (d-major, rows padded by 8 B) live in LDS
-// for the whole workgroup; each wave owns 32 queries.  12 + 12 MFMAs of 32 cycles replace 32 + 32 fp32 MFMAs of 64
+// head); K and V (both row-major fp16 hi/lo planes, 16-byte chunks XOR-swizzled so that the K fragment reads
+// (ds_read_b128) and the V fragment reads (ds_read_b64_tr_b16, the hardware transpose read: 4 keys of one d per lane)
+// are bank-conflict free) live in LDS for the whole workgroup; each wave owns 32 queries.  12 + 12 MFMAs of 32 cycles replace 32 + 32 fp32 MFMAs of 64
 // cycles per 32x32 score tile: 5.3x less matrix-pipe time than k_attn_temporal_f32.
 #include "d3d_kernels.h"
 
@@ -25,6 +26,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int XDH = 64;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// V rows: the four key rows k0..k0+3 of one transpose read must land in four different 64-byte bank groups
+__device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+typedef short s4v __attribute__((ext_vector_type(4)));
 
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
@@ -32,11 +36,10 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
                                                                int T, int J, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int TP = 32 * NKT;
-  constexpr int VT_LD = TP + 4;                       // halfs per V^T row (+8 B: 32 d-rows spread over all banks)
   unsigned char* const sKh = lds;                     // [TP][128 B]
   unsigned char* const sKl = lds + TP * 128;
-  _Float16* const sVh = reinterpret_cast<_Float16*>(lds + 2 * TP * 128);   // [64][VT_LD]
-  _Float16* const sVl = sVh + XDH * VT_LD;
+  unsigned char* const sVh = lds + 2 * TP * 128;
+  unsigned char* const sVl = lds + 3 * TP * 128;
 
   const int unit = blockIdx.x;                        // (b*J + j)*H + hd
   const int hd = unit % H;
@@ -47,26 +50,32 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
   const int r = lane & 31, h = lane >> 5;
   const size_t tok0 = (size_t)b * T * J + j;          // token(t) = tok0 + t*J
 
-  // ---- stage K (swizzled rows) and V^T (transposed) of this (batch, joint, head); pad rows are zero
-  for (int idx = tid; idx < TP * 8; idx += 64 * NKT) {
-    const int row = idx >> 3, c8 = idx & 7;
-    uint4 kh = make_uint4(0, 0, 0, 0), kl = kh, vh = kh, vl = kh;
-    if (row < T) {
-      const size_t o = (tok0 + (size_t)row * J) * D3 + hd * XDH + c8 * 8;
-      kh = *reinterpret_cast<const uint4*>(Ph + o + D);
-      kl = *reinterpret_cast<const uint4*>(Pl + o + D);
-      vh = *reinterpret_cast<const uint4*>(Ph + o + 2 * D);
-      vl = *reinterpret_cast<const uint4*>(Pl + o + 2 * D);
-    }
-    const int ko = kswz(row, c8);
-    *reinterpret_cast<uint4*>(sKh + ko) = kh;
-    *reinterpret_cast<uint4*>(sKl + ko) = kl;
-    const _Float16* vhp = reinterpret_cast<const _Float16*>(&vh);
-    const _Float16* vlp = reinterpret_cast<const _Float16*>(&vl);
+  // ---- stage K and V rows of this (batch, joint, head) (pad rows zero); all global loads are issued before the LDS writes
+  {
+    constexpr int NIT = 4;                            // TP*8 chunk slots / (64*NKT threads)
+    uint4 kh[NIT], kl[NIT], vh[NIT], vl[NIT];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      sVh[(c8 * 8 + e) * VT_LD + row] = vhp[e];
-      sVl[(c8 * 8 + e) * VT_LD + row] = vlp[e];
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 64 * NKT;
+      const int row = idx >> 3, c8 = idx & 7;
+      kh[it] = make_uint4(0, 0, 0, 0); kl[it] = kh[it]; vh[it] = kh[it]; vl[it] = kh[it];
+      if (row < T) {
+        const size_t o = (tok0 + (size_t)row * J) * D3 + hd * XDH + c8 * 8;
+        kh[it] = *reinterpret_cast<const uint4*>(Ph + o + D);
+        kl[it] = *reinterpret_cast<const uint4*>(Pl + o + D);
+        vh[it] = *reinterpret_cast<const uint4*>(Ph + o + 2 * D);
+        vl[it] = *reinterpret_cast<const uint4*>(Pl + o + 2 * D);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 64 * NKT;
+      const int row = idx >> 3, c8 = idx & 7;
+      const int ko = kswz(row, c8), vo = vswz(row, c8);
+      *reinterpret_cast<uint4*>(sKh + ko) = kh[it];
+      *reinterpret_cast<uint4*>(sKl + ko) = kl[it];
+      *reinterpret_cast<uint4*>(sVh + vo) = vh[it];
+      *reinterpret_cast<uint4*>(sVl + vo) = vl[it];
     }
   }
 
@@ -151,15 +160,25 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
         el[jj] = (_Float16)(ev - (float)hh);
       }
       const int k0 = kt * 32 + 16 * s + 4 * h;
+      // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of (row k0+q, columns d0+4p..+3) and
+      // lane i receives column d0+i of the four rows, i.e. V[k0..k0+3][d] for this lane's d -- the MFMA A fragment.
+      const int gi = lane & 15, tq_ = gi >> 2, tp_ = gi & 3;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const _Float16* vh0 = sVh + (dt * 32 + r) * VT_LD + k0;
-        const _Float16* vl0 = sVl + (dt * 32 + r) * VT_LD + k0;
-        const h4 a0 = *reinterpret_cast<const h4*>(vh0), a1 = *reinterpret_cast<const h4*>(vh0 + 8);
-        const h4 c0 = *reinterpret_cast<const h4*>(vl0), c1 = *reinterpret_cast<const h4*>(vl0 + 8);
+        const int d0 = dt * 32 + 16 * ((lane >> 4) & 1);
+        const int ch = (d0 >> 3) + (tp_ >> 1), sub = (tp_ & 1) * 8;
+        const int o0 = vswz(k0 + tq_, ch) + sub, o1 = vswz(k0 + 8 + tq_, ch) + sub;
+        const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVh + o0));
+        const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVh + o1));
+        const s4v c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVl + o0));
+        const s4v c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVl + o1));
         h8 vh, vl;
+        {
+          const h4 a0h = __builtin_bit_cast(h4, a0), a1h = __builtin_bit_cast(h4, a1);
+          const h4 c0h = __builtin_bit_cast(h4, c0), c1h = __builtin_bit_cast(h4, c1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; vl[e] = c0[e]; vl[4 + e] = c1[e]; }
+          for (int e = 0; e < 4; ++e) { vh[e] = a0h[e]; vh[4 + e] = a1h[e]; vl[e] = c0h[e]; vl[4 + e] = c1h[e]; }
+        }
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, eh, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, el, oacc[dt], 0, 0, 0);
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, eh, oacc[dt], 0, 0, 0);
@@ -201,7 +220,7 @@ bool attn_temporal_x3_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H >
 template <int NKT>
 static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16* oh, _Float16* ol, int B, int T, int J, int D,
                                 int H, hipStream_t s) {
-  const size_t lds_bytes = (size_t)2 * 32 * NKT * 128 + (size_t)2 * XDH * (32 * NKT + 4) * 2;
+  const size_t lds_bytes = (size_t)4 * 32 * NKT * 128;   // K_hi, K_lo, V_hi, V_lo planes of TP rows x 128 B
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3<NKT>),
