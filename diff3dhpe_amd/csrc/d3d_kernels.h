@@ -9,25 +9,34 @@ namespace d3d {
 
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 
+// ---- F16X3 operand ("pair") layout ---------------------------------------------------------------------------------
+// A [rows, K] matrix that feeds an F16X3 GEMM lives in HBM as rows of 2K fp16 (K % 32 == 0): for every 32-deep k-tile t
+// the 32 hi values sit at [64 t, 64 t + 32) and the 32 lo values at [64 t + 32, 64 t + 64) -- one 128-byte cache line
+// per row per k-tile, which is exactly what one GEMM k-tile stages (kernels_gemm_x3p.hip).  Element (r, c):
+//   hi at r * 2K + pair_col(c),   lo at r * 2K + pair_col(c) + PAIR_LO.
+constexpr int PAIR_LO = 32;
+__host__ __device__ __forceinline__ size_t pair_col(int c) { return (size_t)((c >> 5) << 6) + (size_t)(c & 31); }
+
 // ---- kernels_gemm.hip -------------------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); all row-major fp32, K % 32 == 0.
 hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
                              int K, int epi, hipStream_t s);
 
 // ---- kernels_gemm_f16x3.hip --------------------------------------------------------------------------------------
-// Same contract, fp32-accurate product from 3 fp16 MFMAs; W given as two fp16 planes made by split_weight_f16x3().
-hipError_t launch_linear_f16x3(const float* A, const void* Wh, const void* Wl, const float* bias, const float* R, float* C,
-                               int M, int N, int K, int epi, hipStream_t s);
-void split_weight_f16x3(const float* w, size_t n, uint16_t* hi, uint16_t* lo);
+// Same contract, fp32-accurate product from 3 fp16 MFMAs; A split on the fly, W in the pair layout made by
+// split_weight_f16x3() ([rows][2*cols] fp16 of 4096*w).
+hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* bias, const float* R, float* C, int M, int N,
+                               int K, int epi, hipStream_t s);
+void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair);
 
 // ---- kernels_gemm_x3p.hip ---------------------------------------------------------------------------------------
-// F16X3 with pre-split operands: A planes (>= ceil(M/256)*256 rows allocated), W planes (>= ceil(N/256)*256 rows).
-// outsplit: write C as hi/lo planes of 8*c (for a following x3p GEMM) instead of fp32.  variant 0 = auto tile choice.
-// qcols: with outsplit, columns < qcols are written as planes of 1*c instead of 8*c (q third of a temporal qkv GEMM).
-hipError_t launch_linear_x3p(const void* Ah, const void* Al, const void* Wh, const void* Wl, const float* bias,
-                             const float* R, float* C, void* Ch, void* Cl, int M, int N, int K, int epi, int outsplit,
-                             int qcols, int variant, hipStream_t s);
-hipError_t launch_split_x3(const float* x, void* hi, void* lo, size_t n, hipStream_t s);
+// F16X3 with pre-split operands in the pair layout: A (>= ceil(M/256)*256 rows allocated), W (>= ceil(N/256)*256 rows).
+// outsplit: 0 = fp32 C; 1 = C as two [M][N] fp16 planes Ch/Cl of 8*c (read by the temporal attention kernel);
+// 2 = C in the pair layout at Ch (operand of a following x3p GEMM; N % 32 == 0).  variant 0 = auto tile choice.
+// qcols: with outsplit, columns < qcols carry 1*c instead of 8*c (q third of a temporal qkv GEMM).
+hipError_t launch_linear_x3p(const void* Apair, const void* Wpair, const float* bias, const float* R, float* C, void* Ch,
+                             void* Cl, int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s);
+hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
 
 // ---- kernels_elem.hip -------------------------------------------------------------------------------------------
 // Row LayerNorm; optionally also writes a second LayerNorm of the first result (post-norm -> next block's norm1).
@@ -37,8 +46,8 @@ struct LnArgs {
   const float* x;
   float* y;          // may alias x; may be nullptr when only h is wanted (then h = LN(x; g1,b1))
   float* h;          // nullable
-  void* h_hi;        // nullable: when set (with h_lo), h is written as fp16 hi/lo planes of 8*h (F16X3 GEMM operand)
-  void* h_lo;        //           instead of fp32 (h itself may then be nullptr)
+  void* h_x3;        // nullable: when set, h is written in the F16X3 pair layout (8*h, D % 32 == 0) instead of fp32
+                     //           (h itself may then be nullptr)
   const float* g1; const float* b1; float eps1;
   const float* g2; const float* b2; float eps2;
   const float* pos;  // nullable, (pos_mod, D)
@@ -94,20 +103,19 @@ hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, con
 
 // ---- kernels_attn.hip -------------------------------------------------------------------------------------------
 // qkv: (B*T*J, 3*D) -> out (B*T*J, D), GRAND core  O = softmax(q k^T * dh^-0.5) v - v
-// When out_hi/out_lo are non-null the result is written as fp16 hi/lo planes of 8*o (F16X3 GEMM operand) and `out`
-// is ignored.
-hipError_t launch_attn_spatial_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+// When out_x3 is non-null the result is written in the F16X3 pair layout (8*o, operand of the proj GEMM; D % 32 == 0)
+// and `out` is ignored.
+hipError_t launch_attn_spatial_f32(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H, hipStream_t s);
+hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H, hipStream_t s);
+hipError_t launch_attn_generic(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H, int temporal,
+                               hipStream_t s);
+// ---- kernels_attn_x3.hip: temporal attention on fp16 MFMA with F16X3 accuracy; qkv as hi/lo planes ([rows][3D] each,
+// written by the qkv GEMM with outsplit = 1), output in the pair layout
+hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_x3, int B, int T, int J, int D, int H,
                                    hipStream_t s);
-hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
-                                    hipStream_t s);
-hipError_t launch_attn_generic(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
-                               int temporal, hipStream_t s);
-// ---- kernels_attn_x3.hip: temporal attention on fp16 MFMA with F16X3 accuracy; qkv and output as hi/lo planes
-hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int T, int J,
-                                   int D, int H, hipStream_t s);
 bool attn_temporal_x3_ok(int T, int D, int H);
 hipError_t launch_split_qkv(const float* x, void* hi, void* lo, size_t rows, int D, hipStream_t s);
-hipError_t launch_unsplit(const void* hi, const void* lo, float* x, size_t n, hipStream_t s);
+hipError_t launch_unsplit_pair(const void* pair, float* x, size_t rows, int cols, hipStream_t s);
 bool attn_spatial_fast_ok(int J, int D, int H);
 bool attn_temporal_fast_ok(int T, int D, int H);
 

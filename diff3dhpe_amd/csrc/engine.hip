@@ -42,8 +42,7 @@ struct WeightSlot {
 struct BlockW {
   const float *n1g, *n1b, *qkvw, *qkvb, *projw, *projb, *n2g, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
   // F16X3 mode: fp16 hi/lo planes of the four GEMM weights (same [N][K] layout)
-  const uint16_t *qkv_h = nullptr, *qkv_l = nullptr, *proj_h = nullptr, *proj_l = nullptr;
-  const uint16_t *fc1_h = nullptr, *fc1_l = nullptr, *fc2_h = nullptr, *fc2_l = nullptr;
+  const uint16_t *qkv_x3 = nullptr, *proj_x3 = nullptr, *fc1_x3 = nullptr, *fc2_x3 = nullptr;   // F16X3 pair layout
 };
 
 }  // namespace
@@ -238,13 +237,13 @@ int compute_temb(d3d_engine* e, const float* times_dev, int n, float* out, float
   return D3D_OK;
 }
 
-int attention(d3d_engine* e, const float* qkv, float* out, void* out_hi, void* out_lo, int B, bool temporal, hipStream_t s) {
+int attention(d3d_engine* e, const float* qkv, float* out, void* out_x3, int B, bool temporal, hipStream_t s) {
   if (!temporal) {
-    if (attn_spatial_fast_ok(e->J, e->D, e->H)) HIP_TRY(launch_attn_spatial_f32(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, s));
-    else HIP_TRY(launch_attn_generic(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, 0, s));
+    if (attn_spatial_fast_ok(e->J, e->D, e->H)) HIP_TRY(launch_attn_spatial_f32(qkv, out, out_x3, B, e->T, e->J, e->D, e->H, s));
+    else HIP_TRY(launch_attn_generic(qkv, out, out_x3, B, e->T, e->J, e->D, e->H, 0, s));
   } else {
-    if (attn_temporal_fast_ok(e->T, e->D, e->H)) HIP_TRY(launch_attn_temporal_f32(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, s));
-    else HIP_TRY(launch_attn_generic(qkv, out, out_hi, out_lo, B, e->T, e->J, e->D, e->H, 1, s));
+    if (attn_temporal_fast_ok(e->T, e->D, e->H)) HIP_TRY(launch_attn_temporal_f32(qkv, out, out_x3, B, e->T, e->J, e->D, e->H, s));
+    else HIP_TRY(launch_attn_generic(qkv, out, out_x3, B, e->T, e->J, e->D, e->H, 1, s));
   }
   return D3D_OK;
 }
@@ -262,25 +261,23 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
                          y_bcast, s));
   }
   const bool x3 = e->cfg.precision == D3D_PREC_F16X3;
-  // F16X3: every GEMM A-operand lives as two fp16 planes (hi, lo of 8*a) written by its producer; the plane pair of
-  // an (rows x cols) activation occupies the same bytes as the fp32 tensor would (rows padded to 256).
-  const size_t Mp = ((size_t)M + 255) / 256 * 256;
-  uint16_t* HNh = reinterpret_cast<uint16_t*>(w.HN);
-  uint16_t* HNl = HNh + Mp * D;
-  uint16_t* HIDh = reinterpret_cast<uint16_t*>(w.HID);
-  uint16_t* HIDl = HIDh + Mp * e->Dm;
-  // A: fp32 activation (FP32 mode) or its planes (F16X3 mode); `split_out`: write C as planes (fc1 -> fc2 hand-off)
+  // F16X3: every GEMM A-operand lives in the fp16 hi/lo pair layout (d3d_kernels.h) written by its producer; the pair
+  // buffer of an (rows x cols) activation occupies the same bytes as the fp32 tensor would (rows padded to 256, the
+  // padding rows are staged by edge tiles but never stored).
+  uint16_t* HNx = reinterpret_cast<uint16_t*>(w.HN);
+  uint16_t* HIDx = reinterpret_cast<uint16_t*>(w.HID);
+  // A: fp32 activation (FP32 mode) or its pair buffer (F16X3 mode).  outsplit (F16X3 only): 1 = C as hi/lo planes
+  // Ch/Cl (qkv -> temporal attention), 2 = C in the pair layout at Ch (fc1 -> fc2 hand-off)
   int qcols_ = 0;
-  auto linear = [&](const float* A, const uint16_t* Ah_, const uint16_t* Al_, const float* W, const uint16_t* Wh,
-                    const uint16_t* Wl, const float* bias, const float* R, float* C, uint16_t* Ch_, uint16_t* Cl_, int N, int K,
-                    int epi) -> hipError_t {
+  auto linear = [&](const float* A, const uint16_t* Ax, const float* W, const uint16_t* Wx, const float* bias, const float* R,
+                    float* C, uint16_t* Ch_, uint16_t* Cl_, int outsplit, int N, int K, int epi) -> hipError_t {
     Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), s);
-    if (x3) return launch_linear_x3p(Ah_, Al_, Wh, Wl, bias, R, C, Ch_, Cl_, M, N, K, epi, Ch_ != nullptr, qcols_, 0, s);
+    if (x3) return launch_linear_x3p(Ax, Wx, bias, R, C, Ch_, Cl_, M, N, K, epi, outsplit, qcols_, 0, s);
     return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
   };
   auto lnorm = [&](LnArgs a) -> hipError_t {
-    if (x3 && a.h) { a.h = nullptr; a.h_hi = HNh; a.h_lo = HNl; }   // normalised activations go out as GEMM operand planes
-    Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + (a.y ? 1 : 0) + ((a.h || a.h_hi) ? 1 : 0)), s);
+    if (x3 && a.h) { a.h = nullptr; a.h_x3 = HNx; }   // normalised activations go out as GEMM operands
+    Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + (a.y ? 1 : 0) + ((a.h || a.h_x3) ? 1 : 0)), s);
     return launch_layernorm(a, s);
   };
   {  // h = norm1_0(x)
@@ -297,29 +294,29 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
     uint16_t* QKVh = reinterpret_cast<uint16_t*>(w.QKV);
     uint16_t* QKVl = QKVh + (size_t)M * 3 * D;
     qcols_ = attn_x3 ? D : 0;
-    HIP_TRY(linear(w.HN, HNh, HNl, bw.qkvw, bw.qkv_h, bw.qkv_l, bw.qkvb, nullptr, w.QKV, attn_x3 ? QKVh : nullptr,
-                   attn_x3 ? QKVl : nullptr, 3 * D, D, EPI_NONE));
+    HIP_TRY(linear(w.HN, HNx, bw.qkvw, bw.qkv_x3, bw.qkvb, nullptr, w.QKV, attn_x3 ? QKVh : nullptr, attn_x3 ? QKVl : nullptr,
+                   attn_x3 ? 1 : 0, 3 * D, D, EPI_NONE));
     qcols_ = 0;
     {
       const int N = temporal ? T : J;
       Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
       if (attn_x3) {
-        HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, HNh, HNl, B, T, J, D, e->H, s));
+        HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, HNx, B, T, J, D, e->H, s));
       } else {
-        int rc = attention(e, w.QKV, w.HN, x3 ? HNh : nullptr, x3 ? HNl : nullptr, B, temporal, s);
+        int rc = attention(e, w.QKV, w.HN, x3 ? HNx : nullptr, B, temporal, s);
         if (rc) return rc;
       }
     }
-    HIP_TRY(linear(w.HN, HNh, HNl, bw.projw, bw.proj_h, bw.proj_l, bw.projb, w.X, w.X, nullptr, nullptr, D, D, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HN, HNx, bw.projw, bw.proj_x3, bw.projb, w.X, w.X, nullptr, nullptr, 0, D, D, EPI_RESIDUAL));
     {  // h = norm2(x)
       LnArgs a{};
       a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       HIP_TRY(lnorm(a));
     }
-    HIP_TRY(linear(w.HN, HNh, HNl, bw.fc1w, bw.fc1_h, bw.fc1_l, bw.fc1b, nullptr, w.HID, x3 ? HIDh : nullptr, x3 ? HIDl : nullptr,
-                   e->Dm, D, EPI_GELU));
-    HIP_TRY(linear(w.HID, HIDh, HIDl, bw.fc2w, bw.fc2_h, bw.fc2_l, bw.fc2b, w.X, w.X, nullptr, nullptr, D, e->Dm, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HN, HNx, bw.fc1w, bw.fc1_x3, bw.fc1b, nullptr, w.HID, x3 ? HIDx : nullptr, nullptr, x3 ? 2 : 0, e->Dm, D,
+                   EPI_GELU));
+    HIP_TRY(linear(w.HID, HIDx, bw.fc2w, bw.fc2_x3, bw.fc2b, w.X, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL));
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = next.norm1(x)
       LnArgs a{};
       a.x = w.X; a.y = w.X;
@@ -486,8 +483,8 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     e->blk.push_back(blockw("TTEblocks." + std::to_string(i)));
   }
   if (e->cfg.precision == D3D_PREC_F16X3) {
-    // fp16 hi/lo planes of the four GEMM weights of every block, rows padded to a multiple of 256 (zero rows) so the
-    // LDS-DMA of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
+    // fp16 hi/lo pair layout of the four GEMM weights of every block, rows padded to a multiple of 256 (zero rows) so
+    // the LDS-DMA of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
     const size_t D = e->D, Dm = e->Dm;
     auto pad256 = [](size_t n) { return (n + 255) / 256 * 256; };
     const size_t per_blk = 2 * (pad256(3 * D) * D + pad256(D) * D + pad256(Dm) * D + pad256(D) * Dm);
@@ -497,18 +494,17 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     size_t o = 0;
     for (int k = 0; k < e->nblk; ++k) {
       const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2);
-      auto plane = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& hi, const uint16_t*& lo) {
+      auto pair = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& dst) {
         const WeightSlot& ws = e->slots[e->index[name]];
-        const size_t padded = pad256(rows) * cols;
-        split_weight_f16x3(ws.host.data(), rows * cols, host.data() + o, host.data() + o + padded);
-        hi = e->arena16 + o; lo = e->arena16 + o + padded;
-        o += 2 * padded;
+        split_weight_f16x3(ws.host.data(), rows, cols, host.data() + o);
+        dst = e->arena16 + o;
+        o += 2 * pad256(rows) * cols;
       };
       BlockW& b = e->blk[k];
-      plane(p + ".attn.qkv.weight", 3 * D, D, b.qkv_h, b.qkv_l);
-      plane(p + ".attn.proj.weight", D, D, b.proj_h, b.proj_l);
-      plane(p + ".mlp.fc1.weight", Dm, D, b.fc1_h, b.fc1_l);
-      plane(p + ".mlp.fc2.weight", D, Dm, b.fc2_h, b.fc2_l);
+      pair(p + ".attn.qkv.weight", 3 * D, D, b.qkv_x3);
+      pair(p + ".attn.proj.weight", D, D, b.proj_x3);
+      pair(p + ".mlp.fc1.weight", Dm, D, b.fc1_x3);
+      pair(p + ".mlp.fc2.weight", D, Dm, b.fc2_x3);
     }
     HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
@@ -830,30 +826,26 @@ int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, floa
 }
 
 namespace {
-// test/bench helper: device planes for an fp32 device matrix (rows padded to 256).  Weights are split on the host with
-// the same routine the engine uses at commit; activations on the device with the producers' split.
-struct TmpPlanes {
+// test/bench helper: F16X3 pair buffer of an fp32 device matrix (rows padded to 256, zero rows).  Weights are split on
+// the host with the same routine the engine uses at commit; activations on the device with the producers' split.
+struct TmpPair {
   uint16_t* dev = nullptr;
-  size_t plane = 0;
-  ~TmpPlanes() { (void)hipFree(dev); }
-  const uint16_t* hi() const { return dev; }
-  const uint16_t* lo() const { return dev + plane; }
+  ~TmpPair() { (void)hipFree(dev); }
 };
-int make_planes(TmpPlanes& t, const float* src_dev, int rows, int cols, bool weight, hipStream_t s) {
+int make_pair(TmpPair& t, const float* src_dev, int rows, int cols, bool weight, hipStream_t s) {
   const size_t rp = ((size_t)rows + 255) / 256 * 256;
-  t.plane = rp * cols;
-  HIP_TRY(hipMalloc(&t.dev, 2 * t.plane * sizeof(uint16_t)));
-  HIP_TRY(hipMemsetAsync(t.dev, 0, 2 * t.plane * sizeof(uint16_t), s));
+  const size_t n16 = 2 * rp * cols;
+  HIP_TRY(hipMalloc(&t.dev, n16 * sizeof(uint16_t)));
+  HIP_TRY(hipMemsetAsync(t.dev, 0, n16 * sizeof(uint16_t), s));
   if (weight) {
     std::vector<float> h((size_t)rows * cols);
-    std::vector<uint16_t> pl(2 * h.size());
+    std::vector<uint16_t> pr(2 * h.size());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpy(h.data(), src_dev, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-    split_weight_f16x3(h.data(), h.size(), pl.data(), pl.data() + h.size());
-    HIP_TRY(hipMemcpy(t.dev, pl.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.dev + t.plane, pl.data() + h.size(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    split_weight_f16x3(h.data(), rows, cols, pr.data());
+    HIP_TRY(hipMemcpy(t.dev, pr.data(), pr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else {
-    HIP_TRY(launch_split_x3(src_dev, t.dev, t.dev + t.plane, (size_t)rows * cols, s));
+    HIP_TRY(launch_split_x3(src_dev, t.dev, (size_t)rows, cols, s));
   }
   return D3D_OK;
 }
@@ -870,20 +862,20 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
   if (!A || !W || !C || reps < 1) return fail(D3D_EINVAL, "bad argument");
   if (K % 32) return fail(D3D_EUNSUP, "K must be a multiple of 32");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  TmpPlanes ap, wp;
+  TmpPair ap, wp;
   if (precision == D3D_PREC_F16X3 && (N % 4) != 0) variant = 9;   // the plane kernel stores 4 columns at a time
   if (precision == D3D_PREC_F16X3) {
-    int rc = make_planes(wp, W, N, K, true, s);
+    int rc = make_pair(wp, W, N, K, true, s);
     if (rc) return rc;
     if (variant != 9) {
-      rc = make_planes(ap, A, M, K, false, s);
+      rc = make_pair(ap, A, M, K, false, s);
       if (rc) return rc;
     }
   }
   auto once = [&]() -> hipError_t {
     if (precision == D3D_PREC_FP32) return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
-    if (variant == 9) return launch_linear_f16x3(A, wp.hi(), wp.lo(), bias, R, C, M, N, K, epi, s);   // on-the-fly A split
-    return launch_linear_x3p(ap.hi(), ap.lo(), wp.hi(), wp.lo(), bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s);
+    if (variant == 9) return launch_linear_f16x3(A, wp.dev, bias, R, C, M, N, K, epi, s);   // on-the-fly A split
+    return launch_linear_x3p(ap.dev, wp.dev, bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s);
   };
   HIP_TRY(once());
   if (avg_ms) {
@@ -921,13 +913,13 @@ int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t
   if (!qkv || !out || B <= 0 || T <= 0 || J <= 0 || D <= 0 || H <= 0 || D % H) return fail(D3D_EINVAL, "bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (precision == D3D_PREC_F16X3 && temporal && !force_generic && attn_temporal_x3_ok(T, D, H)) {
-    // test hook: fp32 qkv -> planes (as the qkv GEMM epilogue writes them) -> fp16-MFMA attention -> planes -> fp32
+    // test hook: fp32 qkv -> planes (as the qkv GEMM epilogue writes them) -> fp16-MFMA attention -> pair layout -> fp32
     const size_t rows = (size_t)B * T * J, nq = rows * 3 * D, no = rows * D;
     uint16_t* tmp = nullptr;
     HIP_TRY(hipMalloc(&tmp, (2 * nq + 2 * no) * sizeof(uint16_t)));
     hipError_t e1 = launch_split_qkv(qkv, tmp, tmp + nq, rows, D, s);
-    hipError_t e2 = (e1 == hipSuccess) ? launch_attn_temporal_x3(tmp, tmp + nq, tmp + 2 * nq, tmp + 2 * nq + no, B, T, J, D, H, s) : e1;
-    hipError_t e3 = (e2 == hipSuccess) ? launch_unsplit(tmp + 2 * nq, tmp + 2 * nq + no, out, no, s) : e2;
+    hipError_t e2 = (e1 == hipSuccess) ? launch_attn_temporal_x3(tmp, tmp + nq, tmp + 2 * nq, B, T, J, D, H, s) : e1;
+    hipError_t e3 = (e2 == hipSuccess) ? launch_unsplit_pair(tmp + 2 * nq, out, rows, D, s) : e2;
     hipError_t e4 = hipStreamSynchronize(s);
     (void)hipFree(tmp);
     HIP_TRY(e3);
@@ -935,11 +927,11 @@ int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t
     return D3D_OK;
   }
   if (!force_generic && !temporal && attn_spatial_fast_ok(J, D, H)) {
-    HIP_TRY(launch_attn_spatial_f32(qkv, out, nullptr, nullptr, B, T, J, D, H, s));
+    HIP_TRY(launch_attn_spatial_f32(qkv, out, nullptr, B, T, J, D, H, s));
   } else if (!force_generic && temporal && attn_temporal_fast_ok(T, D, H)) {
-    HIP_TRY(launch_attn_temporal_f32(qkv, out, nullptr, nullptr, B, T, J, D, H, s));
+    HIP_TRY(launch_attn_temporal_f32(qkv, out, nullptr, B, T, J, D, H, s));
   } else {
-    HIP_TRY(launch_attn_generic(qkv, out, nullptr, nullptr, B, T, J, D, H, temporal, s));
+    HIP_TRY(launch_attn_generic(qkv, out, nullptr, B, T, J, D, H, temporal, s));
   }
   return D3D_OK;
 }

@@ -45,7 +45,7 @@ constexpr int SP_DH = 64;
 
 template <int NJ>
 __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restrict__ qkv, float* __restrict__ out,
-                                                          _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                          _Float16* __restrict__ out_x3,
                                                           int units, int H, int D) {
   constexpr int UPW = 64 / NJ;                   // (group, head) units per wave
   constexpr int UNIT_LD = NJ * SP_DH + 4;        // +16 B so the UPW broadcast addresses fall in different banks
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
   }
   if (valid) {
     const size_t oo = ((size_t)g * NJ + i) * D + h * SP_DH;
-    if (out_hi) {   // 16-byte stores: 8 fp16 per plane per instruction
+    if (out_x3) {   // pair layout, 16-byte stores: 8 hi at pair_col(c), their 8 lo 32 elements further
 #pragma unroll
       for (int c = 0; c < SP_DH; c += 8) {
         h8a hi, lo;
@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
           hi[e] = x;
           lo[e] = y;
         }
-        *reinterpret_cast<h8a*>(out_hi + oo + c) = hi;
-        *reinterpret_cast<h8a*>(out_lo + oo + c) = lo;
+        _Float16* op = out_x3 + 2 * oo + pair_col(c);   // oo % 32 == 0, so pair_col(oo + c) = 2 oo + pair_col(c)
+        *reinterpret_cast<h8a*>(op) = hi;
+        *reinterpret_cast<h8a*>(op + PAIR_LO) = lo;
       }
     } else {
 #pragma unroll
@@ -169,15 +170,14 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
 
 bool attn_spatial_fast_ok(int J, int D, int H) { return J == 17 && H > 0 && D == H * SP_DH; }
 
-hipError_t launch_attn_spatial_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+hipError_t launch_attn_spatial_f32(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H,
                                    hipStream_t s) {
   if (!attn_spatial_fast_ok(J, D, H)) return hipErrorInvalidValue;
   const long long units = (long long)B * T * H;
   constexpr int UPB = 4 * (64 / 17);
   const long long grid = (units + UPB - 1) / UPB;
   if (units > 0x7fffffffLL || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_attn_spatial_f32<17>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_hi,
-                     (_Float16*)out_lo, (int)units, H, D);
+  hipLaunchKernelGGL(k_attn_spatial_f32<17>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_x3, (int)units, H, D);
   return hipGetLastError();
 }
 
@@ -186,7 +186,7 @@ constexpr int TP_DH = 64, K_LD = 68, V_LD = 64;
 
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                                _Float16* __restrict__ out_x3,
                                                                 int T, int J, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TP = 32 * NKT;
@@ -297,8 +297,9 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __r
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const size_t o = oo + dt * 32 + 8 * g4 + 4 * hh;
-        if (out_hi)
-          store4_x3(out_hi + o, out_lo + o, oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
+        if (out_x3)   // pair layout: oo % 32 == 0, the 32-column tile dt is one 128-byte line
+          store4_x3(out_x3 + 2 * oo + dt * 64 + 8 * g4 + 4 * hh, out_x3 + 2 * oo + dt * 64 + 8 * g4 + 4 * hh + PAIR_LO,
+                    oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
         else
           *reinterpret_cast<float4*>(out + o) =
               make_float4(oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __r
 bool attn_temporal_fast_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * TP_DH; }
 
 template <int NKT>
-static hipError_t launch_temporal_nkt(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+static hipError_t launch_temporal_nkt(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H,
                                       hipStream_t s) {
   const size_t lds_bytes = (size_t)32 * NKT * (K_LD + V_LD) * sizeof(float);
   static bool attr_set = false;
@@ -322,29 +323,29 @@ static hipError_t launch_temporal_nkt(const float* qkv, float* out, void* out_hi
   const long long grid = (long long)B * J * H;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_attn_temporal_f32<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, qkv, out,
-                     (_Float16*)out_hi, (_Float16*)out_lo, T, J, H, D);
+                     (_Float16*)out_x3, T, J, H, D);
   return hipGetLastError();
 }
 
-hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H,
                                     hipStream_t s) {
   if (!attn_temporal_fast_ok(T, D, H)) return hipErrorInvalidValue;
   switch ((T + 31) / 32) {
-    case 1: return launch_temporal_nkt<1>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
-    case 2: return launch_temporal_nkt<2>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
-    case 3: return launch_temporal_nkt<3>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
-    case 4: return launch_temporal_nkt<4>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
-    case 5: return launch_temporal_nkt<5>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
-    case 6: return launch_temporal_nkt<6>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
-    case 7: return launch_temporal_nkt<7>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
-    default: return launch_temporal_nkt<8>(qkv, out, out_hi, out_lo, B, T, J, D, H, s);
+    case 1: return launch_temporal_nkt<1>(qkv, out, out_x3, B, T, J, D, H, s);
+    case 2: return launch_temporal_nkt<2>(qkv, out, out_x3, B, T, J, D, H, s);
+    case 3: return launch_temporal_nkt<3>(qkv, out, out_x3, B, T, J, D, H, s);
+    case 4: return launch_temporal_nkt<4>(qkv, out, out_x3, B, T, J, D, H, s);
+    case 5: return launch_temporal_nkt<5>(qkv, out, out_x3, B, T, J, D, H, s);
+    case 6: return launch_temporal_nkt<6>(qkv, out, out_x3, B, T, J, D, H, s);
+    case 7: return launch_temporal_nkt<7>(qkv, out, out_x3, B, T, J, D, H, s);
+    default: return launch_temporal_nkt<8>(qkv, out, out_x3, B, T, J, D, H, s);
   }
 }
 
 // =============================================================================================== generic (any N, dh)
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_generic(const float* __restrict__ qkv, float* __restrict__ out,
-                                                      _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                      _Float16* __restrict__ out_x3,
                                                       long long rows, int N, int H, int D, int temporal, int T, int J) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= rows) return;
@@ -389,12 +390,15 @@ __global__ __launch_bounds__(256) void k_attn_generic(const float* __restrict__ 
   const size_t oo = token(i) * D + h * DH;
 #pragma unroll
   for (int c = 0; c < DH; ++c) {
-    if (out_hi) split1_x3(o[c], out_hi[oo + c], out_lo[oo + c]);
+    if (out_x3) {
+      _Float16* op = out_x3 + token(i) * 2 * D + pair_col(h * DH + c);
+      split1_x3(o[c], op[0], op[PAIR_LO]);
+    }
     else out[oo + c] = o[c];
   }
 }
 
-hipError_t launch_attn_generic(const float* qkv, float* out, void* out_hi, void* out_lo, int B, int T, int J, int D, int H,
+hipError_t launch_attn_generic(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H,
                                int temporal, hipStream_t s) {
   if (H <= 0 || D % H) return hipErrorInvalidValue;
   const int dh = D / H;
@@ -405,8 +409,8 @@ hipError_t launch_attn_generic(const float* qkv, float* out, void* out_hi, void*
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
 #define D3D_GEN(DH)                                                                                                    \
   case DH:                                                                                                             \
-    hipLaunchKernelGGL(k_attn_generic<DH>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_hi,           \
-                       (_Float16*)out_lo, rows, N, H, D, temporal, T, J);                                                                                             \
+    hipLaunchKernelGGL(k_attn_generic<DH>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_x3, rows, N, \
+                       H, D, temporal, T, J);                                                                          \
     break;
   switch (dh) {
     D3D_GEN(4) D3D_GEN(8) D3D_GEN(16) D3D_GEN(32) D3D_GEN(64)

@@ -32,7 +32,7 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
-                                                               _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                               _Float16* __restrict__ out_x3,
                                                                int T, int J, int H, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int TP = 32 * NKT;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
     const float inv = 1.0f / (8192.0f * l);
     const size_t tokq = tok0 + (size_t)tq * J;
     const size_t vo = tokq * D3 + 2 * D + hd * XDH;
-    const size_t oo = tokq * D + hd * XDH;
+    const size_t oo = tokq * 2 * D + hd * 2 * XDH;   // pair layout: a head's 64 columns are two 128-byte lines
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
           oh[e] = (_Float16)sc;
           ol[e] = (_Float16)(sc - (float)oh[e]);
         }
-        *reinterpret_cast<h4*>(out_hi + oo + d) = oh;
-        *reinterpret_cast<h4*>(out_lo + oo + d) = ol;
+        *reinterpret_cast<h4*>(out_x3 + oo + pair_col(d)) = oh;
+        *reinterpret_cast<h4*>(out_x3 + oo + pair_col(d) + PAIR_LO) = ol;
       }
   }
 }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
 bool attn_temporal_x3_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * XDH; }
 
 template <int NKT>
-static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16* oh, _Float16* ol, int B, int T, int J, int D,
+static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D,
                                 int H, hipStream_t s) {
   const size_t lds_bytes = (size_t)4 * 32 * NKT * 128;   // K_hi, K_lo, V_hi, V_lo planes of TP rows x 128 B
   static bool attr_set = false;
@@ -230,24 +230,24 @@ static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16
   }
   const long long grid = (long long)B * J * H;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_attn_temporal_x3<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, oh, ol, T, J, H, D);
+  hipLaunchKernelGGL(k_attn_temporal_x3<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, ox, T, J, H, D);
   return hipGetLastError();
 }
 
-hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int T, int J,
+hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_x3, int B, int T, int J,
                                    int D, int H, hipStream_t s) {
-  if (!attn_temporal_x3_ok(T, D, H) || !qkv_hi || !qkv_lo || !out_hi || !out_lo) return hipErrorInvalidValue;
+  if (!attn_temporal_x3_ok(T, D, H) || !qkv_hi || !qkv_lo || !out_x3) return hipErrorInvalidValue;
   const _Float16 *ph = (const _Float16*)qkv_hi, *pl = (const _Float16*)qkv_lo;
-  _Float16 *oh = (_Float16*)out_hi, *ol = (_Float16*)out_lo;
+  _Float16* ox = (_Float16*)out_x3;
   switch ((T + 31) / 32) {
-    case 1: return launch_x3_nkt<1>(ph, pl, oh, ol, B, T, J, D, H, s);
-    case 2: return launch_x3_nkt<2>(ph, pl, oh, ol, B, T, J, D, H, s);
-    case 3: return launch_x3_nkt<3>(ph, pl, oh, ol, B, T, J, D, H, s);
-    case 4: return launch_x3_nkt<4>(ph, pl, oh, ol, B, T, J, D, H, s);
-    case 5: return launch_x3_nkt<5>(ph, pl, oh, ol, B, T, J, D, H, s);
-    case 6: return launch_x3_nkt<6>(ph, pl, oh, ol, B, T, J, D, H, s);
-    case 7: return launch_x3_nkt<7>(ph, pl, oh, ol, B, T, J, D, H, s);
-    default: return launch_x3_nkt<8>(ph, pl, oh, ol, B, T, J, D, H, s);
+    case 1: return launch_x3_nkt<1>(ph, pl, ox, B, T, J, D, H, s);
+    case 2: return launch_x3_nkt<2>(ph, pl, ox, B, T, J, D, H, s);
+    case 3: return launch_x3_nkt<3>(ph, pl, ox, B, T, J, D, H, s);
+    case 4: return launch_x3_nkt<4>(ph, pl, ox, B, T, J, D, H, s);
+    case 5: return launch_x3_nkt<5>(ph, pl, ox, B, T, J, D, H, s);
+    case 6: return launch_x3_nkt<6>(ph, pl, ox, B, T, J, D, H, s);
+    case 7: return launch_x3_nkt<7>(ph, pl, ox, B, T, J, D, H, s);
+    default: return launch_x3_nkt<8>(ph, pl, ox, B, T, J, D, H, s);
   }
 }
 
@@ -263,10 +263,12 @@ __global__ __launch_bounds__(256) void k_split_qkv(const float* __restrict__ x, 
   lo[i] = (_Float16)(s - (float)hh);
 }
 
-__global__ __launch_bounds__(256) void k_unsplit(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
-                                                 float* __restrict__ x, size_t n) {
+__global__ __launch_bounds__(256) void k_unsplit_pair(const _Float16* __restrict__ pair, float* __restrict__ x, size_t n, int cols) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) x[i] = ((float)hi[i] + (float)lo[i]) * 0.125f;
+  if (i >= n) return;
+  const size_t row = i / cols;
+  const _Float16* p = pair + row * 2 * cols + pair_col((int)(i - row * cols));
+  x[i] = ((float)p[0] + (float)p[PAIR_LO]) * 0.125f;
 }
 
 hipError_t launch_split_qkv(const float* x, void* hi, void* lo, size_t rows, int D, hipStream_t s) {
@@ -275,8 +277,9 @@ hipError_t launch_split_qkv(const float* x, void* hi, void* lo, size_t rows, int
   return hipGetLastError();
 }
 
-hipError_t launch_unsplit(const void* hi, const void* lo, float* x, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_unsplit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const _Float16*)hi, (const _Float16*)lo, x, n);
+hipError_t launch_unsplit_pair(const void* pair, float* x, size_t rows, int cols, hipStream_t s) {
+  const size_t n = rows * (size_t)cols;
+  hipLaunchKernelGGL(k_unsplit_pair, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const _Float16*)pair, x, n, cols);
   return hipGetLastError();
 }
 

@@ -105,19 +105,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
       if (c < D) *reinterpret_cast<float4*>(yr + c) = v[i];
     }
   }
-  if (a.h || a.h_hi) {
+  if (a.h || a.h_x3) {
     if (a.y) ln_row<NV>(v, D, lane, a.g2, a.b2, a.eps2);
-    if (a.h_hi) {
-      _Float16* hh = reinterpret_cast<_Float16*>(a.h_hi) + (size_t)row * D;
-      _Float16* hl = reinterpret_cast<_Float16*>(a.h_lo) + (size_t)row * D;
+    if (a.h_x3) {   // F16X3 pair layout: 8 lanes fill one 128-byte line (64 B of hi, 64 B of lo) of the row
+      _Float16* hp = reinterpret_cast<_Float16*>(a.h_x3) + (size_t)row * 2 * D;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = 4 * (lane + 64 * i);
         if (c < D) {
           h4v hi, lo;
           split4_x3(v[i], hi, lo);
-          *reinterpret_cast<h4v*>(hh + c) = hi;
-          *reinterpret_cast<h4v*>(hl + c) = lo;
+          *reinterpret_cast<h4v*>(hp + pair_col(c)) = hi;
+          *reinterpret_cast<h4v*>(hp + pair_col(c) + PAIR_LO) = lo;
         }
       }
     } else {

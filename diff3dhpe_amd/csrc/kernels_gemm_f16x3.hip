@@ -77,8 +77,8 @@ __device__ __forceinline__ void x3_epilogue(f32x16 (&acc)[2][2], const float* __
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_linear_f16x3(const float* __restrict__ A, const _Float16* __restrict__ Wh,
-                                                          const _Float16* __restrict__ Wl, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, 2) void k_linear_f16x3(const float* __restrict__ A, const _Float16* __restrict__ Wp,
+                                                          const float* __restrict__ bias,
                                                           const float* R, float* C, int M, int N, int K, int mtiles,
                                                           int ntiles) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * PLANE_BYTES];
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void k_linear_f16x3(const float* __restrict
         ra[p][1] = make_float4(0, 0, 0, 0);
       }
       if (gn < N) {
-        const size_t wo = (size_t)gn * K + k0 + sc * 8;
-        rwh[p] = *reinterpret_cast<const uint4*>(Wh + wo);
-        rwl[p] = *reinterpret_cast<const uint4*>(Wl + wo);
+        const size_t wo = (size_t)gn * 2 * K + 2 * k0 + sc * 8;   // pair layout: k-tile k0/32 is the 64 fp16 at 2*k0
+        rwh[p] = *reinterpret_cast<const uint4*>(Wp + wo);
+        rwl[p] = *reinterpret_cast<const uint4*>(Wp + wo + PAIR_LO);
       } else {
         rwh[p] = make_uint4(0, 0, 0, 0);
         rwl[p] = make_uint4(0, 0, 0, 0);
@@ -185,23 +185,22 @@ __global__ __launch_bounds__(256, 2) void k_linear_f16x3(const float* __restrict
   else x3_epilogue<EPI, true>(acc, bias, R, C, mw, nw, M, N);
 }
 
-hipError_t launch_linear_f16x3(const float* A, const void* Wh, const void* Wl, const float* bias, const float* R, float* C,
-                               int M, int N, int K, int epi, hipStream_t s) {
+hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* bias, const float* R, float* C, int M, int N,
+                               int K, int epi, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % XBK) != 0) return hipErrorInvalidValue;
   if (epi == EPI_RESIDUAL && R == nullptr) return hipErrorInvalidValue;
   const int mtiles = (M + XBM - 1) / XBM, ntiles = (N + XBN - 1) / XBN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  const _Float16* wh = reinterpret_cast<const _Float16*>(Wh);
-  const _Float16* wl = reinterpret_cast<const _Float16*>(Wl);
+  const _Float16* wp = reinterpret_cast<const _Float16*>(Wpair);
   switch (epi) {
     case EPI_NONE:
-      hipLaunchKernelGGL(k_linear_f16x3<EPI_NONE>, dim3(grid), dim3(256), 0, s, A, wh, wl, bias, R, C, M, N, K, mtiles, ntiles);
+      hipLaunchKernelGGL(k_linear_f16x3<EPI_NONE>, dim3(grid), dim3(256), 0, s, A, wp, bias, R, C, M, N, K, mtiles, ntiles);
       break;
     case EPI_GELU:
-      hipLaunchKernelGGL(k_linear_f16x3<EPI_GELU>, dim3(grid), dim3(256), 0, s, A, wh, wl, bias, R, C, M, N, K, mtiles, ntiles);
+      hipLaunchKernelGGL(k_linear_f16x3<EPI_GELU>, dim3(grid), dim3(256), 0, s, A, wp, bias, R, C, M, N, K, mtiles, ntiles);
       break;
     case EPI_RESIDUAL:
-      hipLaunchKernelGGL(k_linear_f16x3<EPI_RESIDUAL>, dim3(grid), dim3(256), 0, s, A, wh, wl, bias, R, C, M, N, K, mtiles, ntiles);
+      hipLaunchKernelGGL(k_linear_f16x3<EPI_RESIDUAL>, dim3(grid), dim3(256), 0, s, A, wp, bias, R, C, M, N, K, mtiles, ntiles);
       break;
     default:
       return hipErrorInvalidValue;
@@ -209,17 +208,20 @@ hipError_t launch_linear_f16x3(const float* A, const void* Wh, const void* Wl, c
   return hipGetLastError();
 }
 
-// Host-side weight split: w -> (hi, lo) fp16 planes of s*w with s = 2^12 (round-to-nearest-even both times).
-void split_weight_f16x3(const float* w, size_t n, uint16_t* hi, uint16_t* lo) {
-  for (size_t i = 0; i < n; ++i) {
-    float s = w[i] * 4096.0f;
-    if (s > 65504.0f) s = 65504.0f;
-    if (s < -65504.0f) s = -65504.0f;
-    const _Float16 h = (_Float16)s;
-    const _Float16 l = (_Float16)(s - (float)h);
-    __builtin_memcpy(&hi[i], &h, 2);
-    __builtin_memcpy(&lo[i], &l, 2);
-  }
+// Host-side weight split: w [rows, cols] -> pair layout (d3d_kernels.h) of hi/lo fp16 of s*w with s = 2^12
+// (round-to-nearest-even both times).
+void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair) {
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t c = 0; c < cols; ++c) {
+      float s = w[r * cols + c] * 4096.0f;
+      if (s > 65504.0f) s = 65504.0f;
+      if (s < -65504.0f) s = -65504.0f;
+      const _Float16 h = (_Float16)s;
+      const _Float16 l = (_Float16)(s - (float)h);
+      uint16_t* o = pair + r * 2 * cols + pair_col((int)c);
+      __builtin_memcpy(o, &h, 2);
+      __builtin_memcpy(o + PAIR_LO, &l, 2);
+    }
 }
 
 }  // namespace d3d
