@@ -37,6 +37,8 @@ void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair
 hipError_t launch_linear_x3p(const void* Apair, const void* Wpair, const float* bias, const float* R, float* C, void* Ch,
                              void* Cl, int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s);
 hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
+// diagnostic launches (variants 13 / 11): per (workgroup, wave) six u64 stamps {clk, 100 MHz} x {start, k-loop end, end}
+void set_linear_x3_diag(unsigned long long* dev_buf);
 
 // ---- kernels_elem.hip -------------------------------------------------------------------------------------------
 // Row LayerNorm; optionally also writes a second LayerNorm of the first result (post-norm -> next block's norm1).

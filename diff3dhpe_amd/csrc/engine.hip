@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -878,6 +879,35 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
     return launch_linear_x3p(ap.dev, wp.dev, bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s);
   };
   HIP_TRY(once());
+  if (getenv("D3D_GEMM_DIAG") && precision == D3D_PREC_F16X3 && (variant == 13 || variant == 11)) {
+    // diagnostic: in-kernel clock and k-loop / epilogue split from s_memtime / s_memrealtime stamps (256x256 tiles, 8 waves)
+    const size_t nwg = (size_t)(((M + 255) / 256 + 7) / 8 * 8) * ((N + 255) / 256), nrec = nwg * 8;
+    unsigned long long* dbuf = nullptr;
+    HIP_TRY(hipMalloc(&dbuf, nrec * 6 * sizeof(unsigned long long)));
+    for (int i = 0; i < 20; ++i) HIP_TRY(once());              // warm clocks
+    HIP_TRY(hipMemsetAsync(dbuf, 0, nrec * 6 * sizeof(unsigned long long), s));
+    set_linear_x3_diag(dbuf);
+    hipError_t le = once();
+    set_linear_x3_diag(nullptr);
+    HIP_TRY(le);
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(nrec * 6);
+    HIP_TRY(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dbuf);
+    std::vector<double> ghz, loop_us, epi_us;
+    unsigned long long rmin = ~0ull, rmax = 0;
+    for (size_t i = 0; i < nrec; ++i) {
+      const unsigned long long* d = &h[i * 6];
+      if (!d[1]) continue;
+      ghz.push_back((double)(d[4] - d[0]) / (double)(d[5] - d[1]) * 0.1);
+      loop_us.push_back((double)(d[3] - d[1]) * 0.01);
+      epi_us.push_back((double)(d[5] - d[3]) * 0.01);
+      rmin = std::min(rmin, d[1]); rmax = std::max(rmax, d[5]);
+    }
+    auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+    fprintf(stderr, "[gemm diag] N=%d K=%d v%d: waves %zu, in-kernel clock %.3f GHz, k-loop %.2f us, epilogue %.2f us (medians), "
+            "kernel span %.1f us\n", N, K, variant, ghz.size(), med(ghz), med(loop_us), med(epi_us), (double)(rmax - rmin) * 0.01);
+  }
   if (avg_ms) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));

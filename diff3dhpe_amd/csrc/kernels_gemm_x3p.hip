@@ -316,8 +316,25 @@ static hipError_t launch_tile(const _Float16* Ap, const _Float16* Wp, const floa
 // Wave tile 128(m) x 64(n) = 8 x 4 tiles of 16x16 (128 accumulator VGPRs); weight fragment first, so a tile holds C^T:
 // lane -> token m = lane&15, registers -> n = 4*(lane>>4) + reg.  Fragment read: lane (r16 = lane&15, q = lane>>4) takes
 // 16-byte chunk q (hi) and 4+q (lo) of row r16.
-template <int EPI, int OUTSPLIT, bool CHECK>
-__device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[8][4], float* patch, const float* __restrict__ bias, const float* Rt,
+// GELU(x) = x Phi(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), with erfc from Abramowitz & Stegun 7.1.26
+// (erfc(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and a
+// handful of FMAs, branch-free -- the library erff costs about three times as much, and the fc1 epilogue is VALU-bound
+// (128 outputs per lane).  The absolute error of the result stays below 1e-7 |x|, the rounding level of the fp32 path.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float z = ax * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
+  const float s = 0.5f * ax * (p * t) * e;
+  return __builtin_fmaxf(x, 0.0f) - s;
+}
+
+template <int TM, int EPI, int OUTSPLIT, bool CHECK>
+__device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, const float* __restrict__ bias, const float* Rt,
                                              float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0, int lane, int M, int N,
                                              int qcols) {
   // patch: two wave-private 16 rows x 64 floats (alternating, so the LDS round trip of one m-tile overlaps the stores
@@ -330,8 +347,26 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[8][4], float* patch, c
   if (bias && ncol_ok) b4 = *reinterpret_cast<const float4*>(bias + n);
   const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
   const int pc = (int)pair_col(4 * rc4);
+  // Residual rows are fetched PF m-tiles (PF * 4 KiB per wave) ahead of their use: vmcnt retires in order, so a load
+  // issued right behind the previous m-tile's stores and consumed at once waits for those stores' acknowledgement as well
+  // as its own latency (measured: 22 us per 256x256 tile with load-add-store in sequence, against 3.8 us for the plain
+  // store epilogue).
+  constexpr int PF = (EPI == EPI_RESIDUAL) ? (TM < 3 ? TM : 3) : 0;
+  float4 rr[TM][4];
+  auto load_res = [&](int i) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+    for (int p = 0; p < 4; ++p) {
+      const int row = rrow + 4 * p;
+      rr[i][p] = make_float4(0, 0, 0, 0);
+      if (!CHECK || (mt0 + 16 * i + row < M && ncol_ok)) rr[i][p] = *reinterpret_cast<const float4*>(Rt + (16 * i + row) * N + 4 * rc4);
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) load_res(i);
+  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
@@ -346,26 +381,40 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[8][4], float* patch, c
       float v[4] = {a4.x * P_OUT_SCALE + b4.x, a4.y * P_OUT_SCALE + b4.y, a4.z * P_OUT_SCALE + b4.z, a4.w * P_OUT_SCALE + b4.w};
       if (EPI == EPI_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_p(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
       }
       if (EPI == EPI_RESIDUAL) {
-        const float4 r4 = *reinterpret_cast<const float4*>(Rt + off);
+        const float4 r4 = rr[i][p];
         v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
       }
       if (OUTSPLIT) store_split4<OUTSPLIT>(v, osc, Cht, Clt, off, (16 * i + row) * 2 * N + pc);
       else *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two m-tiles (two patches) in flight at a time
+    if (i & 1) {   // two m-tiles (two patches) in flight at a time; their accumulators are dead: refill the residual window
+      if (EPI == EPI_RESIDUAL) {
+        if (i - 1 + PF < TM) load_res(i - 1 + PF);
+        if (i + PF < TM) load_res(i + PF);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
-template <int EPI, int OUTSPLIT>
-__global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
-                                                    const float* __restrict__ bias, const float* R, float* C, _Float16* Ch,
-                                                    _Float16* Cl, int M, int N, int K, int mtiles, int ntiles, int qcols) {
-  constexpr int BM = 256, BN = 256, WN = 4, NW = 8;
+// Tile shapes: BM = 16*TM*WM rows, BN = 64*WN columns, WM x WN waves, each wave (16 TM) x 64 = TM x 4 MFMA tiles.
+//   <8,2,4> 256x256, 8 waves, 128 KiB LDS, 1 workgroup/CU  -- the main launch
+//   <4,2,2> 128x128, 4 waves,  64 KiB LDS, 2 workgroups/CU -- remainder rows and small problems
+// Every shape adds the same MFMA results in the same order into an output element, so an element's value does not
+// depend on which tile shape (or which launch of a split problem) produced it.
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int SCHED>
+__global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
+                                                             const float* __restrict__ bias, const float* R, float* C,
+                                                             _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
+                                                             int ntiles, int qcols, unsigned long long* diag) {
+  constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
   constexpr int A_REG = BM * 128, STAGE = (BM + BN) * 128;
-  constexpr int A_IT = 4, N_IT = 8;       // 1-KiB DMA pieces per wave per k-tile: 4 of A then 4 of W
+  constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, N_IT = A_IT + B_IT;   // 1-KiB DMA pieces per wave per k-tile
+  static_assert(NW % 2 == 0 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must split evenly over the waves");
+  static_assert(2 * STAGE >= NW * 2 * 16 * 64 * 4, "epilogue patches must fit in the operand stages");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int bid = blockIdx.x;
@@ -374,6 +423,10 @@ __global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__
   const int nt = slot % ntiles;
   if (mt >= mtiles) return;
   const int m0 = mt * BM, n0 = nt * BN;
+  // diag (diagnostic launches only, experiments/gemm_bench.py): shader-clock and 100 MHz stamps around the k-loop and the
+  // epilogue of every workgroup, into a buffer nothing else reads
+  unsigned long long st_c0 = 0, st_r0 = 0;
+  if (diag) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -388,9 +441,9 @@ __global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__
     else D3D_GLDS(srcB + (size_t)(KT) * 64 + ((IT) - A_IT) * it_stride, (ST) * STAGE + dstB + ((IT) - A_IT) * NW * 1024); \
   } while (0)
 
-  f32x4 acc[8][4];
+  f32x4 acc[TM][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -398,14 +451,14 @@ __global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__
 
   // fragment offsets: rows r16 + 16 i all share the swizzle key r16>>1
   const int foff = (q ^ (r16 >> 1)) << 4;
-  const int aoff = (wm * 128 + r16) * 128 + foff, boff = A_REG + (wn * 64 + r16) * 128 + foff;
+  const int aoff = (wm * 16 * TM + r16) * 128 + foff, boff = A_REG + (wn * 64 + r16) * 128 + foff;
   const int nk = K / PBK;
 #pragma unroll
   for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(0, 0, it);
 
-  // one k-tile = 8 groups (one 16-row m-tile each): the A fragments of group g+1 are read, and one DMA piece of the next
-  // k-tile is issued, before the 12 MFMAs of group g; the 8 W fragments are read once at the top of the k-tile.
-#define D3D_QKTILE(KT, PREFETCH)                                                                                         \
+  // one k-tile = TM groups (one 16-row m-tile each): the A fragments of group g+1 are read, and PPG DMA pieces of the
+  // next k-tile are issued, before the 12 MFMAs of group g; the 8 W fragments are read once at the top of the k-tile.
+#define D3D_QKTILE(KT, PREFETCH, G0, NG)                                                                                 \
   do {                                                                                                                   \
     __syncthreads();                                                                                                     \
     const int nst = ((KT) + 1) & 1;                                                                                      \
@@ -417,12 +470,16 @@ __global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__
     }                                                                                                                    \
     ah[0] = *reinterpret_cast<const h8*>(sb + aoff);                                                                     \
     al[0] = *reinterpret_cast<const h8*>(sb + (aoff ^ 64));                                                              \
-    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                      \
-      if (g + 1 < 8) {                                                                                                   \
+    _Pragma("unroll") for (int g = 0; g < TM; ++g) {                                                                     \
+      if (g + 1 < TM) {                                                                                                  \
         ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                      \
         al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                             \
       }                                                                                                                  \
-      if (PREFETCH) D3D_QSTAGE_ONE(nst, (KT) + 1, g);                                                                    \
+      if (PREFETCH && g >= (G0) && g < (G0) + (NG)) {                                                                    \
+        constexpr int ppg = (N_IT + (NG) - 1) / (NG);                                                                    \
+        _Pragma("unroll") for (int pp = 0; pp < ppg; ++pp)                                                               \
+          if ((g - (G0)) * ppg + pp < N_IT) D3D_QSTAGE_ONE(nst, (KT) + 1, (g - (G0)) * ppg + pp);                        \
+      }                                                                                                                  \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
         acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                        \
         acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
@@ -433,33 +490,108 @@ __global__ __launch_bounds__(512) void k_linear_x3q(const _Float16* __restrict__
   } while (0)
 
   int kt = 0;
-  for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true);
-  D3D_QKTILE(kt, false);
+  if (SCHED == 0) {
+    for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true, 0, TM);
+    D3D_QKTILE(kt, false, 0, TM);
+  } else {
+    // SCHED 1: software pipeline ACROSS the k-tile barrier.  The barrier of k-tile k sits before its LAST MFMA group;
+    // behind it the W fragments (refreshed in place, register by register, as the last group's MFMAs retire them) and
+    // the first A fragment of k-tile k+1 are read and the DMA of k-tile k+2 is issued, all under the last group's MFMAs.
+    // So no wave ever waits for a burst of fragment reads right after a barrier, and a DMA has a whole k-tile to land.
+    h8 bh[4], bl[4], ah[2], al[2];
+    __syncthreads();                                            // DMA(0) landed
+    if (nk > 1) {
+#pragma unroll
+      for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(1, 1, it);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bh[j] = *reinterpret_cast<const h8*>(lds + boff + j * 2048);
+      bl[j] = *reinterpret_cast<const h8*>(lds + ((boff + j * 2048) ^ 64));
+    }
+    ah[0] = *reinterpret_cast<const h8*>(lds + aoff);
+    al[0] = *reinterpret_cast<const h8*>(lds + (aoff ^ 64));
+#define D3D_PKTILE(KT, DMA2, NEXT)                                                                                       \
+  do {                                                                                                                   \
+    const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                  \
+    const unsigned char* sn = lds + (((KT) + 1) & 1) * STAGE;                                                            \
+    _Pragma("unroll") for (int g = 0; g + 1 < TM; ++g) {                                                                 \
+      ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                        \
+      al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                        \
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
+      }                                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }                                                                                                                    \
+    __syncthreads(); /* DMA(k+1) landed everywhere; stage k is in registers everywhere */                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+      constexpr int g = TM - 1;                                                                                          \
+      acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                          \
+      acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                          \
+      acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                          \
+      if (NEXT) {                                                                                                        \
+        bh[j] = *reinterpret_cast<const h8*>(sn + boff + j * 2048);                                                      \
+        bl[j] = *reinterpret_cast<const h8*>(sn + ((boff + j * 2048) ^ 64));                                             \
+      }                                                                                                                  \
+      if (DMA2) {                                                                                                        \
+        _Pragma("unroll") for (int it = j * (N_IT / 4); it < (j + 1) * (N_IT / 4); ++it)                                 \
+          D3D_QSTAGE_ONE((KT) & 1, (KT) + 2, it);                                                                        \
+      }                                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }                                                                                                                    \
+    if (NEXT) {                                                                                                          \
+      ah[0] = *reinterpret_cast<const h8*>(sn + aoff);                                                                   \
+      al[0] = *reinterpret_cast<const h8*>(sn + (aoff ^ 64));                                                            \
+    }                                                                                                                    \
+  } while (0)
+    static_assert(TM % 2 == 0 && N_IT % 4 == 0, "fragment slot parity / DMA split");
+    for (; kt + 2 < nk; ++kt) D3D_PKTILE(kt, true, true);
+    if (kt + 1 < nk) {
+      D3D_PKTILE(kt, false, true);
+      ++kt;
+    }
+    D3D_PKTILE(kt, false, false);
+#undef D3D_PKTILE
+  }
 #undef D3D_QKTILE
 #undef D3D_QSTAGE_ONE
 
-  const int mt0 = m0 + wm * 128, nt0 = n0 + wn * 64;          // wave-uniform
+  const int mt0 = m0 + wm * 16 * TM, nt0 = n0 + wn * 64;          // wave-uniform
   const size_t tbase = (size_t)mt0 * N + nt0;
   const float* Rt = R ? R + tbase : nullptr;
   float* Ct = C ? C + tbase : nullptr;
   _Float16* Cht = Ch ? Ch + (OUTSPLIT == 2 ? 2 * tbase : tbase) : nullptr;
   _Float16* Clt = Cl ? Cl + tbase : nullptr;
-  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+  unsigned long long st_c1 = 0, st_r1 = 0;
+  if (diag) { st_c1 = __builtin_amdgcn_s_memtime(); st_r1 = __builtin_amdgcn_s_memrealtime(); }
   float* patch = reinterpret_cast<float*>(lds) + wave * (2 * 16 * 64);
   if (m0 + BM <= M && n0 + BN <= N)
-    x3q_epilogue<EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
+    x3q_epilogue<TM, EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
   else
-    x3q_epilogue<EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
+    x3q_epilogue<TM, EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
+  if (diag) {
+    __builtin_amdgcn_s_waitcnt(0);   // the wave's own stores issued and acknowledged
+    const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* d = diag + ((size_t)bid * NW + wave) * 6;
+      d[0] = st_c0; d[1] = st_r0; d[2] = st_c1; d[3] = st_r1; d[4] = c2; d[5] = r2;
+    }
+  }
 }
 
+template <int TM, int WM, int WN, int SCHED = 0>
 static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
-                             _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s) {
-  const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
+                             _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
+                             size_t lds_extra = 0, unsigned long long* diag = nullptr) {
+  constexpr int BM = 16 * TM * WM, BN = 64 * WN;
+  const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  const size_t lds_bytes = 2 * (size_t)(512 * 128);
+  const size_t lds_bytes = 2 * (size_t)((BM + BN) * 128) + lds_extra;   // lds_extra: occupancy experiments only
 #define D3D_X3Q_LAUNCH(EPI_, OS_)                                                                                         \
   do {                                                                                                                    \
-    auto kfn = k_linear_x3q<EPI_, OS_>;                                                                                   \
+    auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_, SCHED>;                                                                       \
     static bool attr_done = false;                                                                                        \
     if (!attr_done) {                                                                                                     \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -467,12 +599,44 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
       if (ae != hipSuccess) return ae;                                                                                    \
       attr_done = true;                                                                                                   \
     }                                                                                                                     \
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,     \
-                       qcols);                                                                                            \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WM * WN), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles,    \
+                       ntiles, qcols, diag);                                                                           \
   } while (0)
   D3D_X3_DISPATCH(D3D_X3Q_LAUNCH);
 #undef D3D_X3Q_LAUNCH
   return hipGetLastError();
+}
+
+// A problem whose 256x256 tiles do not fill the last round of 256 CUs is split: the leading M-tiles that make whole
+// rounds go to the 256x256 kernel, the remaining rows to 128x128 tiles (two workgroups per CU, a fraction of a round).
+// T=243, B=64: 1033 M-tiles -> 1024 (exactly 8/16/24 rounds for N = 512/1024/1536) + 2240 rows.
+static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
+                                  _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols, int mode,
+                                  hipStream_t s) {
+  constexpr int CUS = 256;
+  const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
+  const long long tiles = (long long)mtiles * ntiles;
+  int m_main = mtiles;
+  if (mode != 1 && N % 256 == 0 && tiles % CUS != 0) {
+    int unit = CUS;                                     // m_main * ntiles must be a multiple of CUS
+    for (int g = ntiles; g > 1 && unit % 2 == 0 && g % 2 == 0; g /= 2) unit /= 2;
+    const int cand = mtiles / unit * unit;
+    const double frac = (double)(tiles % CUS) / CUS;    // how full the last round would be
+    if ((long long)cand * ntiles >= 4 * CUS && frac < 0.6) m_main = cand;
+  }
+  if (N % 256 != 0 || tiles < 4 * CUS) m_main = 0;      // small problems: 128x128 tiles only
+  const int rows_main = m_main < mtiles ? m_main * 256 : M;
+  if (m_main > 0) {
+    hipError_t e = launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, rows_main, N, K, epi, outsplit, qcols, s);
+    if (e != hipSuccess) return e;
+  }
+  if (rows_main < M) {
+    const size_t ro = (size_t)rows_main;
+    return launch_x3q<4, 2, 2>(ap + ro * 2 * K, wp, bias, R ? R + ro * N : nullptr, C ? C + ro * N : nullptr,
+                               ch ? ch + ro * (outsplit == 2 ? 2 * (size_t)N : (size_t)N) : nullptr,
+                               cl ? cl + ro * N : nullptr, M - rows_main, N, K, epi, outsplit, qcols, s);
+  }
+  return hipSuccess;
 }
 
 template <int ABL>
@@ -490,8 +654,14 @@ static hipError_t launch_abl(const _Float16* Ap, const _Float16* Wp, const float
   return hipGetLastError();
 }
 
-// variant: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (32x32x16 MFMA), 13 = 256x256 (16x16x32 MFMA);
-// 4, 5, 6, 14 (+ 16*flags) = timing ablations with wrong results (experiments/gemm_bench.py)
+// Diagnostic stamp buffer for the next variant-13/11 launches (experiments/gemm_bench.py through d3d_op_linear_bench).
+static unsigned long long* g_x3_diag = nullptr;
+void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }
+
+// variant: 0 = auto (16x16x32 MFMA kernels: 256x256 main launch + 128x128 remainder, launch_x3q_auto);
+// experiments/gemm_bench.py only: 13 = 256x256 in one launch (no split); 11 = 13 with the cross-barrier software
+// pipeline; 10 = 128x128 only; 8 = 128x128 at one workgroup per CU; 7 = 256x128 (4 waves);
+// 1 / 2 / 3 = 128x128 / 256x128 / 256x256 on the 32x32x16 MFMA; 4, 5, 6, 14 (+ 16*flags) = timing ablations, wrong results
 hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias, const float* R, float* C, void* Ch, void* Cl,
                              int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % PBK) != 0 || (N % 4) != 0) return hipErrorInvalidValue;
@@ -501,19 +671,16 @@ hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias
   _Float16 *ch = (_Float16*)Ch, *cl = (_Float16*)Cl;
   const int ablate = variant >> 4;
   variant &= 15;
-  if (variant == 0) {
-    // Measured on MI355X (experiments/gemm_bench.py): at M = 264k the 256x256 tile wins for every N in {512,1024,1536}.
-    // Small batches need enough workgroups to fill 256 CUs for several rounds, so fall back to smaller tiles there.
-    auto wgs = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (N % 256 == 0 && wgs(256, 256) >= 1024) variant = 13;
-    else if (N % 128 == 0 && wgs(256, 128) >= 1024) variant = 2;
-    else variant = 1;
-  }
   switch (variant) {
+    case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, 0, s);
+    case 11: return launch_x3q<8, 2, 4, 1>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, g_x3_diag);
+    case 7: return launch_x3q<8, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+    case 8: return launch_x3q<4, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 32 * 1024);
+    case 10: return launch_x3q<4, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+    case 13: return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, g_x3_diag);
     case 1: return launch_tile<128, 128, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 2: return launch_tile<256, 128, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
     case 3: return launch_tile<256, 256, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
-    case 13: return launch_x3q(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
     case 4: return launch_abl<1>(ap, wp, bias, C, M, N, K, ablate, s);
     case 5: return launch_abl<2>(ap, wp, bias, C, M, N, K, ablate, s);
     case 6: return launch_abl<3>(ap, wp, bias, C, M, N, K, ablate, s);

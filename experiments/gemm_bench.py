@@ -9,7 +9,7 @@ from diff3dhpe_amd.engine import op_linear_bench
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 264384
 torch.manual_seed(0)
 shapes = [("qkv", 1536, 512, "none"), ("proj", 512, 512, "residual"), ("fc1", 1024, 512, "gelu"), ("fc2", 512, 1024, "residual")]
-variants = [("f16x3", 3), ("f16x3", 13), ("f16x3", 1), ("f16x3", 2)]
+variants = [("f16x3", int(v)) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["13", "0", "10"])]
 res = {}
 for name, N, K, epi in shapes:
     A = torch.randn(M, K, device="cuda")
