@@ -1,4 +1,4 @@
-// F16X3 token GEMM, pre-split operands ("x3p"/"x3q"): the production GEMM of the F16X3 precision mode.
+// F16X3 token GEMM, pre-split operands ("x3q"): the production GEMM of the F16X3 precision mode.
 //
 //   C[M,N] = epi( A[M,K] . W[N,K]^T + bias[N] )
 //
@@ -23,15 +23,16 @@
 // Two LDS stages; the DMA of k-tile t+1 is issued after the barrier that retires k-tile t-1 and flies under the MFMAs
 // of k-tile t (one barrier per k-tile; __syncthreads() drains the wave's own DMA with vmcnt(0) before the barrier).
 //
-// Tile shapes (BM x BN x 32, waves WM x WN, each wave (BM/WM) x (BN/WN)):
-//   256x256, 2x4 waves of 128x64 (128 accumulator VGPRs, 128 KiB LDS, 1 workgroup/CU)   -- k_linear_x3q, large problems
-//   256x128, 4x2 waves of  64x64                                                         -- k_linear_x3p
-//   128x128, 2x2 waves of  64x64 ( 64 KiB LDS, 2 workgroups/CU)                          -- k_linear_x3p, small problems
+// Products are issued as v_mfma_f32_16x16x32_f16 (one MFMA spans the 32-deep k-tile): measured on MI355X with random
+// fp16 operands (experiments/mfma_ceiling.hip) the chip sustains 1.97 PFLOP/s on this shape against 1.54 PFLOP/s on
+// 32x32x16 (it holds a higher clock).  The weight fragment is the first operand, so an accumulator tile holds C^T:
+// lane -> token m = lane&15, registers -> n = 4*(lane>>4) + reg; fragment read: lane (r16 = lane&15, q = lane>>4) takes
+// 16-byte chunk q (hi) and 4+q (lo) of row r16.
+#include <cstdlib>
 #include "d3d_kernels.h"
 
 namespace d3d {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -39,8 +40,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int PBK = 32;                          // k-tile depth (fp16 elements)
 constexpr float P_OUT_SCALE = 1.0f / 32768.0f;   // 2^-(3+12)
 constexpr float P_A_SCALE = 8.0f;
-
-__device__ __forceinline__ float gelu_erf_p(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // OUTSPLIT: 0 = fp32 C; 1 = hi/lo PLANES of C (two [M][N] fp16 matrices: the temporal attention kernel reads q/k/v
 // that way); 2 = PAIR layout (the consumer is another x3 GEMM).  Both carry 8*c (columns < qcols: 1*c, the q third
@@ -63,66 +62,12 @@ __device__ __forceinline__ void store_split4(const float (&v)[4], float osc, _Fl
   }
 }
 
-// Epilogue of one wave.  The MFMAs are issued with the WEIGHT fragment as the first operand, so an accumulator tile
-// holds C^T: column (lane&31) = token row m, registers = output columns n = 8*(reg>>2) + 4*(lane>>5) + (reg&3).
-// Each 32-row strip of the wave tile is transposed through a wave-private LDS patch (ds_write_b128 of 4 consecutive
-// n per lane, chunk index XOR (row&7) -> conflict-free) and read back row-major, 16 bytes per lane with 8*TNJ lanes per row,
-// so every global store / residual load instruction covers whole 128-byte lines (a store tail of partial lines or of
-// 4-byte-per-lane stores costs more than the transpose).  Addressing is (wave-uniform tile base) + 32-bit offsets.
-template <int TMI, int TNJ, int EPI, int OUTSPLIT, bool CHECK>
-__device__ __forceinline__ void x3p_epilogue(f32x16 (&acc)[TMI][TNJ], float* patch, const float* __restrict__ bias,
-                                             const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0,
-                                             int lane, int M, int N, int qcols) {
-  constexpr int LD = 32 * TNJ;              // floats per patch row; 16-byte chunks XOR-swizzled by (row & 7)
-  constexpr int LPR = 8 * TNJ;              // lanes per row on the read side (one float4 each)
-  constexpr int RPP = 64 / LPR;             // rows per pass
-  constexpr int NPASS = 32 / RPP;
-  const int r = lane & 31, h = lane >> 5;
-  const int rrow = lane / LPR, rc4 = lane % LPR;
-  const int n = nt0 + 4 * rc4;
-  const bool ncol_ok = !CHECK || n < N;
-  float4 b4 = make_float4(0, 0, 0, 0);
-  if (bias && ncol_ok) b4 = *reinterpret_cast<const float4*>(bias + n);
-  const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
-  const int pc = (int)pair_col(4 * rc4);
-#pragma unroll
-  for (int i = 0; i < TMI; ++i) {
-#pragma unroll
-    for (int j = 0; j < TNJ; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(patch + r * LD + (((8 * j + 2 * g + h) ^ (r & 7)) << 2)) =
-            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      const int row = rrow + RPP * p;
-      const float4 a4 = *reinterpret_cast<const float4*>(patch + row * LD + ((rc4 ^ (row & 7)) << 2));
-      const int m = mt0 + 32 * i + row;
-      if (CHECK && (m >= M || !ncol_ok)) continue;
-      const int off = (32 * i + row) * N + 4 * rc4;
-      float v[4] = {a4.x * P_OUT_SCALE + b4.x, a4.y * P_OUT_SCALE + b4.y, a4.z * P_OUT_SCALE + b4.z, a4.w * P_OUT_SCALE + b4.w};
-      if (EPI == EPI_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_p(v[e]);
-      }
-      if (EPI == EPI_RESIDUAL) {
-        const float4 r4 = *reinterpret_cast<const float4*>(Rt + off);
-        v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
-      }
-      if (OUTSPLIT) store_split4<OUTSPLIT>(v, osc, Cht, Clt, off, (32 * i + row) * 2 * N + pc);
-      else *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // one strip at a time
-  }
-}
-
 // Operand tile in LDS: rows of 128 B = 8 chunks of 16 B (0-3 hi, 4-7 lo of the k-tile); physical chunk = c ^ ((row>>1)&7).
 // A 16-lane ds_read_b128 group reads 16 consecutive rows at one logical chunk: row parity picks the half of the 256-byte
 // bank row, (row>>1)&7 permutes the 8 chunks of that half -> 16 distinct 4-bank slots.  The lo chunk of a fragment is
 // the hi chunk's offset XOR 64.
-__device__ __forceinline__ int swzp(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
-// ---- DMA plan shared by both kernels (branch-free): the k-tile of a BM x BN tile is (BM + BN)/8 pieces of 8 rows x
+// ---- DMA plan (branch-free): the k-tile of a BM x BN tile is (BM + BN)/8 pieces of 8 rows x
 // 128 B; wave w moves pieces w, w + NW, ... of A, then of W.  A lane serves row (8 piece + lane/8), LDS slot lane%8,
 // and fetches the source chunk the swizzle assigns to that slot (constant per lane: NW is even, so (row>>1)&7 =
 // 4 (w&1) + lane/16).  Contract: the A buffer holds >= mtiles*BM rows and the W buffer >= ntiles*BN rows
@@ -138,132 +83,6 @@ __device__ __forceinline__ int swzp(int row, int c) { return row * 128 + ((c ^ (
 
 #define D3D_GLDS(SRC, DSTOFF)                                                                                           \
   __builtin_amdgcn_global_load_lds((SRC), (__attribute__((address_space(3))) void*)(uintptr_t)(lds + (DSTOFF)), 16, 0, 0)
-
-template <int BM, int BN, int WM, int WN, int EPI, int OUTSPLIT, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
-                                                             const float* __restrict__ bias, const float* R, float* C,
-                                                             _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
-                                                             int ntiles, int ablate, int qcols) {
-  // ABL / ablate: timing experiments only (wrong results): ABL 1 = no DMA in the k-loop, 2 = no A fragment reads,
-  // 3 = no barrier, 6 = staging + barriers + epilogue only; ablate & 4 = no epilogue
-  constexpr int NW = WM * WN;
-  constexpr int TMI = BM / WM / 32, TNJ = BN / WN / 32;
-  constexpr int A_REG = BM * 128, B_REG = BN * 128, STAGE = A_REG + B_REG;   // bytes
-  constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, N_IT = A_IT + B_IT; // DMA pieces per wave per k-tile
-  static_assert(NW % 2 == 0 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must split evenly over the waves");
-  static_assert(2 * STAGE >= NW * 32 * (32 * TNJ) * 4, "epilogue patches must fit in the operand stages");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int mt = (slot / ntiles) * 8 + xcd;   // the N-tiles of one M-tile run back to back on one XCD (A rows shared in L2)
-  const int nt = slot % ntiles;
-  if (mt >= mtiles) return;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int r = lane & 31, h = lane >> 5;
-
-  D3D_DMA_PLAN(NW, BM);
-#define D3D_STAGE_ONE(ST, KT, IT)                                                                                       \
-  do {                                                                                                                  \
-    if ((IT) < A_IT) D3D_GLDS(srcA + (size_t)(KT) * 64 + (IT) * it_stride, (ST) * STAGE + dstA + (IT) * NW * 1024);       \
-    else D3D_GLDS(srcB + (size_t)(KT) * 64 + ((IT) - A_IT) * it_stride, (ST) * STAGE + dstB + ((IT) - A_IT) * NW * 1024); \
-  } while (0)
-
-  f32x16 acc[TMI][TNJ];
-#pragma unroll
-  for (int i = 0; i < TMI; ++i)
-#pragma unroll
-    for (int j = 0; j < TNJ; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
-
-  const int arow0 = wm * (BM / WM) + r, brow0 = wn * (BN / WN) + r;
-  const int gsw = (r >> 1) & 7;                                // swizzle key of every row this lane reads (rows r + 32 i)
-  const int nk = K / PBK;
-  constexpr int NG = 2 * TMI;                                  // MFMA groups per k-tile: (k-step, m-tile)
-  constexpr int PPG = (N_IT + NG - 1) / NG;                    // DMA pieces issued per group
-#pragma unroll
-  for (int it = 0; it < N_IT; ++it) D3D_STAGE_ONE(0, 0, it);
-  // One k-tile: software pipeline over the NG groups -- the fragments of group g+1 are read from LDS, and one slice of
-  // the NEXT k-tile's DMA is issued, BEFORE the 3*TNJ MFMAs of group g, so LDS latency and DMA issue hide under MFMAs.
-  // The body is branch-free (the last k-tile, which has nothing to prefetch, is peeled) so that it stays one scheduling
-  // region and hipcc emits counted lgkmcnt waits instead of lgkmcnt(0) at block boundaries.
-#define D3D_FRAG(ROW, KSI) ((ROW) * 128 + (((2 * (KSI) + h) ^ gsw) << 4)) /* lane half h feeds k = 16 ks + 8 h .. +7 */
-#define D3D_KTILE(KT, PREFETCH)                                                                                          \
-  do {                                                                                                                   \
-    if (ABL != 3) __syncthreads(); /* own DMA drained (vmcnt(0)) + everyone done reading the other stage */             \
-    const int nst = ((KT) + 1) & 1;                                                                                      \
-    const unsigned char* sA = lds + ((KT) & 1) * STAGE;                                                                  \
-    const unsigned char* sB = sA + A_REG;                                                                                \
-    h8 bh[2][TNJ], bl[2][TNJ], ah[2], al[2];                                                                             \
-    _Pragma("unroll") for (int j = 0; j < TNJ; ++j) {                                                                    \
-      const int ob = D3D_FRAG(brow0 + 32 * j, 0);                                                                        \
-      bh[0][j] = *reinterpret_cast<const h8*>(sB + ob);                                                                  \
-      bl[0][j] = *reinterpret_cast<const h8*>(sB + (ob ^ 64));                                                           \
-    }                                                                                                                    \
-    {                                                                                                                    \
-      const int oa = D3D_FRAG(arow0, 0);                                                                                 \
-      ah[0] = *reinterpret_cast<const h8*>(sA + oa);                                                                     \
-      al[0] = *reinterpret_cast<const h8*>(sA + (oa ^ 64));                                                              \
-    }                                                                                                                    \
-    _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                                     \
-      const int ks = g / TMI, i = g % TMI;                                                                               \
-      if (g + 1 < NG && ((ABL != 2 && ABL != 6) || (KT) == 0)) {                                                         \
-        const int ks2 = (g + 1) / TMI, i2 = (g + 1) % TMI;                                                               \
-        const int oa = D3D_FRAG(arow0 + 32 * i2, ks2);                                                                   \
-        ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sA + oa);                                                         \
-        al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sA + (oa ^ 64));                                                  \
-        if (i2 == 0) {                                                                                                   \
-          _Pragma("unroll") for (int j = 0; j < TNJ; ++j) {                                                              \
-            const int ob = D3D_FRAG(brow0 + 32 * j, ks2);                                                                \
-            bh[ks2 & 1][j] = *reinterpret_cast<const h8*>(sB + ob);                                                      \
-            bl[ks2 & 1][j] = *reinterpret_cast<const h8*>(sB + (ob ^ 64));                                               \
-          }                                                                                                              \
-        }                                                                                                                \
-      }                                                                                                                  \
-      if (PREFETCH && ABL != 1) {                                                                                        \
-        _Pragma("unroll") for (int pp = 0; pp < PPG; ++pp) {                                                             \
-          const int it_ = g * PPG + pp;                                                                                  \
-          if (it_ < N_IT) D3D_STAGE_ONE(nst, (KT) + 1, it_);                                                             \
-        }                                                                                                                \
-      }                                                                                                                  \
-      if (ABL != 6 || (KT) == 0) {                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < TNJ; ++j) { /* operands swapped: accumulator = C^T tile (x3p_epilogue) */ \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks & 1][j], al[g & 1], acc[i][j], 0, 0, 0);              \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks & 1][j], ah[g & 1], acc[i][j], 0, 0, 0);              \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks & 1][j], ah[g & 1], acc[i][j], 0, 0, 0);              \
-        }                                                                                                                \
-      }                                                                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    }                                                                                                                    \
-  } while (0)
-
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) D3D_KTILE(kt, true);
-  D3D_KTILE(kt, false);
-#undef D3D_KTILE
-#undef D3D_FRAG
-#undef D3D_STAGE_ONE
-
-  if ((ablate & 4) && acc[0][0][0] != 12345.678f) return;
-  const int mt0 = m0 + wm * (BM / WM), nt0 = n0 + wn * (BN / WN);          // wave-uniform
-  const size_t tbase = (size_t)mt0 * N + nt0;
-  const float* Rt = R ? R + tbase : nullptr;
-  float* Ct = C ? C + tbase : nullptr;
-  _Float16* Cht = Ch ? Ch + (OUTSPLIT == 2 ? 2 * tbase : tbase) : nullptr;  // nt0 % 32 == 0: pair_col(nt0) = 2 nt0
-  _Float16* Clt = Cl ? Cl + tbase : nullptr;
-  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
-  float* patch = reinterpret_cast<float*>(lds) + wave * (32 * 32 * TNJ);
-  if (m0 + BM <= M && n0 + BN <= N)
-    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
-  else
-    x3p_epilogue<TMI, TNJ, EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
-}
 
 // Launch-time dispatch over (epilogue, output form): the five combinations the engine and the op hooks use.
 #define D3D_X3_DISPATCH(LAUNCH)                                                                                          \
@@ -283,39 +102,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3p(const _Float16* __r
     }                                                                                                                    \
   } while (0)
 
-template <int BM, int BN, int WM, int WN>
-static hipError_t launch_tile(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C,
-                              _Float16* Ch, _Float16* Cl, int M, int N, int K, int epi, int outsplit, int ablate, int qcols,
-                              hipStream_t s) {
-  const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
-  const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  const size_t lds_bytes = 2 * (size_t)(BM + BN) * 128;
-#define D3D_X3P_LAUNCH(EPI_, OS_)                                                                                         \
-  do {                                                                                                                    \
-    auto kfn = k_linear_x3p<BM, BN, WM, WN, EPI_, OS_, 0>;                                                                \
-    static bool attr_done = false;                                                                                        \
-    if (!attr_done) {                                                                                                     \
-      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          (int)lds_bytes);                                                                \
-      if (ae != hipSuccess) return ae;                                                                                    \
-      attr_done = true;                                                                                                   \
-    }                                                                                                                     \
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WM * WN), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles,    \
-                       ntiles, ablate, qcols);                                                                            \
-  } while (0)
-  D3D_X3_DISPATCH(D3D_X3P_LAUNCH);
-#undef D3D_X3P_LAUNCH
-  return hipGetLastError();
-}
-
-// ---- 16x16x32 form ("x3q") -------------------------------------------------------------------------------------------
-// Same algorithm and staging as k_linear_x3p<256,256,2,4>, but the products are issued as v_mfma_f32_16x16x32_f16: one
-// MFMA spans the whole 32-deep k-tile.  Measured on MI355X with random fp16 operands (experiments/mfma_ceiling.hip) the
-// chip sustains 1.97 PFLOP/s on this shape against 1.54 PFLOP/s on 32x32x16 (it holds a higher clock), so the
-// MFMA-bound part of the GEMM gets ~1.28x faster at identical cycle counts.
-// Wave tile 128(m) x 64(n) = 8 x 4 tiles of 16x16 (128 accumulator VGPRs); weight fragment first, so a tile holds C^T:
-// lane -> token m = lane&15, registers -> n = 4*(lane>>4) + reg.  Fragment read: lane (r16 = lane&15, q = lane>>4) takes
-// 16-byte chunk q (hi) and 4+q (lo) of row r16.
 // GELU(x) = x Phi(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), with erfc from Abramowitz & Stegun 7.1.26
 // (erfc(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and a
 // handful of FMAs, branch-free -- the library erff costs about three times as much, and the fc1 epilogue is VALU-bound
@@ -350,15 +136,24 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
   // Residual rows are fetched PF m-tiles (PF * 4 KiB per wave) ahead of their use: vmcnt retires in order, so a load
   // issued right behind the previous m-tile's stores and consumed at once waits for those stores' acknowledgement as well
   // as its own latency (measured: 22 us per 256x256 tile with load-add-store in sequence, against 3.8 us for the plain
-  // store epilogue).
-  constexpr int PF = (EPI == EPI_RESIDUAL) ? (TM < 3 ? TM : 3) : 0;
+  // store epilogue; 12 us with the window).  Touching the tile's lines from inside the last k-tile to pull them into L2
+  // was tried and lost: the 64-line gathers are slower than the window they were meant to shorten.
+  constexpr int PF = (EPI == EPI_RESIDUAL) ? (TM < 4 ? TM : 4) : 0;
+  // Addressing: wave-uniform tile base (SGPR pair) + 32-bit unsigned byte offset per lane, so that a load/store needs one
+  // address VGPR (global_* saddr form) instead of a 64-bit pair -- with 64-bit pairs the 32 row addresses of a wave tile
+  // cost more registers than the residual window.
+  const unsigned ob = (unsigned)(rrow * N + 4 * rc4) * 4u;          // byte offset of this lane's float4 in row rrow
+  const unsigned rstep = (unsigned)N * 16u;                          // 4 rows
+  const char* Rb = reinterpret_cast<const char*>(Rt);
+  char* Cb = reinterpret_cast<char*>(Ct);
   float4 rr[TM][4];
   auto load_res = [&](int i) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = rrow + 4 * p;
       rr[i][p] = make_float4(0, 0, 0, 0);
-      if (!CHECK || (mt0 + 16 * i + row < M && ncol_ok)) rr[i][p] = *reinterpret_cast<const float4*>(Rt + (16 * i + row) * N + 4 * rc4);
+      if (!CHECK || (mt0 + 16 * i + row < M && ncol_ok))
+        rr[i][p] = *reinterpret_cast<const float4*>(Rb + (ob + (unsigned)(4 * i + p) * rstep));
     }
   };
   __builtin_amdgcn_sched_barrier(0);
@@ -377,7 +172,6 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       const float4 a4 = *reinterpret_cast<const float4*>(patch + (i & 1) * 1024 + row * 64 + ((rc4 ^ (row & 7)) << 2));
       const int m = mt0 + 16 * i + row;
       if (CHECK && (m >= M || !ncol_ok)) continue;
-      const int off = (16 * i + row) * N + 4 * rc4;
       float v[4] = {a4.x * P_OUT_SCALE + b4.x, a4.y * P_OUT_SCALE + b4.y, a4.z * P_OUT_SCALE + b4.z, a4.w * P_OUT_SCALE + b4.w};
       if (EPI == EPI_GELU) {
 #pragma unroll
@@ -387,25 +181,32 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
         const float4 r4 = rr[i][p];
         v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
       }
-      if (OUTSPLIT) store_split4<OUTSPLIT>(v, osc, Cht, Clt, off, (16 * i + row) * 2 * N + pc);
-      else *reinterpret_cast<float4*>(Ct + off) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (i & 1) {   // two m-tiles (two patches) in flight at a time; their accumulators are dead: refill the residual window
-      if (EPI == EPI_RESIDUAL) {
-        if (i - 1 + PF < TM) load_res(i - 1 + PF);
-        if (i + PF < TM) load_res(i + PF);
+      if (OUTSPLIT) {
+        const int off = (16 * i + row) * N + 4 * rc4;
+        store_split4<OUTSPLIT>(v, osc, Cht, Clt, off, (16 * i + row) * 2 * N + pc);
+      } else {
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(4 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
       }
+    }
+    if (EPI == EPI_RESIDUAL) {   // this m-tile's accumulators and residual registers are dead: refill the residual window
+      if (i + PF < TM) load_res(i + PF);
       __builtin_amdgcn_sched_barrier(0);
+    } else if (i & 1) {
+      __builtin_amdgcn_sched_barrier(0);   // two m-tiles (two patches) in flight at a time
     }
   }
 }
 
 // Tile shapes: BM = 16*TM*WM rows, BN = 64*WN columns, WM x WN waves, each wave (16 TM) x 64 = TM x 4 MFMA tiles.
-//   <8,2,4> 256x256, 8 waves, 128 KiB LDS, 1 workgroup/CU  -- the main launch
-//   <4,2,2> 128x128, 4 waves,  64 KiB LDS, 2 workgroups/CU -- remainder rows and small problems
-// Every shape adds the same MFMA results in the same order into an output element, so an element's value does not
-// depend on which tile shape (or which launch of a split problem) produced it.
-template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int SCHED>
+//   <8,2,4> 256x256, 8 waves of 128x64, 128 KiB LDS  -- large problems
+//   <4,4,2> 256x128, 8 waves of  64x64,  96 KiB LDS  -- problems too small to fill the chip with 256x256 tiles
+// Both put ONE 8-wave workgroup on a CU.  Every shape adds the same MFMA results in the same order into an output element,
+// so an element's value does not depend on the tile shape that produced it (results are batch-size independent, bitwise).
+// Shapes with 4-wave workgroups (<4,2,2>, <8,2,2>) or two workgroups per CU (<2,4,2>, <4,2,2>) stay instantiable for
+// experiments/gemm_bench.py but are NOT used: with two processes sharing the GPU they gave run-to-run differences in
+// 1 of ~1000 launches (experiments/two_rank_repeat.sh; also with kernels serialised, so a race inside the launch), while
+// both 8-wave one-per-CU shapes were bit-stable in every run; cause not found.
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT>
 __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                                              const float* __restrict__ bias, const float* R, float* C,
                                                              _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
@@ -413,6 +214,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
   constexpr int A_REG = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, N_IT = A_IT + B_IT;   // 1-KiB DMA pieces per wave per k-tile
+  constexpr int PPG = (N_IT + TM - 1) / TM;                                   // pieces issued per MFMA group
   static_assert(NW % 2 == 0 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must split evenly over the waves");
   static_assert(2 * STAGE >= NW * 2 * 16 * 64 * 4, "epilogue patches must fit in the operand stages");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -458,7 +260,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
 
   // one k-tile = TM groups (one 16-row m-tile each): the A fragments of group g+1 are read, and PPG DMA pieces of the
   // next k-tile are issued, before the 12 MFMAs of group g; the 8 W fragments are read once at the top of the k-tile.
-#define D3D_QKTILE(KT, PREFETCH, G0, NG)                                                                                 \
+#define D3D_QKTILE(KT, PREFETCH)                                                                                         \
   do {                                                                                                                   \
     __syncthreads();                                                                                                     \
     const int nst = ((KT) + 1) & 1;                                                                                      \
@@ -475,10 +277,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
         ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                      \
         al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                             \
       }                                                                                                                  \
-      if (PREFETCH && g >= (G0) && g < (G0) + (NG)) {                                                                    \
-        constexpr int ppg = (N_IT + (NG) - 1) / (NG);                                                                    \
-        _Pragma("unroll") for (int pp = 0; pp < ppg; ++pp)                                                               \
-          if ((g - (G0)) * ppg + pp < N_IT) D3D_QSTAGE_ONE(nst, (KT) + 1, (g - (G0)) * ppg + pp);                        \
+      if (PREFETCH) {                                                                                                    \
+        _Pragma("unroll") for (int pp = 0; pp < PPG; ++pp)                                                               \
+          if (g * PPG + pp < N_IT) D3D_QSTAGE_ONE(nst, (KT) + 1, g * PPG + pp);                                          \
       }                                                                                                                  \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
         acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                        \
@@ -490,71 +291,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   } while (0)
 
   int kt = 0;
-  if (SCHED == 0) {
-    for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true, 0, TM);
-    D3D_QKTILE(kt, false, 0, TM);
-  } else {
-    // SCHED 1: software pipeline ACROSS the k-tile barrier.  The barrier of k-tile k sits before its LAST MFMA group;
-    // behind it the W fragments (refreshed in place, register by register, as the last group's MFMAs retire them) and
-    // the first A fragment of k-tile k+1 are read and the DMA of k-tile k+2 is issued, all under the last group's MFMAs.
-    // So no wave ever waits for a burst of fragment reads right after a barrier, and a DMA has a whole k-tile to land.
-    h8 bh[4], bl[4], ah[2], al[2];
-    __syncthreads();                                            // DMA(0) landed
-    if (nk > 1) {
-#pragma unroll
-      for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(1, 1, it);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bh[j] = *reinterpret_cast<const h8*>(lds + boff + j * 2048);
-      bl[j] = *reinterpret_cast<const h8*>(lds + ((boff + j * 2048) ^ 64));
-    }
-    ah[0] = *reinterpret_cast<const h8*>(lds + aoff);
-    al[0] = *reinterpret_cast<const h8*>(lds + (aoff ^ 64));
-#define D3D_PKTILE(KT, DMA2, NEXT)                                                                                       \
-  do {                                                                                                                   \
-    const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                  \
-    const unsigned char* sn = lds + (((KT) + 1) & 1) * STAGE;                                                            \
-    _Pragma("unroll") for (int g = 0; g + 1 < TM; ++g) {                                                                 \
-      ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                        \
-      al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
-        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                        \
-        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
-        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
-      }                                                                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    }                                                                                                                    \
-    __syncthreads(); /* DMA(k+1) landed everywhere; stage k is in registers everywhere */                               \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
-      constexpr int g = TM - 1;                                                                                          \
-      acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                          \
-      acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                          \
-      acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                          \
-      if (NEXT) {                                                                                                        \
-        bh[j] = *reinterpret_cast<const h8*>(sn + boff + j * 2048);                                                      \
-        bl[j] = *reinterpret_cast<const h8*>(sn + ((boff + j * 2048) ^ 64));                                             \
-      }                                                                                                                  \
-      if (DMA2) {                                                                                                        \
-        _Pragma("unroll") for (int it = j * (N_IT / 4); it < (j + 1) * (N_IT / 4); ++it)                                 \
-          D3D_QSTAGE_ONE((KT) & 1, (KT) + 2, it);                                                                        \
-      }                                                                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    }                                                                                                                    \
-    if (NEXT) {                                                                                                          \
-      ah[0] = *reinterpret_cast<const h8*>(sn + aoff);                                                                   \
-      al[0] = *reinterpret_cast<const h8*>(sn + (aoff ^ 64));                                                            \
-    }                                                                                                                    \
-  } while (0)
-    static_assert(TM % 2 == 0 && N_IT % 4 == 0, "fragment slot parity / DMA split");
-    for (; kt + 2 < nk; ++kt) D3D_PKTILE(kt, true, true);
-    if (kt + 1 < nk) {
-      D3D_PKTILE(kt, false, true);
-      ++kt;
-    }
-    D3D_PKTILE(kt, false, false);
-#undef D3D_PKTILE
-  }
+  for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true);
+  D3D_QKTILE(kt, false);
 #undef D3D_QKTILE
 #undef D3D_QSTAGE_ONE
 
@@ -581,7 +319,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   }
 }
 
-template <int TM, int WM, int WN, int SCHED = 0>
+template <int TM, int WM, int WN>
 static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
                              _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
                              size_t lds_extra = 0, unsigned long long* diag = nullptr) {
@@ -591,7 +329,7 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   const size_t lds_bytes = 2 * (size_t)((BM + BN) * 128) + lds_extra;   // lds_extra: occupancy experiments only
 #define D3D_X3Q_LAUNCH(EPI_, OS_)                                                                                         \
   do {                                                                                                                    \
-    auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_, SCHED>;                                                                       \
+    auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_>;                                                                       \
     static bool attr_done = false;                                                                                        \
     if (!attr_done) {                                                                                                     \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -607,61 +345,24 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   return hipGetLastError();
 }
 
-// A problem whose 256x256 tiles do not fill the last round of 256 CUs is split: the leading M-tiles that make whole
-// rounds go to the 256x256 kernel, the remaining rows to 128x128 tiles (two workgroups per CU, a fraction of a round).
-// T=243, B=64: 1033 M-tiles -> 1024 (exactly 8/16/24 rounds for N = 512/1024/1536) + 2240 rows.
+// Tile choice: 256x256 wherever it fills the chip for a few rounds, else 256x128.  Splitting off the rows of the last,
+// partly filled round into a small-tile launch was measured and gained nothing (the workgroups of a launch do not run in
+// lock-step rounds: per-tile times spread by +-10 %, and the extra launch costs what it saves).
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
-                                  _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols, int mode,
+                                  _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols,
                                   hipStream_t s) {
-  constexpr int CUS = 256;
-  const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
-  const long long tiles = (long long)mtiles * ntiles;
-  int m_main = mtiles;
-  if (mode != 1 && N % 256 == 0 && tiles % CUS != 0) {
-    int unit = CUS;                                     // m_main * ntiles must be a multiple of CUS
-    for (int g = ntiles; g > 1 && unit % 2 == 0 && g % 2 == 0; g /= 2) unit /= 2;
-    const int cand = mtiles / unit * unit;
-    const double frac = (double)(tiles % CUS) / CUS;    // how full the last round would be
-    if ((long long)cand * ntiles >= 4 * CUS && frac < 0.6) m_main = cand;
-  }
-  if (N % 256 != 0 || tiles < 4 * CUS) m_main = 0;      // small problems: 128x128 tiles only
-  const int rows_main = m_main < mtiles ? m_main * 256 : M;
-  if (m_main > 0) {
-    hipError_t e = launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, rows_main, N, K, epi, outsplit, qcols, s);
-    if (e != hipSuccess) return e;
-  }
-  if (rows_main < M) {
-    const size_t ro = (size_t)rows_main;
-    return launch_x3q<4, 2, 2>(ap + ro * 2 * K, wp, bias, R ? R + ro * N : nullptr, C ? C + ro * N : nullptr,
-                               ch ? ch + ro * (outsplit == 2 ? 2 * (size_t)N : (size_t)N) : nullptr,
-                               cl ? cl + ro * N : nullptr, M - rows_main, N, K, epi, outsplit, qcols, s);
-  }
-  return hipSuccess;
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if (N % 256 == 0 && tiles >= 4 * 256) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+  return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
 }
 
-template <int ABL>
-static hipError_t launch_abl(const _Float16* Ap, const _Float16* Wp, const float* bias, float* C, int M, int N, int K, int ablate,
-                             hipStream_t s) {
-  constexpr int BM = 256, BN = 256;
-  const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
-  const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  const size_t lds_bytes = 2 * (size_t)(BM + BN) * 128;
-  auto kfn = k_linear_x3p<256, 256, 2, 4, EPI_NONE, 0, ABL>;
-  hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (ae != hipSuccess) return ae;
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ap, Wp, bias, nullptr, C, nullptr, nullptr, M, N, K, mtiles,
-                     ntiles, ablate, 0);
-  return hipGetLastError();
-}
-
-// Diagnostic stamp buffer for the next variant-13/11 launches (experiments/gemm_bench.py through d3d_op_linear_bench).
+// Diagnostic stamp buffer for the next variant-13 launches (experiments/gemm_bench.py through d3d_op_linear_bench).
 static unsigned long long* g_x3_diag = nullptr;
 void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }
 
-// variant: 0 = auto (16x16x32 MFMA kernels: 256x256 main launch + 128x128 remainder, launch_x3q_auto);
-// experiments/gemm_bench.py only: 13 = 256x256 in one launch (no split); 11 = 13 with the cross-barrier software
-// pipeline; 10 = 128x128 only; 8 = 128x128 at one workgroup per CU; 7 = 256x128 (4 waves);
-// 1 / 2 / 3 = 128x128 / 256x128 / 256x256 on the 32x32x16 MFMA; 4, 5, 6, 14 (+ 16*flags) = timing ablations, wrong results
+// variant: 0 = auto (launch_x3q_auto).  experiments only (gemm_bench.py, two_rank_repeat.sh via D3D_X3_VARIANT):
+// 13 = 256x256, 4 = 256x128 (8 waves), 5 = 128x128 (8 waves, 2/CU), 7 = 256x128 (4 waves), 10 = 128x128 (4 waves, 2/CU),
+// 8 = 10 at one workgroup per CU
 hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias, const float* R, float* C, void* Ch, void* Cl,
                              int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % PBK) != 0 || (N % 4) != 0) return hipErrorInvalidValue;
@@ -669,22 +370,18 @@ hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias
   if (outsplit == 0 ? !C : outsplit == 1 ? (!Ch || !Cl) : (!Ch || (N % 32) != 0)) return hipErrorInvalidValue;
   const _Float16 *ap = (const _Float16*)Ap_, *wp = (const _Float16*)Wp_;
   _Float16 *ch = (_Float16*)Ch, *cl = (_Float16*)Cl;
-  const int ablate = variant >> 4;
-  variant &= 15;
+  if (variant == 0) {
+    static const char* ov = getenv("D3D_X3_VARIANT");   // experiments only
+    if (ov) variant = atoi(ov);
+  }
   switch (variant) {
-    case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, 0, s);
-    case 11: return launch_x3q<8, 2, 4, 1>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, g_x3_diag);
+    case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+    case 13: return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, g_x3_diag);
+    case 4: return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+    case 5: return launch_x3q<2, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
     case 7: return launch_x3q<8, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
     case 8: return launch_x3q<4, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 32 * 1024);
     case 10: return launch_x3q<4, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
-    case 13: return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, g_x3_diag);
-    case 1: return launch_tile<128, 128, 2, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
-    case 2: return launch_tile<256, 128, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
-    case 3: return launch_tile<256, 256, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, ablate, qcols, s);
-    case 4: return launch_abl<1>(ap, wp, bias, C, M, N, K, ablate, s);
-    case 5: return launch_abl<2>(ap, wp, bias, C, M, N, K, ablate, s);
-    case 6: return launch_abl<3>(ap, wp, bias, C, M, N, K, ablate, s);
-    case 14: return launch_abl<6>(ap, wp, bias, C, M, N, K, ablate, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -173,6 +173,27 @@ def test_batch_independence_sharding_and_determinism(prec):
     assert full.abs().max().item() <= 1.0 and torch.isfinite(full).all()
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_result_does_not_depend_on_workspace_contents(prec):
+    """The caller-owned workspace arrives uninitialised (the GEMM stages the padding rows of its edge tiles, which no
+    kernel ever writes): NaN / Inf / random bit patterns in it must not change a single output bit."""
+    cfg = cfg_full(27)
+    _, diff = build_product(cfg, 8, sampling=3, precision=prec)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = diff._engine(dev)
+    inp = inputs(3, 27, 42)                  # M = 1377 rows: ragged against every tile height
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    ws = eng._workspace(3)
+    ws.zero_()
+    ref = eng.ddim_sample(x2d, nz).clone()
+    for fill in (lambda: ws.fill_(0xFF), lambda: ws.fill_(0x7C),
+                 lambda: ws.copy_(torch.randint(0, 256, ws.shape, dtype=torch.uint8, device=dev))):
+        fill()
+        out = eng.ddim_sample(x2d, nz)
+        assert torch.equal(out, ref)
+    assert torch.isfinite(ref).all()
+
+
 def test_engine_matches_oracle_on_fresh_seeded_inputs():
     """HIP path vs the CPU oracle on inputs no fixture holds (small enough for the oracle to finish in seconds)."""
     from oracle import d3d_oracle as orc
