@@ -290,8 +290,9 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
-    // F16X3 temporal blocks: the qkv GEMM hands q/k/v to the fp16-MFMA attention kernel as hi/lo planes
-    const bool attn_x3 = x3 && temporal && attn_temporal_x3_ok(T, D, e->H);
+    // F16X3: the qkv GEMM hands q/k/v to the fp16-MFMA attention kernel as hi/lo planes.  A spatial block is the same
+    // kernel over groups of J consecutive tokens (one "joint", "frames" = the J tokens of a frame, B*T "batches").
+    const bool attn_x3 = x3 && attn_temporal_x3_ok(temporal ? T : J, D, e->H);
     uint16_t* QKVh = reinterpret_cast<uint16_t*>(w.QKV);
     uint16_t* QKVl = QKVh + (size_t)M * 3 * D;
     qcols_ = attn_x3 ? D : 0;
@@ -302,7 +303,8 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
       const int N = temporal ? T : J;
       Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
       if (attn_x3) {
-        HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, HNx, B, T, J, D, e->H, s));
+        if (temporal) HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, HNx, B, T, J, D, e->H, s));
+        else HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, HNx, B * T, J, 1, D, e->H, s));
       } else {
         int rc = attention(e, w.QKV, w.HN, x3 ? HNx : nullptr, B, temporal, s);
         if (rc) return rc;

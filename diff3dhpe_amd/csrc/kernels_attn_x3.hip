@@ -16,6 +16,7 @@
 #include "d3d_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace d3d {
 
@@ -30,23 +31,33 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((c
 __device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
 typedef short s4v __attribute__((ext_vector_type(4)));
 
-template <int NKT>
-__global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
-                                                               _Float16* __restrict__ out_x3,
-                                                               int T, int J, int H, int D) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+// MU > 1 (only with NKT == 1, i.e. groups of <= 32 tokens: the spatial blocks): one workgroup carries MU independent
+// (group, head) units, one per wave, each in its own LDS slice -- a 64-thread workgroup per unit is bound by the
+// workgroup launch rate (124k launches per call at T=243, B=64), not by HBM.
+template <int NKT, int MU>
+__global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
+                                                                    _Float16* __restrict__ out_x3,
+                                                                    int T, int J, int H, int D, int units) {
+  static_assert(MU == 1 || NKT == 1, "several units per workgroup only for single-tile groups");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   constexpr int TP = 32 * NKT;
+  const int lane = threadIdx.x & 63;
+  const int sub = (MU > 1) ? (int)(threadIdx.x >> 6) : 0;          // unit of this workgroup
+  const int wave = (MU > 1) ? 0 : (int)(threadIdx.x >> 6);         // 32-query tile of the unit
+  const int tid = (MU > 1) ? lane : (int)threadIdx.x;              // thread index within the unit
+  unsigned char* const lds = lds_all + sub * (4 * TP * 128);
   unsigned char* const sKh = lds;                     // [TP][128 B]
   unsigned char* const sKl = lds + TP * 128;
   unsigned char* const sVh = lds + 2 * TP * 128;
   unsigned char* const sVl = lds + 3 * TP * 128;
 
-  const int unit = blockIdx.x;                        // (b*J + j)*H + hd
+  const int unit_raw = blockIdx.x * MU + sub;         // (b*J + j)*H + hd
+  const bool unit_ok = unit_raw < units;
+  const int unit = unit_ok ? unit_raw : units - 1;    // surplus waves redo the last unit and store nothing
   const int hd = unit % H;
   const int bj = unit / H;
   const int j = bj % J, b = bj / J;
   const int D3 = 3 * D;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const size_t tok0 = (size_t)b * T * J + j;          // token(t) = tok0 + t*J
 
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
   }
 
   // ---- O = O^T / (2^13 l) - v_query, written as hi/lo planes of 8*o for the proj GEMM
-  if (tq < T) {
+  if (tq < T && unit_ok) {
     const float inv = 1.0f / (8192.0f * l);
     const size_t tokq = tok0 + (size_t)tq * J;
     const size_t vo = tokq * D3 + 2 * D + hd * XDH;
@@ -217,20 +228,21 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3(const _Float16* _
 
 bool attn_temporal_x3_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * XDH; }
 
-template <int NKT>
+template <int NKT, int MU = 1>
 static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D,
                                 int H, hipStream_t s) {
-  const size_t lds_bytes = (size_t)4 * 32 * NKT * 128;   // K_hi, K_lo, V_hi, V_lo planes of TP rows x 128 B
+  const size_t lds_bytes = (size_t)MU * 4 * 32 * NKT * 128;   // per unit: K_hi, K_lo, V_hi, V_lo planes of TP rows x 128 B
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3<NKT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3<NKT, MU>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const long long grid = (long long)B * J * H;
-  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_attn_temporal_x3<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, ox, T, J, H, D);
+  const long long units = (long long)B * J * H;
+  if (units > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_attn_temporal_x3<NKT, MU>), dim3((unsigned)((units + MU - 1) / MU)), dim3(64 * NKT * MU), lds_bytes, s, ph,
+                     pl, ox, T, J, H, D, (int)units);
   return hipGetLastError();
 }
 
@@ -240,7 +252,11 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
   const _Float16 *ph = (const _Float16*)qkv_hi, *pl = (const _Float16*)qkv_lo;
   _Float16* ox = (_Float16*)out_x3;
   switch ((T + 31) / 32) {
-    case 1: return launch_x3_nkt<1>(ph, pl, ox, B, T, J, D, H, s);
+    case 1:   // groups of <= 32 tokens (spatial blocks: the 17 joints of a frame).  8 units per workgroup = the 8 heads of one
+              // frame at H = 8, so a workgroup reads whole token rows; measured 0.61 ms per launch at T=243, B=64 against
+              // 0.82 / 0.68 / 0.69 ms with 1 / 2 / 4 units per workgroup.
+      if ((long long)B * J * H >= 4096) return launch_x3_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
+      return launch_x3_nkt<1, 1>(ph, pl, ox, B, T, J, D, H, s);
     case 2: return launch_x3_nkt<2>(ph, pl, ox, B, T, J, D, H, s);
     case 3: return launch_x3_nkt<3>(ph, pl, ox, B, T, J, D, H, s);
     case 4: return launch_x3_nkt<4>(ph, pl, ox, B, T, J, D, H, s);

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun, from the repo root): every rocprofv3 pass of the default bench workload, each in
+# its own run (kernel trace + stats; FETCH_SIZE; WRITE_SIZE; SQ/GRBM counters -- counters never combined with traces),
+# condensed into profiles/<tag>_*.  Raw output stays under gpurun_out/ (scratch).
+#   profiles/collect.sh r01_f16x3 [bench.py args...]
+set -eo pipefail
+tag=${1:-r01_f16x3}; shift || true
+args="--steps 1 --warmup 1 --no-cpu-baseline $*"
+out=gpurun_out/prof_$tag
+rm -rf $out && mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py $args > $out/stats.log 2>&1
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $args > $out/fetch.log 2>&1
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $args > $out/write.log 2>&1
+echo "write pass done"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv \
+  -d $out/sq -- python3 bench.py $args > $out/sq.log 2>&1
+echo "sq pass done"
+python3 profiles/summarize.py stats $out/stats $out/stats_table.md > /dev/null
+{ echo "rocprofv3 --kernel-trace --stats -- python3 bench.py $args"; echo; cat $out/stats_table.md; } > profiles/${tag}_kernel_stats.md
+python3 profiles/summarize.py pmc $out/fetch $out/write profiles/${tag}_pmc.json "bench.py $args" > /dev/null
+python3 profiles/summarize.py sq $out/sq profiles/${tag}_sq_counters.json > /dev/null
+grep '^{' $out/stats.log | tail -1 > profiles/${tag}_bench_under_rocprof.json || true
+cp profiles/${tag}_* gpurun_out/ 2>/dev/null || true
+cat profiles/${tag}_kernel_stats.md

@@ -3,6 +3,10 @@
 
     python profiles/summarize.py stats  <rocprof_dir> <out.md>        # --kernel-trace --stats run
     python profiles/summarize.py pmc    <fetch_dir> <write_dir> <out.json> [label]   # two --pmc runs (FETCH_SIZE / WRITE_SIZE)
+    python profiles/summarize.py sq     <sq_dir> <out.json>           # one --pmc run of SQ / GRBM counters
+    python profiles/summarize.py traffic <pmc.json> <hbm_traffic.json> <T> <B> <precision>   # per-class bytes for bench.py
+
+profiles/collect.sh runs all the passes on the GPU box and calls these.
 
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
 separate passes (TCC slots), both are in KiB-units of 1024 B... (FETCH_SIZE = TCC_EA0_RDREQ x 64 B reported /1024), and on gfx950
@@ -32,15 +36,32 @@ def demangle(name: str) -> str:
                 break
             except Exception:
                 continue
+        if out.startswith("_Z"):   # c++filt without _Float16 (DF16_) support: recover "name<ints>" from the mangled form
+            m = re.search(r"\d+(k_[A-Za-z0-9_]+?)I((?:Li\d+E)+)E", out)
+            if m:
+                out = "{}<{}>".format(m.group(1), ", ".join(re.findall(r"Li(\d+)E", m.group(2))))
         _DEMANGLE[name] = out
     return _DEMANGLE[name]
+
+
+_EPI = {"0": "EPI_NONE", "1": "EPI_GELU", "2": "EPI_RESIDUAL"}
+_OUT = {"0": "fp32-out", "1": "planes-out", "2": "pair-out"}
 
 
 def short(name: str) -> str:
     name = demangle(name)
     name = re.sub(r"\(.*$", "", name)
-    name = name.replace("void ", "").replace("d3d::", "")
-    return name.strip()[:70]
+    name = name.replace("void ", "").replace("d3d::", "").strip()
+    m = re.match(r"k_linear_x3q<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    if m:   # <TM, WM, WN, EPI, OUTSPLIT> -> tile and role
+        tm, wm, wn, epi, osp = m.groups()
+        role = {("0", "0"): "qkv", ("0", "1"): "qkv", ("2", "0"): "proj, fc2", ("1", "2"): "fc1"}.get((epi, osp), "")
+        return "k_linear_x3q<{}x{}, {}, {}>{}".format(16 * int(tm) * int(wm), 64 * int(wn), _EPI[epi], _OUT[osp],
+                                                     " (" + role + ")" if role else "")
+    m = re.match(r"k_attn_temporal_x3<(\d+), (\d+)>", name)
+    if m:
+        return "k_attn_temporal_x3<{} key tiles, {} units/wg>{}".format(m.group(1), m.group(2), " (spatial blocks)" if m.group(2) != "1" else " (temporal blocks)")
+    return name[:70]
 
 
 def find(dirpath, pattern):
@@ -92,8 +113,48 @@ def pmc(fetch_dir, write_dir, out, label=""):
     print(json.dumps(res, indent=1)[:6000])
 
 
+def sq(dirpath, out):
+    """Sums of every collected counter per kernel over all its launches (SQ_* are in quad-cycles except
+    SQ_VALU_MFMA_BUSY_CYCLES; GRBM_GUI_ACTIVE is summed over the 8 XCDs)."""
+    acc = defaultdict(lambda: defaultdict(float))
+    for f in find(dirpath, "*counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    res = {k: {c: round(v) for c, v in sorted(d.items())} for k, d in acc.items()}
+    for k, d in res.items():
+        if d.get("SQ_BUSY_CU_CYCLES") and d.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            # MFMA pipe busy share of the time a CU had waves: MFMA_BUSY sums the 4 SIMDs of a CU, in the unit of BUSY_CU_CYCLES
+            d["mfma_busy_fraction"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * d["SQ_BUSY_CU_CYCLES"]), 4)
+        if d.get("SQ_WAVE_CYCLES"):
+            d["wave_time_parked_fraction"] = round(d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"], 4)
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1)[:5000])
+
+
+def traffic(pmc_json, traffic_json, T, B, prec):
+    """Mean HBM-side bytes per launch of each bench.py kernel class -> profiles/hbm_traffic.json (read by bench.py)."""
+    k = json.load(open(pmc_json))["kernels"]
+    cls = {"linear": "k_linear", "attn_temporal": "(temporal blocks)", "attn_spatial": "(spatial blocks)", "layernorm": "k_layernorm"}
+    if not any("(spatial blocks)" in n for n in k):
+        cls["attn_spatial"] = "k_attn_spatial"
+        cls["attn_temporal"] = "k_attn_temporal"
+    tj = json.load(open(traffic_json)) if os.path.exists(traffic_json) else {}
+    for c, pat in cls.items():
+        sel = [v for n, v in k.items() if pat in n]
+        n = sum(v["launches"] for v in sel)
+        if n:
+            tj["{}:T{}:B{}:{}".format(c, T, B, prec)] = round(sum(v["hbm_bytes"] * v["launches"] for v in sel) / n)
+    json.dump(tj, open(traffic_json, "w"), indent=1)
+    print(json.dumps(tj, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic":
+        traffic(*sys.argv[2:7])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
