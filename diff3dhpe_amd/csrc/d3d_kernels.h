@@ -34,8 +34,24 @@ void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair
 // outsplit: 0 = fp32 C; 1 = C as two [M][N] fp16 planes Ch/Cl of 8*c (read by the temporal attention kernel);
 // 2 = C in the pair layout at Ch (operand of a following x3p GEMM; N % 32 == 0).  variant 0 = auto tile choice.
 // qcols: with outsplit, columns < qcols carry 1*c instead of 8*c (q third of a temporal qkv GEMM).
+//
+// X3Fold (optional): the LayerNorm-folded / plane-resident forms used by the F16X3 engine path (engine.hip run_blocks):
+//   st_in != null  : A holds the RAW rows x (pair layout of 8x), W holds W*diag(gamma), bias holds b + W beta, csum[n] =
+//                    sum_k W[n,k] gamma[k]; the epilogue forms  LN(x) W^T + b = rstd (x W'^T) - rstd mu csum + b'  with the
+//                    row's mean / rstd from st_in[(m * st_np + p)] = (sum, sum of squares) partials over the K columns
+//   Rp != null     : EPI_RESIDUAL takes the residual from a pair-layout plane buffer [M][2N] of 8r (instead of fp32 R);
+//                    with outsplit == 2 and Ch == Rp the residual stream is updated in place, plane to plane
+//   st_out != null : (with EPI_RESIDUAL) per row and N-tile the (sum, sum of squares) of the new row values go to
+//                    st_out[(m * ntiles + nt)] -- the st_in of the next folded GEMM (st_np = ntiles, see x3q_ntiles())
+struct X3Fold {
+  const float* st_in; int st_np; const float* csum; float eps;
+  const void* Rp;
+  float* st_out;
+};
 hipError_t launch_linear_x3p(const void* Apair, const void* Wpair, const float* bias, const float* R, float* C, void* Ch,
-                             void* Cl, int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s);
+                             void* Cl, int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s,
+                             const X3Fold* fold = nullptr);
+int x3q_ntiles(int M, int N);   // number of N-tiles launch_linear_x3p(variant 0) uses for an (M, N) problem
 hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
 // diagnostic launches (variants 13 / 11): per (workgroup, wave) six u64 stamps {clk, 100 MHz} x {start, k-loop end, end}
 void set_linear_x3_diag(unsigned long long* dev_buf);
@@ -54,6 +70,9 @@ struct LnArgs {
   const float* g2; const float* b2; float eps2;
   const float* pos;  // nullable, (pos_mod, D)
   int pos_div, pos_mod;
+  int skip_ln1;      // 1: y = x (+ pos + tvec) without the first normalisation (entry of block 0)
+  void* y_x3;        // nullable: y also / instead goes out in the F16X3 pair layout (8*y): the plane-resident residual stream
+  float* stats;      // nullable: (sum, sum of squares) of every y row, [rows][2] -- consumed by an LN-folded GEMM (X3Fold)
   const float* tvec; // nullable, per-batch vector (n, D) with row stride tvec_stride (0 = broadcast)
   int64_t tvec_stride;
   int rows_per_batch;

@@ -44,6 +44,10 @@ struct BlockW {
   const float *n1g, *n1b, *qkvw, *qkvb, *projw, *projb, *n2g, *n2b, *fc1w, *fc1b, *fc2w, *fc2b;
   // F16X3 mode: fp16 hi/lo planes of the four GEMM weights (same [N][K] layout)
   const uint16_t *qkv_x3 = nullptr, *proj_x3 = nullptr, *fc1_x3 = nullptr, *fc2_x3 = nullptr;   // F16X3 pair layout
+  // LayerNorm-folded forms (X3Fold, d3d_kernels.h): W diag(gamma) in the pair layout, csum[n] = sum_k W[n,k] gamma[k],
+  // b'[n] = b[n] + sum_k W[n,k] beta[k], for norm1 -> qkv and norm2 -> fc1
+  const uint16_t *qkv_f3 = nullptr, *fc1_f3 = nullptr;
+  const float *qkv_cs = nullptr, *qkv_fb = nullptr, *fc1_cs = nullptr, *fc1_fb = nullptr;
 };
 
 }  // namespace
@@ -60,6 +64,7 @@ struct d3d_engine {
   float* arena = nullptr;  // all weights, device
   size_t arena_floats = 0;
   uint16_t* arena16 = nullptr;  // F16X3: hi/lo planes of the GEMM weights
+  float* arena_fold = nullptr;  // F16X3: csum / folded bias vectors of the LN-folded GEMMs
   std::vector<BlockW> blk;  // execution order: STE0, TTE0, STE1, ...
   const float *fus_w = nullptr, *fus_b = nullptr, *spos = nullptr, *tpos = nullptr;
   const float *sn_g = nullptr, *sn_b = nullptr, *tn_g = nullptr, *tn_b = nullptr;
@@ -102,7 +107,7 @@ struct d3d_engine {
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
-    (void)hipFree(arena); (void)hipFree(arena16); (void)hipFree(tblk_w); (void)hipFree(tblk_b); (void)hipFree(freqs_dev);
+    (void)hipFree(arena); (void)hipFree(arena16); (void)hipFree(arena_fold); (void)hipFree(tblk_w); (void)hipFree(tblk_b); (void)hipFree(freqs_dev);
     (void)hipFree(ac_dev); (void)hipFree(somac_dev); (void)hipFree(sqrt_ac_dev); (void)hipFree(temb_sched);
   }
 };
@@ -198,7 +203,7 @@ struct Prof {
 
 // Workspace carve-up (float offsets).  AO (attention output) aliases HN: norm1(x) is dead once the qkv GEMM has run.
 struct Workspace {
-  float *X, *HN, *QKV, *HID, *Y0, *Y1, *TEMB, *TSCR, *RED, *TIMES, *XIN, *NIN, *OUTB;
+  float *X, *HN, *QKV, *HID, *Y0, *Y1, *TEMB, *TSCR, *RED, *TIMES, *XIN, *NIN, *OUTB, *ST1, *ST2;
   size_t total_bytes;
 };
 
@@ -214,14 +219,15 @@ Workspace carve(const d3d_engine* e, int B, void* base) {
   float* b = reinterpret_cast<float*>(base);
   Workspace w{};
   const size_t Mp = (M + 255) / 256 * 256;   // F16X3 operand planes are read in whole 256-row tiles
-  size_t oX = take(M * D), oHN = take(Mp * D), oQKV = take(M * 3 * D), oHID = take(Mp * e->Dm);
+  size_t oX = take(Mp * D), oHN = take(Mp * D), oQKV = take(M * 3 * D), oHID = take(Mp * e->Dm);
   size_t oY0 = take(M * 3), oY1 = take(M * 3);
   size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
   size_t oRED = take((size_t)B * e->J * D), oTI = take((size_t)B + 64);
   size_t oXI = take(M * e->cfg.in_chans), oNI = take(M * 3), oOB = take(M * 3);   // graph-mode staging copies
+  size_t oS1 = take(M * 2), oS2 = take(M * 2 * (size_t)((D + 127) / 128));      // row statistics of the LN-folded GEMMs
   w.X = b + oX; w.HN = b + oHN; w.QKV = b + oQKV; w.HID = b + oHID; w.Y0 = b + oY0; w.Y1 = b + oY1;
   w.TEMB = b + oTE; w.TSCR = b + oTS; w.RED = b + oRED; w.TIMES = b + oTI;
-  w.XIN = b + oXI; w.NIN = b + oNI; w.OUTB = b + oOB;
+  w.XIN = b + oXI; w.NIN = b + oNI; w.OUTB = b + oOB; w.ST1 = b + oS1; w.ST2 = b + oS2;
   w.total_bytes = off * sizeof(float);
   return w;
 }
@@ -249,6 +255,89 @@ int attention(d3d_engine* e, const float* qkv, float* out, void* out_x3, int B, 
   return D3D_OK;
 }
 
+// F16X3 production flow ("plane-resident, LayerNorm-folded"): the residual stream lives in the GEMM operand (pair) layout
+// in w.X, so it is at once the A operand of the qkv / fc1 GEMMs and the residual input of the proj / fc2 epilogues; norm1
+// and norm2 are folded into those two GEMMs (X3Fold), their row statistics coming from the producer of the stream (the
+// post-norm kernel, resp. the proj epilogue).  Per block only ONE stand-alone row kernel remains (post-norm of the fc2
+// output, read as fp32 from w.HN), against two LayerNorm kernels and three extra passes over the stream before.
+// Same op sequence as run_blocks (S2S:222-247, 111-135); leaves the final Temporal_norm output as fp32 in w.X.
+int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast, const float* tvec, int64_t tvec_stride,
+                    int B, const Workspace& w, hipStream_t s) {
+  const int T = e->T, J = e->J, D = e->D;
+  const int M = B * T * J;
+  const double MD4 = (double)M * D * 4.0;
+  uint16_t* XP = reinterpret_cast<uint16_t*>(w.X);      // residual stream, pair layout of 8x
+  uint16_t* AOx = reinterpret_cast<uint16_t*>(w.HN);    // attention output (pair layout); w.HN as fp32 = embed / fc2 output
+  uint16_t* HIDx = reinterpret_cast<uint16_t*>(w.HID);
+  uint16_t* QKVh = reinterpret_cast<uint16_t*>(w.QKV);
+  uint16_t* QKVl = QKVh + (size_t)M * 3 * D;
+  {
+    Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
+    HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.HN, B, T, J, D, e->cfg.in_chans, y_bcast, s));
+  }
+  auto rowk = [&](LnArgs a, int outs) -> hipError_t {
+    Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + outs), s);
+    return launch_layernorm(a, s);
+  };
+  {  // stream entry: planes + row statistics of x (no normalisation)
+    LnArgs a{};
+    a.x = w.HN; a.skip_ln1 = 1; a.y_x3 = XP; a.stats = w.ST1;
+    a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+    HIP_TRY(rowk(a, 1));
+  }
+  const int np2 = x3q_ntiles(M, D);                     // N-tiles of the proj GEMM = statistics partials per row
+  for (int k = 0; k < e->nblk; ++k) {
+    const BlockW& bw = e->blk[k];
+    const bool temporal = (k & 1) != 0;
+    auto gemm = [&](const uint16_t* A, const uint16_t* W, const float* bias, float* C, uint16_t* Ch, uint16_t* Cl, int outsplit,
+                    int N, int K, int epi, int qcols, const X3Fold& f) -> hipError_t {
+      Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s);
+      return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f);
+    };
+    {  // q, k, v planes = norm1(x) Wqkv^T + b   (LayerNorm folded; q third pre-scaled by dh^-0.5)
+      X3Fold f{};
+      f.st_in = w.ST1; f.st_np = 1; f.csum = bw.qkv_cs; f.eps = 1e-6f;
+      HIP_TRY(gemm(XP, bw.qkv_f3, bw.qkv_fb, nullptr, QKVh, QKVl, 1, 3 * D, D, EPI_NONE, D, f));
+    }
+    {
+      const int N = temporal ? T : J;
+      Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
+      if (temporal) HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, AOx, B, T, J, D, e->H, s));
+      else HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, AOx, B * T, J, 1, D, e->H, s));
+    }
+    {  // x += attn Wproj^T + b, plane to plane in place; row statistics of the new x for the folded norm2
+      X3Fold f{};
+      f.Rp = XP; f.st_out = w.ST2;
+      HIP_TRY(gemm(AOx, bw.proj_x3, bw.projb, nullptr, XP, nullptr, 2, D, D, EPI_RESIDUAL, 0, f));
+    }
+    {  // hidden = gelu(norm2(x) W1^T + b1), LayerNorm folded
+      X3Fold f{};
+      f.st_in = w.ST2; f.st_np = np2; f.csum = bw.fc1_cs; f.eps = 1e-6f;
+      HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
+    }
+    {  // x + hidden W2^T + b2 -> fp32 (w.HN) for the post-norm
+      X3Fold f{};
+      f.Rp = XP;
+      HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, w.HN, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
+    }
+    {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector] -> planes + statistics (or fp32 at the end)
+      LnArgs a{};
+      a.x = w.HN;
+      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = 1e-6f;
+      a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+      if (k == 0) { a.pos = e->tpos; a.pos_div = J; a.pos_mod = T; }
+      if (k + 1 < e->nblk) {
+        if (tvec) { a.tvec = tvec + (size_t)(k + 1) * D; a.tvec_stride = tvec_stride; }
+        a.y_x3 = XP; a.stats = w.ST1;
+      } else {
+        a.y = w.X;
+      }
+      HIP_TRY(rowk(a, 1));
+    }
+  }
+  return D3D_OK;
+}
+
 // One denoiser forward up to (not including) the head: leaves the final Temporal_norm output in w.X.
 // tvec: (n, nblk, D) time-embedding table slice or nullptr; tvec_stride = 0 (all rows share entry 0) or nblk*D.
 int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, const float* tvec, int64_t tvec_stride,
@@ -256,6 +345,9 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   const int T = e->T, J = e->J, D = e->D;
   const int M = B * T * J;
   const double MD4 = (double)M * D * 4.0;
+  if (e->cfg.precision == D3D_PREC_F16X3 && attn_temporal_x3_ok(T, D, e->H) && attn_temporal_x3_ok(J, D, e->H) && D % 32 == 0 &&
+      !getenv("D3D_NO_FOLD"))
+    return run_blocks_fold(e, x2d, y, y_bcast, tvec, tvec_stride, B, w, s);
   {
     Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
     HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.X, B, T, J, D, e->cfg.in_chans,
@@ -490,8 +582,14 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     // the LDS-DMA of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
     const size_t D = e->D, Dm = e->Dm;
     auto pad256 = [](size_t n) { return (n + 255) / 256 * 256; };
-    const size_t per_blk = 2 * (pad256(3 * D) * D + pad256(D) * D + pad256(Dm) * D + pad256(D) * Dm);
+    const size_t per_blk = 2 * (2 * pad256(3 * D) * D + pad256(D) * D + 2 * pad256(Dm) * D + pad256(D) * Dm);
     std::vector<uint16_t> host(per_blk * e->nblk, 0);
+    const size_t fold_per_blk = 2 * (3 * D + Dm);
+    std::vector<float> fold(fold_per_blk * e->nblk, 0.f);
+    if (e->arena_fold) { (void)hipFree(e->arena_fold); e->arena_fold = nullptr; }
+    HIP_TRY(hipMalloc(&e->arena_fold, fold.size() * sizeof(float)));
+    size_t fo = 0;
+    std::vector<float> wg;
     if (e->arena16) { (void)hipFree(e->arena16); e->arena16 = nullptr; }
     HIP_TRY(hipMalloc(&e->arena16, host.size() * sizeof(uint16_t)));
     size_t o = 0;
@@ -508,8 +606,37 @@ int d3d_engine_commit_weights(d3d_engine* e) {
       pair(p + ".attn.proj.weight", D, D, b.proj_x3);
       pair(p + ".mlp.fc1.weight", Dm, D, b.fc1_x3);
       pair(p + ".mlp.fc2.weight", D, Dm, b.fc2_x3);
+      // LayerNorm folded into the consuming GEMM: LN(x) W^T + b = rstd (x (W diag g)^T) - rstd mean csum + (b + W beta)
+      auto folded = [&](const std::string& wname, const std::string& bname, const std::string& norm, size_t rows, size_t cols,
+                        const uint16_t*& w3, const float*& cs, const float*& fb) {
+        const std::vector<float>& W = e->slots[e->index[wname]].host;
+        const std::vector<float>& bb = e->slots[e->index[bname]].host;
+        const std::vector<float>& g = e->slots[e->index[norm + ".weight"]].host;
+        const std::vector<float>& be = e->slots[e->index[norm + ".bias"]].host;
+        wg.resize(rows * cols);
+        for (size_t r = 0; r < rows; ++r) {
+          double c = 0.0, bsum = (double)bb[r];
+          for (size_t q = 0; q < cols; ++q) {
+            const float wv = W[r * cols + q] * g[q];        // the fp32 product the GEMM operand is split from
+            wg[r * cols + q] = wv;
+            c += (double)wv;
+            bsum += (double)W[r * cols + q] * (double)be[q];
+          }
+          fold[fo + r] = (float)c;
+          fold[fo + rows + r] = (float)bsum;
+        }
+        split_weight_f16x3(wg.data(), rows, cols, host.data() + o);
+        w3 = e->arena16 + o;
+        o += 2 * pad256(rows) * cols;
+        cs = e->arena_fold + fo;
+        fb = e->arena_fold + fo + rows;
+        fo += 2 * rows;
+      };
+      folded(p + ".attn.qkv.weight", p + ".attn.qkv.bias", p + ".norm1", 3 * D, D, b.qkv_f3, b.qkv_cs, b.qkv_fb);
+      folded(p + ".mlp.fc1.weight", p + ".mlp.fc1.bias", p + ".norm2", Dm, D, b.fc1_f3, b.fc1_cs, b.fc1_fb);
     }
     HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->arena_fold, fold.data(), fold.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   e->fus_w = wptr(e, "fusion_layer.weight"); e->fus_b = wptr(e, "fusion_layer.bias");
   e->spos = wptr(e, "Spatial_pos_embed"); e->tpos = wptr(e, "Temporal_pos_embed");

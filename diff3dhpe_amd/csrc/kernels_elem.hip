@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
     const int c = 4 * (lane + 64 * i);
     v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
   }
-  ln_row<NV>(v, D, lane, a.g1, a.b1, a.eps1);
+  if (!a.skip_ln1) ln_row<NV>(v, D, lane, a.g1, a.b1, a.eps1);
   if (a.pos) {  // S2S:238-242 (Temporal_pos_embed is added after Spatial_norm, before the block's time-emb add)
     const float* pr = a.pos + (size_t)((row / a.pos_div) % a.pos_mod) * D;
 #pragma unroll
@@ -105,8 +105,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
       if (c < D) *reinterpret_cast<float4*>(yr + c) = v[i];
     }
   }
+  if (a.y_x3) {   // the residual stream itself as GEMM operand planes (the consuming GEMM folds the LayerNorm, X3Fold)
+    _Float16* yp = reinterpret_cast<_Float16*>(a.y_x3) + (size_t)row * 2 * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) {
+        h4v hi, lo;
+        split4_x3(v[i], hi, lo);
+        *reinterpret_cast<h4v*>(yp + pair_col(c)) = hi;
+        *reinterpret_cast<h4v*>(yp + pair_col(c) + PAIR_LO) = lo;
+      }
+    }
+  }
+  if (a.stats) {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (4 * (lane + 64 * i) < D) {
+        sm += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    sm = wave_sum(sm);
+    sq = wave_sum(sq);
+    if (lane == 0) *reinterpret_cast<float2*>(a.stats + 2 * (size_t)row) = make_float2(sm, sq);
+  }
   if (a.h || a.h_x3) {
-    if (a.y) ln_row<NV>(v, D, lane, a.g2, a.b2, a.eps2);
+    if (a.y || a.y_x3) ln_row<NV>(v, D, lane, a.g2, a.b2, a.eps2);
     if (a.h_x3) {   // F16X3 pair layout: 8 lanes fill one 128-byte line (64 B of hi, 64 B of lo) of the row
       _Float16* hp = reinterpret_cast<_Float16*>(a.h_x3) + (size_t)row * 2 * D;
 #pragma unroll

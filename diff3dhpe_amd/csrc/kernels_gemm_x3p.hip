@@ -119,20 +119,46 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return __builtin_fmaxf(x, 0.0f) - s;
 }
 
-template <int TM, int EPI, int OUTSPLIT, bool CHECK>
-__device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, const float* __restrict__ bias, const float* Rt,
-                                             float* Ct, _Float16* Cht, _Float16* Clt, int mt0, int nt0, int lane, int M, int N,
-                                             int qcols) {
+// FX flags of the folded forms (X3Fold in d3d_kernels.h)
+constexpr int FX_LNF = 1;   // LayerNorm folded into this GEMM: per-row (rstd, -mean rstd) from LDS, csum per column
+constexpr int FX_RP = 2;    // residual from pair-layout planes
+constexpr int FX_SO = 4;    // per-row (sum, sum of squares) of the output rows -> st_out
+
+// sum over the 16 lanes of a DPP row (all 16 lanes get the total): quad xor 1, xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+struct X3Tail {            // per-launch extras of the folded forms (device copy of X3Fold + derived)
+  const float* st_in; int st_np; const float* csum; float eps;
+  const _Float16* Rp;
+  float* st_out;
+};
+
+// lds_x: the workgroup's LDS beyond the operand stages: [BM] float2 row statistics (FX_LNF), then [BM][WN] float2 partials (FX_SO)
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
+__device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
+                                             const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
+                                             const float* __restrict__ csum, int mt0, int nt0, int rbase, int wn, int lane, int M,
+                                             int N, int qcols) {
   // patch: two wave-private 16 rows x 64 floats (alternating, so the LDS round trip of one m-tile overlaps the stores
   // of the previous one), 16-byte chunks XOR-swizzled by (row & 7)
+  constexpr int BM = 16 * TM * WM;
   const int m16 = lane & 15, q4 = lane >> 4;
   const int rrow = lane >> 4, rc4 = lane & 15;         // read side: 16 lanes per row, 4 rows per pass
   const int n = nt0 + 4 * rc4;
   const bool ncol_ok = !CHECK || n < N;
-  float4 b4 = make_float4(0, 0, 0, 0);
+  float4 b4 = make_float4(0, 0, 0, 0), cs4 = make_float4(0, 0, 0, 0);
   if (bias && ncol_ok) b4 = *reinterpret_cast<const float4*>(bias + n);
+  if ((FX & FX_LNF) && ncol_ok) cs4 = *reinterpret_cast<const float4*>(csum + n);
   const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
   const int pc = (int)pair_col(4 * rc4);
+  const float2* srow = reinterpret_cast<const float2*>(lds_x);                 // (rstd, -mean * rstd) per workgroup row
+  float2* spart = reinterpret_cast<float2*>(lds_x + BM * 8);                   // [BM][WN] (sum, sum of squares)
   // Residual rows are fetched PF m-tiles (PF * 4 KiB per wave) ahead of their use: vmcnt retires in order, so a load
   // issued right behind the previous m-tile's stores and consumed at once waits for those stores' acknowledgement as well
   // as its own latency (measured: 22 us per 256x256 tile with load-add-store in sequence, against 3.8 us for the plain
@@ -144,7 +170,9 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
   // cost more registers than the residual window.
   const unsigned ob = (unsigned)(rrow * N + 4 * rc4) * 4u;          // byte offset of this lane's float4 in row rrow
   const unsigned rstep = (unsigned)N * 16u;                          // 4 rows
+  const unsigned obp = (unsigned)(rrow * 2 * N + pc) * 2u;          // same position in a pair-layout buffer (hi; lo 64 B on)
   const char* Rb = reinterpret_cast<const char*>(Rt);
+  const char* Rpb = reinterpret_cast<const char*>(Rpt);
   char* Cb = reinterpret_cast<char*>(Ct);
   float4 rr[TM][4];
   auto load_res = [&](int i) {
@@ -152,8 +180,15 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
     for (int p = 0; p < 4; ++p) {
       const int row = rrow + 4 * p;
       rr[i][p] = make_float4(0, 0, 0, 0);
-      if (!CHECK || (mt0 + 16 * i + row < M && ncol_ok))
-        rr[i][p] = *reinterpret_cast<const float4*>(Rb + (ob + (unsigned)(4 * i + p) * rstep));
+      if (!CHECK || (mt0 + 16 * i + row < M && ncol_ok)) {
+        if (FX & FX_RP) {   // 4 hi + 4 lo fp16 of 8 r, kept packed (same 4 registers as the fp32 form)
+          const float2 hh = *reinterpret_cast<const float2*>(Rpb + (obp + (unsigned)(4 * i + p) * rstep));
+          const float2 ll = *reinterpret_cast<const float2*>(Rpb + (obp + (unsigned)(4 * i + p) * rstep) + 64u);
+          rr[i][p] = make_float4(hh.x, hh.y, ll.x, ll.y);
+        } else {
+          rr[i][p] = *reinterpret_cast<const float4*>(Rb + (ob + (unsigned)(4 * i + p) * rstep));
+        }
+      }
     }
   };
   __builtin_amdgcn_sched_barrier(0);
@@ -171,15 +206,39 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       const int row = rrow + 4 * p;
       const float4 a4 = *reinterpret_cast<const float4*>(patch + (i & 1) * 1024 + row * 64 + ((rc4 ^ (row & 7)) << 2));
       const int m = mt0 + 16 * i + row;
-      if (CHECK && (m >= M || !ncol_ok)) continue;
-      float v[4] = {a4.x * P_OUT_SCALE + b4.x, a4.y * P_OUT_SCALE + b4.y, a4.z * P_OUT_SCALE + b4.z, a4.w * P_OUT_SCALE + b4.w};
+      const bool ok = !CHECK || (m < M && ncol_ok);
+      if (!(FX & FX_SO) && !ok) continue;
+      float v[4];
+      if (FX & FX_LNF) {   // LN(x) W^T + b = rstd (x W'^T) - rstd mean csum + b'
+        const float2 st = srow[rbase + 16 * i + row];
+        v[0] = fmaf(st.x, a4.x * P_OUT_SCALE, fmaf(st.y, cs4.x, b4.x));
+        v[1] = fmaf(st.x, a4.y * P_OUT_SCALE, fmaf(st.y, cs4.y, b4.y));
+        v[2] = fmaf(st.x, a4.z * P_OUT_SCALE, fmaf(st.y, cs4.z, b4.z));
+        v[3] = fmaf(st.x, a4.w * P_OUT_SCALE, fmaf(st.y, cs4.w, b4.w));
+      } else {
+        v[0] = a4.x * P_OUT_SCALE + b4.x; v[1] = a4.y * P_OUT_SCALE + b4.y;
+        v[2] = a4.z * P_OUT_SCALE + b4.z; v[3] = a4.w * P_OUT_SCALE + b4.w;
+      }
       if (EPI == EPI_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
       }
       if (EPI == EPI_RESIDUAL) {
-        const float4 r4 = rr[i][p];
+        float4 r4 = rr[i][p];
+        if (FX & FX_RP) {
+          const h4 hh = __builtin_bit_cast(h4, make_float2(r4.x, r4.y)), ll = __builtin_bit_cast(h4, make_float2(r4.z, r4.w));
+          r4 = make_float4(((float)hh[0] + (float)ll[0]) * 0.125f, ((float)hh[1] + (float)ll[1]) * 0.125f,
+                           ((float)hh[2] + (float)ll[2]) * 0.125f, ((float)hh[3] + (float)ll[3]) * 0.125f);
+        }
         v[0] = r4.x + v[0]; v[1] = r4.y + v[1]; v[2] = r4.z + v[2]; v[3] = r4.w + v[3];
+      }
+      if (FX & FX_SO) {   // row statistics of the new residual stream for the LayerNorm folded into the next GEMM
+        float sm = ok ? (v[0] + v[1]) + (v[2] + v[3]) : 0.0f;
+        float sq = ok ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.0f;
+        sm = row16_sum(sm);
+        sq = row16_sum(sq);
+        if (rc4 == 0) spart[(rbase + 16 * i + row) * WN + wn] = make_float2(sm, sq);
+        if (!ok) continue;
       }
       if (OUTSPLIT) {
         const int off = (16 * i + row) * N + 4 * rc4;
@@ -206,11 +265,11 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
 // experiments/gemm_bench.py but are NOT used: with two processes sharing the GPU they gave run-to-run differences in
 // 1 of ~1000 launches (experiments/two_rank_repeat.sh; also with kernels serialised, so a race inside the launch), while
 // both 8-wave one-per-CU shapes were bit-stable in every run; cause not found.
-template <int TM, int WM, int WN, int EPI, int OUTSPLIT>
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
 __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                                              const float* __restrict__ bias, const float* R, float* C,
                                                              _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
-                                                             int ntiles, int qcols, unsigned long long* diag) {
+                                                             int ntiles, int qcols, unsigned long long* diag, X3Tail fx) {
   constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
   constexpr int A_REG = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, N_IT = A_IT + B_IT;   // 1-KiB DMA pieces per wave per k-tile
@@ -229,6 +288,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   // epilogue of every workgroup, into a buffer nothing else reads
   unsigned long long st_c0 = 0, st_r0 = 0;
   if (diag) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  unsigned char* const lds_x = lds + 2 * STAGE;   // beyond the operand stages (allocated only for the folded forms)
+  if (FX & FX_LNF) {   // row statistics of the LayerNorm folded into this GEMM; visible after the first k-tile barrier
+    if ((int)threadIdx.x < BM) {
+      const int row = m0 + (int)threadIdx.x;
+      float sm = 0.f, sq = 0.f;
+      if (row < M)
+        for (int p = 0; p < fx.st_np; ++p) {
+          const float2 t = *reinterpret_cast<const float2*>(fx.st_in + 2 * ((size_t)row * fx.st_np + p));
+          sm += t.x; sq += t.y;
+        }
+      const float mean = sm / (float)K;
+      const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
+      const float rstd = 1.0f / sqrtf(var + fx.eps);
+      reinterpret_cast<float2*>(lds_x)[threadIdx.x] = make_float2(rstd, -mean * rstd);
+    }
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -305,10 +380,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   unsigned long long st_c1 = 0, st_r1 = 0;
   if (diag) { st_c1 = __builtin_amdgcn_s_memtime(); st_r1 = __builtin_amdgcn_s_memrealtime(); }
   float* patch = reinterpret_cast<float*>(lds) + wave * (2 * 16 * 64);
+  const _Float16* Rpt = (FX & FX_RP) ? fx.Rp + 2 * tbase : nullptr;
   if (m0 + BM <= M && n0 + BN <= N)
-    x3q_epilogue<TM, EPI, OUTSPLIT, false>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
+    x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, mt0, nt0,
+                                                      mt0 - m0, wn, lane, M, N, qcols);
   else
-    x3q_epilogue<TM, EPI, OUTSPLIT, true>(acc, patch, bias, Rt, Ct, Cht, Clt, mt0, nt0, lane, M, N, qcols);
+    x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, mt0, nt0,
+                                                     mt0 - m0, wn, lane, M, N, qcols);
+  if (FX & FX_SO) {   // combine the WN column partials of every row in fixed order: (sum, sum of squares) per (row, N-tile)
+    __syncthreads();
+    if ((int)threadIdx.x < BM && m0 + (int)threadIdx.x < M) {
+      const float2* sp = reinterpret_cast<const float2*>(lds_x + BM * 8) + threadIdx.x * WN;
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) { sm += sp[w].x; sq += sp[w].y; }
+      *reinterpret_cast<float2*>(fx.st_out + 2 * ((size_t)(m0 + threadIdx.x) * ntiles + nt)) = make_float2(sm, sq);
+    }
+  }
   if (diag) {
     __builtin_amdgcn_s_waitcnt(0);   // the wave's own stores issued and acknowledged
     const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
@@ -322,14 +410,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
 template <int TM, int WM, int WN>
 static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
                              _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
-                             size_t lds_extra = 0, unsigned long long* diag = nullptr) {
+                             size_t lds_extra = 0, unsigned long long* diag = nullptr, const X3Fold* fold = nullptr) {
   constexpr int BM = 16 * TM * WM, BN = 64 * WN;
   const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  const size_t lds_bytes = 2 * (size_t)((BM + BN) * 128) + lds_extra;   // lds_extra: occupancy experiments only
-#define D3D_X3Q_LAUNCH(EPI_, OS_)                                                                                         \
+  size_t lds_bytes = 2 * (size_t)((BM + BN) * 128) + lds_extra;   // lds_extra: occupancy experiments only
+  X3Tail tail{};
+  int fx = 0;
+  if (fold) {
+    if (fold->st_in) fx |= FX_LNF;
+    if (fold->Rp) fx |= FX_RP;
+    if (fold->st_out) fx |= FX_SO;
+    tail.st_in = fold->st_in; tail.st_np = fold->st_np; tail.csum = fold->csum; tail.eps = fold->eps;
+    tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out;
+    if (fx) lds_bytes += (size_t)BM * 8 * (1 + WN);   // row statistics + column partials beyond the operand stages
+    if ((fx & FX_LNF) && (!fold->csum || fold->st_np < 1)) return hipErrorInvalidValue;
+  }
+#define D3D_X3Q_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
   do {                                                                                                                    \
-    auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_>;                                                                       \
+    auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_, FX_>;                                                                  \
     static bool attr_done = false;                                                                                        \
     if (!attr_done) {                                                                                                     \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -338,22 +437,40 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
       attr_done = true;                                                                                                   \
     }                                                                                                                     \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WM * WN), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles,    \
-                       ntiles, qcols, diag);                                                                           \
+                       ntiles, qcols, diag, tail);                                                                        \
   } while (0)
-  D3D_X3_DISPATCH(D3D_X3Q_LAUNCH);
+#define D3D_X3Q_LAUNCH(EPI_, OS_) D3D_X3Q_LAUNCH_FX(EPI_, OS_, 0)
+  if (fx == 0) {
+    D3D_X3_DISPATCH(D3D_X3Q_LAUNCH);
+  } else if constexpr (WM * WN == 8) {   // folded forms exist for the production (8-wave) shapes only
+    // the four folded forms of the engine's plane-resident block (engine.hip run_blocks)
+    if (fx == FX_LNF && epi == EPI_NONE && outsplit == 1) D3D_X3Q_LAUNCH_FX(EPI_NONE, 1, FX_LNF);                        // qkv
+    else if (fx == (FX_RP | FX_SO) && epi == EPI_RESIDUAL && outsplit == 2) D3D_X3Q_LAUNCH_FX(EPI_RESIDUAL, 2, FX_RP | FX_SO);  // proj
+    else if (fx == FX_LNF && epi == EPI_GELU && outsplit == 2) D3D_X3Q_LAUNCH_FX(EPI_GELU, 2, FX_LNF);                   // fc1
+    else if (fx == FX_RP && epi == EPI_RESIDUAL && outsplit == 0) D3D_X3Q_LAUNCH_FX(EPI_RESIDUAL, 0, FX_RP);             // fc2
+    else return hipErrorInvalidValue;
+  } else {
+    return hipErrorInvalidValue;
+  }
 #undef D3D_X3Q_LAUNCH
+#undef D3D_X3Q_LAUNCH_FX
   return hipGetLastError();
 }
 
 // Tile choice: 256x256 wherever it fills the chip for a few rounds, else 256x128.  Splitting off the rows of the last,
 // partly filled round into a small-tile launch was measured and gained nothing (the workgroups of a launch do not run in
 // lock-step rounds: per-tile times spread by +-10 %, and the extra launch costs what it saves).
+static bool x3q_big(int M, int N) {
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  return N % 256 == 0 && tiles >= 4 * 256;
+}
+int x3q_ntiles(int M, int N) { return x3q_big(M, N) ? (N + 255) / 256 : (N + 127) / 128; }
+
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
                                   _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols,
-                                  hipStream_t s) {
-  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
-  if (N % 256 == 0 && tiles >= 4 * 256) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
-  return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+                                  hipStream_t s, const X3Fold* fold) {
+  if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
+  return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
 }
 
 // Diagnostic stamp buffer for the next variant-13 launches (experiments/gemm_bench.py through d3d_op_linear_bench).
@@ -364,9 +481,11 @@ void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }
 // 13 = 256x256, 4 = 256x128 (8 waves), 5 = 128x128 (8 waves, 2/CU), 7 = 256x128 (4 waves), 10 = 128x128 (4 waves, 2/CU),
 // 8 = 10 at one workgroup per CU
 hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias, const float* R, float* C, void* Ch, void* Cl,
-                             int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s) {
+                             int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s,
+                             const X3Fold* fold) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % PBK) != 0 || (N % 4) != 0) return hipErrorInvalidValue;
-  if (epi == EPI_RESIDUAL && R == nullptr) return hipErrorInvalidValue;
+  if (epi == EPI_RESIDUAL && R == nullptr && !(fold && fold->Rp)) return hipErrorInvalidValue;
+  if (fold && variant != 0) return hipErrorInvalidValue;
   if (outsplit == 0 ? !C : outsplit == 1 ? (!Ch || !Cl) : (!Ch || (N % 32) != 0)) return hipErrorInvalidValue;
   const _Float16 *ap = (const _Float16*)Ap_, *wp = (const _Float16*)Wp_;
   _Float16 *ch = (_Float16*)Ch, *cl = (_Float16*)Cl;
@@ -375,7 +494,7 @@ hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias
     if (ov) variant = atoi(ov);
   }
   switch (variant) {
-    case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+    case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold);
     case 13: return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, g_x3_diag);
     case 4: return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
     case 5: return launch_x3q<2, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
