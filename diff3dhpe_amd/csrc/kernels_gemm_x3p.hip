@@ -265,11 +265,12 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
 // experiments/gemm_bench.py but are NOT used: with two processes sharing the GPU they gave run-to-run differences in
 // 1 of ~1000 launches (experiments/two_rank_repeat.sh; also with kernels serialised, so a race inside the launch), while
 // both 8-wave one-per-CU shapes were bit-stable in every run; cause not found.
+// One output tile (device function: the launch wrappers below map blockIdx to tiles).
 template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
-__global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
-                                                             const float* __restrict__ bias, const float* R, float* C,
-                                                             _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
-                                                             int ntiles, int qcols, unsigned long long* diag, X3Tail fx) {
+__device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
+                                         const float* __restrict__ bias, const float* R, float* C, _Float16* Ch, _Float16* Cl,
+                                         int M, int N, int K, int m0, int n0, int nt, int ntiles, int qcols,
+                                         unsigned long long* diag, const X3Tail& fx) {
   constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
   constexpr int A_REG = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, N_IT = A_IT + B_IT;   // 1-KiB DMA pieces per wave per k-tile
@@ -279,11 +280,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int mt = (slot / ntiles) * 8 + xcd;
-  const int nt = slot % ntiles;
-  if (mt >= mtiles) return;
-  const int m0 = mt * BM, n0 = nt * BN;
   // diag (diagnostic launches only, experiments/gemm_bench.py): shader-clock and 100 MHz stamps around the k-loop and the
   // epilogue of every workgroup, into a buffer nothing else reads
   unsigned long long st_c0 = 0, st_r0 = 0;
@@ -407,6 +403,47 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   }
 }
 
+// Uniform launch: every workgroup one BM x BN tile; blockIdx -> tile keeps all N-tiles of an M-tile on one XCD.
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
+__global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
+                                                             const float* __restrict__ bias, const float* R, float* C,
+                                                             _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
+                                                             int ntiles, int qcols, unsigned long long* diag, X3Tail fx) {
+  constexpr int BM = 16 * TM * WM, BN = 64 * WN;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int mt = (slot / ntiles) * 8 + xcd;
+  const int nt = slot % ntiles;
+  if (mt >= mtiles) return;
+  x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, diag, fx);
+}
+
+// Two-shape launch for large problems: the first mt_big M-tiles (whole rounds of the 256 CUs) as 256x256 tiles, the
+// remaining rows as 64x256 tiles -- same launch, dispatched last, so the partly filled last round of big tiles (a whole
+// tile time for 18 tiles of the proj / fc2 GEMMs at T=243, B=64: 10 % of those launches) shrinks to a round of quarter
+// tiles.  Both shapes run 8 waves on a CU of their own (the launch's LDS size is the big shape's) and produce identical
+// values for an element (same MFMA, same k order).
+template <int EPI, int OUTSPLIT, int FX>
+__global__ __launch_bounds__(512) void k_linear_x3q_mix(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
+                                                        const float* __restrict__ bias, const float* R, float* C, _Float16* Ch,
+                                                        _Float16* Cl, int M, int N, int K, int mt_big, int ntiles, int qcols,
+                                                        unsigned long long* diag, X3Tail fx) {
+  const int bid = blockIdx.x;
+  const int nbig = mt_big * ntiles;
+  if (bid < nbig) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int mt = (slot / ntiles) * 8 + xcd;      // mt_big % 8 == 0
+    const int nt = slot % ntiles;
+    x3q_tile<8, 2, 4, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * 256, nt * 256, nt, ntiles, qcols, diag, fx);
+  } else {
+    const int sid = bid - nbig;
+    const int nt = sid % ntiles;
+    const int m0 = mt_big * 256 + (sid / ntiles) * 64;
+    if (m0 >= M) return;
+    x3q_tile<2, 2, 4, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, m0, nt * 256, nt, ntiles, qcols, diag, fx);
+  }
+}
+
 template <int TM, int WM, int WN>
 static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
                              _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
@@ -457,19 +494,68 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   return hipGetLastError();
 }
 
-// Tile choice: 256x256 wherever it fills the chip for a few rounds, else 256x128.  Splitting off the rows of the last,
-// partly filled round into a small-tile launch was measured and gained nothing (the workgroups of a launch do not run in
-// lock-step rounds: per-tile times spread by +-10 %, and the extra launch costs what it saves).
+// Tile choice: 256x256 (+ 64x256 for the rows of the last partial round, same launch) wherever that fills the chip for a few
+// rounds, else 256x128.  (A SEPARATE small-tile launch for the remainder rows was measured first and gained nothing: the
+// launch gap costs what the shorter tail saves.)
 static bool x3q_big(int M, int N) {
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   return N % 256 == 0 && tiles >= 4 * 256;
 }
 int x3q_ntiles(int M, int N) { return x3q_big(M, N) ? (N + 255) / 256 : (N + 127) / 128; }
 
+// Two-shape launch (k_linear_x3q_mix) for large problems.
+static hipError_t launch_x3q_mix(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
+                                 _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
+                                 const X3Fold* fold) {
+  const int ntiles = N / 256;
+  const int mfull = M / 256;
+  const int mt_big = (int)(((long long)mfull * ntiles / 256 * 256) / ntiles) / 8 * 8;   // whole rounds of 256 CUs, whole XCD groups
+  const int rem_rows = M - mt_big * 256;
+  const long long grid = (long long)mt_big * ntiles + (long long)((rem_rows + 63) / 64) * ntiles;
+  size_t lds_bytes = 2 * (size_t)(512 * 128);
+  X3Tail tail{};
+  int fx = 0;
+  if (fold) {
+    if (fold->st_in) fx |= FX_LNF;
+    if (fold->Rp) fx |= FX_RP;
+    if (fold->st_out) fx |= FX_SO;
+    tail.st_in = fold->st_in; tail.st_np = fold->st_np; tail.csum = fold->csum; tail.eps = fold->eps;
+    tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out;
+    if (fx) lds_bytes += (size_t)256 * 8 * (1 + 4);
+    if ((fx & FX_LNF) && (!fold->csum || fold->st_np < 1)) return hipErrorInvalidValue;
+  }
+#define D3D_X3M_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
+  do {                                                                                                                    \
+    auto kfn = k_linear_x3q_mix<EPI_, OS_, FX_>;                                                                          \
+    static bool attr_done = false;                                                                                        \
+    if (!attr_done) {                                                                                                     \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds_bytes);                                                                \
+      if (ae != hipSuccess) return ae;                                                                                    \
+      attr_done = true;                                                                                                   \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt_big,   \
+                       ntiles, qcols, (unsigned long long*)nullptr, tail);                                                \
+  } while (0)
+#define D3D_X3M_LAUNCH(EPI_, OS_) D3D_X3M_LAUNCH_FX(EPI_, OS_, 0)
+  if (fx == 0) {
+    D3D_X3_DISPATCH(D3D_X3M_LAUNCH);
+  } else {
+    if (fx == FX_LNF && epi == EPI_NONE && outsplit == 1) D3D_X3M_LAUNCH_FX(EPI_NONE, 1, FX_LNF);                        // qkv
+    else if (fx == (FX_RP | FX_SO) && epi == EPI_RESIDUAL && outsplit == 2) D3D_X3M_LAUNCH_FX(EPI_RESIDUAL, 2, FX_RP | FX_SO);  // proj
+    else if (fx == FX_LNF && epi == EPI_GELU && outsplit == 2) D3D_X3M_LAUNCH_FX(EPI_GELU, 2, FX_LNF);                   // fc1
+    else if (fx == FX_RP && epi == EPI_RESIDUAL && outsplit == 0) D3D_X3M_LAUNCH_FX(EPI_RESIDUAL, 0, FX_RP);             // fc2
+    else return hipErrorInvalidValue;
+  }
+#undef D3D_X3M_LAUNCH
+#undef D3D_X3M_LAUNCH_FX
+  return hipGetLastError();
+}
+
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
                                   _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols,
                                   hipStream_t s, const X3Fold* fold) {
-  if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
+  if (x3q_big(M, N)) return launch_x3q_mix(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold);
   return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
 }
 
