@@ -226,6 +226,245 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
   }
 }
 
+// ---- persistent form for multi-wave units (temporal blocks) ----------------------------------------------------------
+// One workgroup per CU walks units u = blockIdx, blockIdx + gridDim, ...; K and V planes are staged by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers; the bank swizzles of kswz / vswz are applied to the per-lane SOURCE
+// chunk, the LDS image stays lane-linear) and the staging of the NEXT unit flies under the arithmetic of the current one:
+//
+//   top barrier    K(u), Q(u) landed (the only operations outstanding); V region free
+//   issue V(u) DMA; store the outputs of unit u-1 (kept packed in registers over the barrier)
+//   S^T = K Q^T, softmax numerators                                   (K from LDS, Q in registers)
+//   barrier        V(u) landed, everybody done with K  ->  issue K(u+1) DMA, load Q(u+1) into the dead Q registers
+//   O^T = V^T E^T, O = O^T / (2^13 l) - v_query                        (V and v_query from LDS)
+//
+// Every wait is a plain vmcnt(0): by construction nothing younger than the data waited for is in flight at a barrier.
+// The non-persistent kernel above serialises load -> compute -> store per workgroup with ONE workgroup per CU (128 KiB of
+// LDS): 0.90 ms per launch at T=243, B=64, of which about 0.15 ms is staging latency nothing overlaps.
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3p(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
+                                                                _Float16* __restrict__ out_x3, int T, int J, int H, int D,
+                                                                int units) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int TP = 32 * NKT;
+  constexpr int PLANE = TP * 128;
+  unsigned char* const sKh = lds;
+  unsigned char* const sKl = lds + PLANE;
+  unsigned char* const sVh = lds + 2 * PLANE;
+  unsigned char* const sVl = lds + 3 * PLANE;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // lane index behind an opaque barrier, refreshed every iteration: all per-lane LDS / global offsets are then re-derived
+  // inside the loop (a few VALU ops) instead of being hoisted out of it and kept in ~80 registers (which spilled)
+  int lane = tid & 63;
+  asm volatile("" : "+v"(lane));
+  int r = lane & 31, h = lane >> 5;
+  const int D3 = 3 * D;
+  int u = blockIdx.x;
+  if (u >= units) return;
+
+  // pad rows [T, TP) of all four planes: zero once, the DMA never writes them (their lanes are masked off)
+  for (int idx = tid; idx < (TP - T) * 8 * 4; idx += 64 * NKT) {
+    const int pl = idx / ((TP - T) * 8), rem = idx % ((TP - T) * 8);
+    *reinterpret_cast<uint4*>(lds + pl * PLANE + (T + (rem >> 3)) * 128 + ((rem & 7) << 4)) = make_uint4(0, 0, 0, 0);
+  }
+
+  // DMA plan: a plane is TP/8 = 4*NKT pieces of 8 rows x 128 B; wave w moves pieces w, w + NKT, w + 2 NKT, w + 3 NKT of each
+  // plane.  Lane l serves row 8*piece + l/8, LDS slot l%8, and fetches the source chunk the swizzle maps to that slot.
+  auto dma = [&](int which, size_t tok0, int hd) {   // which: 1 = K, 2 = V
+    const int drow = lane >> 3, dslot = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int piece = wave + NKT * it;
+      const int row = 8 * piece + drow;
+      const int chunk = (which == 1) ? (dslot ^ ((row >> 1) & 7)) : (dslot ^ (((row >> 1) & 1) << 2));
+      const size_t o = (tok0 + (size_t)row * J) * D3 + (size_t)which * D + hd * XDH + chunk * 8;
+      unsigned char* dh = (which == 1 ? sKh : sVh) + piece * 1024;
+      unsigned char* dl = (which == 1 ? sKl : sVl) + piece * 1024;
+      if (row < T) {
+        __builtin_amdgcn_global_load_lds(Ph + o, (__attribute__((address_space(3))) void*)(uintptr_t)dh, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(Pl + o, (__attribute__((address_space(3))) void*)(uintptr_t)dl, 16, 0, 0);
+      }
+    }
+  };
+  auto unit_of = [&](int uu, int& hd, size_t& tok0) {
+    hd = uu % H;
+    const int bj = uu / H;
+    tok0 = (size_t)(bj / J) * T * J + (bj % J);
+  };
+  h8 qh[4], ql[4];
+  auto load_q = [&](size_t tok0, int hd) {
+    const int tq = 32 * wave + r;
+    const size_t o = (tok0 + (size_t)(tq < T ? tq : 0) * J) * D3 + hd * XDH + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = *reinterpret_cast<const h8*>(Ph + o + 16 * ks);     // rows >= T reuse row 0: their columns are never stored
+      ql[ks] = *reinterpret_cast<const h8*>(Pl + o + 16 * ks);
+    }
+  };
+
+  int hd;
+  size_t tok0;
+  unit_of(u, hd, tok0);
+  dma(1, tok0, hd);
+  load_q(tok0, hd);
+  h4 po_h[8], po_l[8];          // packed outputs of the previous unit, stored one barrier later
+  size_t po_off = 0;
+  bool po_valid = false;
+  int tq = 32 * wave + r;
+
+  for (;;) {
+    __syncthreads();            // K(u), Q(u) landed; V region free
+    asm volatile("" : "+v"(lane));
+    r = lane & 31; h = lane >> 5; tq = 32 * wave + r;
+    dma(2, tok0, hd);
+    if (po_valid && tq < T) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d = dt * 32 + 8 * g4 + 4 * h;
+          *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d)) = po_h[dt * 4 + g4];
+          *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d) + PAIR_LO) = po_l[dt * 4 + g4];
+        }
+    }
+
+    // ---- S^T tiles (rows = keys, column = query tq); acc = 64 * s
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sacc[kt][q] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ko = kswz(kt * 32 + r, 2 * ks + h);
+        const h8 kh = *reinterpret_cast<const h8*>(sKh + ko);
+        const h8 kl = *reinterpret_cast<const h8*>(sKl + ko);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc[kt], 0, 0, 0);
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (kt == NKT - 1) {
+          const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (key >= T) sacc[kt][q] = -INFINITY;
+        }
+        m = fmaxf(m, sacc[kt][q]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    constexpr float C_EXP = 1.4426950408889634f / 64.0f;
+    const float mb = m * C_EXP;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][q], C_EXP, -mb));
+        sacc[kt][q] = e;
+        l += e;
+      }
+    l += __shfl_xor(l, 32, 64);
+
+    __syncthreads();            // V(u) landed (and the stores above acknowledged); everybody is done with K
+    const int un = u + (int)gridDim.x;
+    const bool has_next = un < units;     // workgroup-uniform
+    int hd_n = 0;
+    size_t tok0_n = 0;
+    if (has_next) {
+      unit_of(un, hd_n, tok0_n);
+      dma(1, tok0_n, hd_n);
+    }
+
+    // ---- O^T[d][query] = sum_key V^T[d][key] E^T[key][query]
+    f32x16 oacc[2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { oacc[0][q] = 0.f; oacc[1][q] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        h8 eh, el;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float ev = sacc[kt][8 * s2 + jj] * 1024.0f;
+          const _Float16 hh = (_Float16)ev;
+          eh[jj] = hh;
+          el[jj] = (_Float16)(ev - (float)hh);
+        }
+        const int k0 = kt * 32 + 16 * s2 + 4 * h;
+        const int gi = lane & 15, tq_ = gi >> 2, tp_ = gi & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int d0 = dt * 32 + 16 * ((lane >> 4) & 1);
+          const int ch = (d0 >> 3) + (tp_ >> 1), sub = (tp_ & 1) * 8;
+          const int o0 = vswz(k0 + tq_, ch) + sub, o1 = vswz(k0 + 8 + tq_, ch) + sub;
+          const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVh + o0));
+          const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVh + o1));
+          const s4v c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVl + o0));
+          const s4v c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sVl + o1));
+          h8 vh, vl;
+          {
+            const h4 a0h = __builtin_bit_cast(h4, a0), a1h = __builtin_bit_cast(h4, a1);
+            const h4 c0h = __builtin_bit_cast(h4, c0), c1h = __builtin_bit_cast(h4, c1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vh[e] = a0h[e]; vh[4 + e] = a1h[e]; vl[e] = c0h[e]; vl[4 + e] = c1h[e]; }
+          }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, eh, oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, el, oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, eh, oacc[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the next unit's query fragments go into the dead Q registers once two score tiles have been consumed (register room)
+      if (kt == (NKT > 2 ? 2 : NKT - 1) && has_next) load_q(tok0_n, hd_n);
+    }
+
+    // ---- O = O^T / (2^13 l) - v_query (v_query from the V planes in LDS), packed as hi/lo of 8*o; stored after the next barrier
+    {
+      const float inv = 1.0f / (8192.0f * l);
+      const int tqc = tq < T ? tq : 0;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int vo = vswz(tqc, dt * 4 + g4) + 8 * h;
+          const h4 vqh = *reinterpret_cast<const h4*>(sVh + vo);
+          const h4 vql = *reinterpret_cast<const h4*>(sVl + vo);
+          h4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
+            const float o = oacc[dt][4 * g4 + e] * inv - vq;
+            const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
+            oh[e] = (_Float16)sc;
+            ol[e] = (_Float16)(sc - (float)oh[e]);
+          }
+          po_h[dt * 4 + g4] = oh;
+          po_l[dt * 4 + g4] = ol;
+        }
+      po_off = (tok0 + (size_t)tqc * J) * 2 * D + hd * 2 * XDH;
+      po_valid = true;
+    }
+    if (!has_next) break;
+    u = un; hd = hd_n; tok0 = tok0_n;
+  }
+  // outputs of the last unit
+  if (tq < T) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = dt * 32 + 8 * g4 + 4 * h;
+        *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d)) = po_h[dt * 4 + g4];
+        *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d) + PAIR_LO) = po_l[dt * 4 + g4];
+      }
+  }
+}
+
 bool attn_temporal_x3_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * XDH; }
 
 template <int NKT, int MU = 1>
@@ -246,11 +485,40 @@ static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16
   return hipGetLastError();
 }
 
+template <int NKT>
+static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H,
+                                 hipStream_t s) {
+  const size_t lds_bytes = (size_t)4 * 32 * NKT * 128;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const long long units = (long long)B * J * H;
+  if (units > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;   // resident workgroups per CU
+  const long long grid = units < (long long)n_cu * per_cu ? units : (long long)n_cu * per_cu;
+  hipLaunchKernelGGL(k_attn_temporal_x3p<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, ox, T, J, H, D,
+                     (int)units);
+  return hipGetLastError();
+}
+
 hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_x3, int B, int T, int J,
                                    int D, int H, hipStream_t s) {
   if (!attn_temporal_x3_ok(T, D, H) || !qkv_hi || !qkv_lo || !out_x3) return hipErrorInvalidValue;
   const _Float16 *ph = (const _Float16*)qkv_hi, *pl = (const _Float16*)qkv_lo;
   _Float16* ox = (_Float16*)out_x3;
+  // persistent, DMA-staged form where a launch has several units per CU (instantiated for the frame counts of the
+  // reference configs: T = 81 -> 3 key tiles, T = 243 -> 8)
+  static const bool no_persist = getenv("D3D_ATTN_NO_PERSIST") != nullptr;   // experiments only
+  const bool persist = !no_persist && (long long)B * J * H >= 1024;
   switch ((T + 31) / 32) {
     case 1:   // groups of <= 32 tokens (spatial blocks: the 17 joints of a frame).  8 units per workgroup = the 8 heads of one
               // frame at H = 8, so a workgroup reads whole token rows; measured 0.61 ms per launch at T=243, B=64 against
@@ -258,12 +526,12 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
       if ((long long)B * J * H >= 4096) return launch_x3_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
       return launch_x3_nkt<1, 1>(ph, pl, ox, B, T, J, D, H, s);
     case 2: return launch_x3_nkt<2>(ph, pl, ox, B, T, J, D, H, s);
-    case 3: return launch_x3_nkt<3>(ph, pl, ox, B, T, J, D, H, s);
+    case 3: return (persist ? launch_x3p_nkt<3> : launch_x3_nkt<3, 1>)(ph, pl, ox, B, T, J, D, H, s);
     case 4: return launch_x3_nkt<4>(ph, pl, ox, B, T, J, D, H, s);
     case 5: return launch_x3_nkt<5>(ph, pl, ox, B, T, J, D, H, s);
     case 6: return launch_x3_nkt<6>(ph, pl, ox, B, T, J, D, H, s);
     case 7: return launch_x3_nkt<7>(ph, pl, ox, B, T, J, D, H, s);
-    default: return launch_x3_nkt<8>(ph, pl, ox, B, T, J, D, H, s);
+    default: return (persist ? launch_x3p_nkt<8> : launch_x3_nkt<8, 1>)(ph, pl, ox, B, T, J, D, H, s);
   }
 }
 
