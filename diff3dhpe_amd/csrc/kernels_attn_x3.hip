@@ -240,30 +240,42 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
 // Every wait is a plain vmcnt(0): by construction nothing younger than the data waited for is in flight at a barrier.
 // The non-persistent kernel above serialises load -> compute -> store per workgroup with ONE workgroup per CU (128 KiB of
 // LDS): 0.90 ms per launch at T=243, B=64, of which about 0.15 ms is staging latency nothing overlaps.
-template <int NKT>
-__global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3p(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
-                                                                _Float16* __restrict__ out_x3, int T, int J, int H, int D,
-                                                                int units) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+// MU > 1 (NKT == 1: groups of <= 32 tokens, the spatial blocks): every wave is its own persistent worker on its own LDS
+// slice (units blockIdx * MU + wave, + gridDim * MU, ...); the barriers become wave-local waits, so the MU waves of a
+// workgroup drift apart and their load / MFMA / VALU phases overlap.
+template <int NKT, int MU>
+__global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
+                                                                     _Float16* __restrict__ out_x3, int T, int J, int H, int D,
+                                                                     int units) {
+  static_assert(MU == 1 || NKT == 1, "wave-private units only for single-tile groups");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   constexpr int TP = 32 * NKT;
   constexpr int PLANE = TP * 128;
+  constexpr bool WAVEP = MU > 1;
+  unsigned char* const lds = lds_all + (WAVEP ? (int)(threadIdx.x >> 6) * 4 * PLANE : 0);
+#define D3D_ATTN_SYNC()                                                                     \
+  do {                                                                                      \
+    if (WAVEP) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
+    else __syncthreads();                                                                   \
+  } while (0)
   unsigned char* const sKh = lds;
   unsigned char* const sKl = lds + PLANE;
   unsigned char* const sVh = lds + 2 * PLANE;
   unsigned char* const sVl = lds + 3 * PLANE;
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = WAVEP ? (int)(threadIdx.x & 63) : (int)threadIdx.x;     // thread index within the unit
+  const int wave = WAVEP ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // 32-query tile of the unit
   // lane index behind an opaque barrier, refreshed every iteration: all per-lane LDS / global offsets are then re-derived
   // inside the loop (a few VALU ops) instead of being hoisted out of it and kept in ~80 registers (which spilled)
   int lane = tid & 63;
   asm volatile("" : "+v"(lane));
   int r = lane & 31, h = lane >> 5;
   const int D3 = 3 * D;
-  int u = blockIdx.x;
-  if (u >= units) return;
+  int u = WAVEP ? (int)(blockIdx.x * MU + (threadIdx.x >> 6)) : (int)blockIdx.x;
+  const int ustep = (int)gridDim.x * MU;
+  if (u >= units) return;     // wave-uniform (workgroup-uniform when MU == 1)
 
   // pad rows [T, TP) of all four planes: zero once, the DMA never writes them (their lanes are masked off)
-  for (int idx = tid; idx < (TP - T) * 8 * 4; idx += 64 * NKT) {
+  for (int idx = tid; idx < (TP - T) * 8 * 4; idx += 64 * NKT) {   // (the unit's own threads: 64 * NKT)
     const int pl = idx / ((TP - T) * 8), rem = idx % ((TP - T) * 8);
     *reinterpret_cast<uint4*>(lds + pl * PLANE + (T + (rem >> 3)) * 128 + ((rem & 7) << 4)) = make_uint4(0, 0, 0, 0);
   }
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3p(const _Float16* 
   int tq = 32 * wave + r;
 
   for (;;) {
-    __syncthreads();            // K(u), Q(u) landed; V region free
+    D3D_ATTN_SYNC();            // K(u), Q(u) landed; V region free
     asm volatile("" : "+v"(lane));
     r = lane & 31; h = lane >> 5; tq = 32 * wave + r;
     dma(2, tok0, hd);
@@ -369,8 +381,8 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3p(const _Float16* 
       }
     l += __shfl_xor(l, 32, 64);
 
-    __syncthreads();            // V(u) landed (and the stores above acknowledged); everybody is done with K
-    const int un = u + (int)gridDim.x;
+    D3D_ATTN_SYNC();            // V(u) landed (and the stores above acknowledged); everybody is done with K
+    const int un = u + ustep;
     const bool has_next = un < units;     // workgroup-uniform
     int hd_n = 0;
     size_t tok0_n = 0;
@@ -452,6 +464,7 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3p(const _Float16* 
     if (!has_next) break;
     u = un; hd = hd_n; tok0 = tok0_n;
   }
+#undef D3D_ATTN_SYNC
   // outputs of the last unit
   if (tq < T) {
 #pragma unroll
@@ -485,14 +498,14 @@ static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16
   return hipGetLastError();
 }
 
-template <int NKT>
+template <int NKT, int MU = 1>
 static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H,
                                  hipStream_t s) {
-  const size_t lds_bytes = (size_t)4 * 32 * NKT * 128;
+  const size_t lds_bytes = (size_t)MU * 4 * 32 * NKT * 128;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     int dev = 0;
@@ -504,9 +517,10 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
   const long long units = (long long)B * J * H;
   if (units > 0x7fffffffLL) return hipErrorInvalidValue;
   const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;   // resident workgroups per CU
-  const long long grid = units < (long long)n_cu * per_cu ? units : (long long)n_cu * per_cu;
-  hipLaunchKernelGGL(k_attn_temporal_x3p<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, ox, T, J, H, D,
-                     (int)units);
+  const long long wgs = (units + MU - 1) / MU;
+  const long long grid = wgs < (long long)n_cu * per_cu ? wgs : (long long)n_cu * per_cu;
+  hipLaunchKernelGGL((k_attn_temporal_x3p<NKT, MU>), dim3((unsigned)grid), dim3(64 * NKT * MU), lds_bytes, s, ph, pl, ox, T, J, H,
+                     D, (int)units);
   return hipGetLastError();
 }
 
@@ -523,6 +537,7 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
     case 1:   // groups of <= 32 tokens (spatial blocks: the 17 joints of a frame).  8 units per workgroup = the 8 heads of one
               // frame at H = 8, so a workgroup reads whole token rows; measured 0.61 ms per launch at T=243, B=64 against
               // 0.82 / 0.68 / 0.69 ms with 1 / 2 / 4 units per workgroup.
+      if ((long long)B * J * H >= 4096 && !no_persist) return launch_x3p_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
       if ((long long)B * J * H >= 4096) return launch_x3_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
       return launch_x3_nkt<1, 1>(ph, pl, ox, B, T, J, D, H, s);
     case 2: return launch_x3_nkt<2>(ph, pl, ox, B, T, J, D, H, s);
