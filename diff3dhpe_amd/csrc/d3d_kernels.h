@@ -41,8 +41,8 @@ void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair
 //                    row's mean / rstd from st_in[(m * st_np + p)] = (sum, sum of squares) partials over the K columns
 //   Rp != null     : EPI_RESIDUAL takes the residual from a pair-layout plane buffer [M][2N] of 8r (instead of fp32 R);
 //                    with outsplit == 2 and Ch == Rp the residual stream is updated in place, plane to plane
-//   st_out != null : (with EPI_RESIDUAL) per row and N-tile the (sum, sum of squares) of the new row values go to
-//                    st_out[(m * ntiles + nt)] -- the st_in of the next folded GEMM (st_np = ntiles, see x3q_ntiles())
+//   st_out != null : (with EPI_RESIDUAL) per row and 64-column block the (sum, sum of squares) of the new row values go to
+//                    st_out[(m * (N/64) + block)] -- the st_in of the next folded GEMM (st_np = x3q_ntiles() = N/64)
 struct X3Fold {
   const float* st_in; int st_np; const float* csum; float eps;
   const void* Rp;
@@ -51,7 +51,7 @@ struct X3Fold {
 hipError_t launch_linear_x3p(const void* Apair, const void* Wpair, const float* bias, const float* R, float* C, void* Ch,
                              void* Cl, int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s,
                              const X3Fold* fold = nullptr);
-int x3q_ntiles(int M, int N);   // number of N-tiles launch_linear_x3p(variant 0) uses for an (M, N) problem
+int x3q_ntiles(int M, int N);   // statistics partials per row an st_out launch writes
 hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
 // diagnostic launches (variants 13 / 11): per (workgroup, wave) six u64 stamps {clk, 100 MHz} x {start, k-loop end, end}
 void set_linear_x3_diag(unsigned long long* dev_buf);

@@ -224,7 +224,7 @@ Workspace carve(const d3d_engine* e, int B, void* base) {
   size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
   size_t oRED = take((size_t)B * e->J * D), oTI = take((size_t)B + 64);
   size_t oXI = take(M * e->cfg.in_chans), oNI = take(M * 3), oOB = take(M * 3);   // graph-mode staging copies
-  size_t oS1 = take(M * 2), oS2 = take(M * 2 * (size_t)((D + 127) / 128));      // row statistics of the LN-folded GEMMs
+  size_t oS1 = take(M * 2), oS2 = take(M * 2 * (size_t)((D + 63) / 64));      // row statistics of the LN-folded GEMMs
   w.X = b + oX; w.HN = b + oHN; w.QKV = b + oQKV; w.HID = b + oHID; w.Y0 = b + oY0; w.Y1 = b + oY1;
   w.TEMB = b + oTE; w.TSCR = b + oTS; w.RED = b + oRED; w.TIMES = b + oTI;
   w.XIN = b + oXI; w.NIN = b + oNI; w.OUTB = b + oOB; w.ST1 = b + oS1; w.ST2 = b + oS2;
@@ -285,7 +285,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
     HIP_TRY(rowk(a, 1));
   }
-  const int np2 = x3q_ntiles(M, D);                     // N-tiles of the proj GEMM = statistics partials per row
+  const int np2 = x3q_ntiles(M, D);                     // statistics partials per row written by the proj epilogue
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
