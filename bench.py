@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--seq2frame", action="store_true", help="BASELINE configs[4]: ...S2F... model, (B,1,J,3) targets")
     ap.add_argument("--no-time-emb", action="store_true", help="with_time_emb=False (3DHP command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the bitwise batch-vs-pair check (profiling passes: keeps the kernel tables to the timed workload)")
     a = ap.parse_args()
 
     import torch
@@ -173,9 +174,11 @@ def main():
     prof = eng.profile_read()
     # self-check of the timed configuration (no oracle runs at this size): the first two sequences of the batch, sampled
     # again as a batch of two (the small-problem kernels the golden-vector tests cover), must come out bit-identical
-    pred_big = eng.ddim_sample(x2d, noise)
-    pred_two = eng.ddim_sample(x2d[:2].contiguous(), noise[:2].contiguous())
-    selfcheck = bool(torch.equal(pred_big[:2], pred_two)) and bool(torch.isfinite(pred_big).all())
+    selfcheck = None
+    if not a.no_selfcheck:
+        pred_big = eng.ddim_sample(x2d, noise)
+        pred_two = eng.ddim_sample(x2d[:2].contiguous(), noise[:2].contiguous())
+        selfcheck = bool(torch.equal(pred_big[:2], pred_two)) and bool(torch.isfinite(pred_big).all())
 
     if rank == 0:
         value = Bg * a.steps / elapsed

@@ -27,8 +27,12 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr int XDH = 64;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// V rows: the four key rows k0..k0+3 of one transpose read must land in four different 64-byte bank groups
-__device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+// V rows: the four key rows k0..k0+3 of one transpose read must land in four different 64-byte bank groups (row parity
+// picks the half of the 256-byte bank row, bit 1 of the row flips chunk bit 2); rows 4 apart are additionally rotated
+// over the low chunk bits so that the row-parallel v_query reads of the epilogue (32 lanes, 32 rows, same logical
+// chunk) are 2-way instead of 16-way conflicted.  (row >> 2) is constant inside a transpose read, so those stay conflict-free.
+__device__ __forceinline__ int vkey(int row) { return (((row >> 1) & 1) << 2) ^ ((row >> 2) & 3); }
+__device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ vkey(row)) << 4); }
 typedef short s4v __attribute__((ext_vector_type(4)));
 
 // MU > 1 (only with NKT == 1, i.e. groups of <= 32 tokens: the spatial blocks): one workgroup carries MU independent
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     for (int it = 0; it < 4; ++it) {
       const int piece = wave + NKT * it;
       const int row = 8 * piece + drow;
-      const int chunk = (which == 1) ? (dslot ^ ((row >> 1) & 7)) : (dslot ^ (((row >> 1) & 1) << 2));
+      const int chunk = (which == 1) ? (dslot ^ ((row >> 1) & 7)) : (dslot ^ vkey(row));
       const size_t o = (tok0 + (size_t)row * J) * D3 + (size_t)which * D + hd * XDH + chunk * 8;
       unsigned char* dh = (which == 1 ? sKh : sVh) + piece * 1024;
       unsigned char* dl = (which == 1 ? sKl : sVl) + piece * 1024;

@@ -72,17 +72,27 @@ __device__ __forceinline__ void store_split4(const float (&v)[4], float osc, _Fl
 // and fetches the source chunk the swizzle assigns to that slot (constant per lane: NW is even, so (row>>1)&7 =
 // 4 (w&1) + lane/16).  Contract: the A buffer holds >= mtiles*BM rows and the W buffer >= ntiles*BN rows
 // (padding rows are staged and multiplied but never stored).
+// Source addresses are formed as (wave-uniform byte base: SGPR pair, advanced by scalar adds) + (one 32-bit per-lane byte
+// offset, the same for every piece and k-tile), so that the DMA takes the saddr form and needs no per-piece 64-bit VALU
+// address arithmetic.
 #define D3D_DMA_PLAN(NW_, BM_)                                                                                          \
   const int lr_ = lane >> 3;                                                                                            \
   const int csrc_ = (lane & 7) ^ (((wave & 1) << 2) | (lr_ >> 1));                                                      \
   const size_t K2_ = 2 * (size_t)K;                                                                                     \
-  const _Float16* srcA = Ap + (size_t)(m0 + wave * 8 + lr_) * K2_ + csrc_ * 8;                                          \
-  const _Float16* srcB = Wp + (size_t)(n0 + wave * 8 + lr_) * K2_ + csrc_ * 8;                                          \
-  const size_t it_stride = (size_t)((NW_) * 8) * K2_;                                                                   \
+  const char* ubA = reinterpret_cast<const char*>(Ap) + (size_t)(m0 + wave * 8) * K2_ * 2;                             \
+  const char* ubB = reinterpret_cast<const char*>(Wp) + (size_t)(n0 + wave * 8) * K2_ * 2;                             \
+  unsigned lofs_ = (unsigned)(lr_ * (int)K2_ + csrc_ * 8) * 2u;                                                   \
+  const size_t it_stride = (size_t)((NW_) * 8) * K2_ * 2;                 /* bytes */                                   \
   const int dstA = wave * 1024 + lane * 16, dstB = (BM_) * 128 + wave * 1024 + lane * 16
 
 #define D3D_GLDS(SRC, DSTOFF)                                                                                           \
   __builtin_amdgcn_global_load_lds((SRC), (__attribute__((address_space(3))) void*)(uintptr_t)(lds + (DSTOFF)), 16, 0, 0)
+// wave-uniform pointer pinned into an SGPR pair
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
 
 // Launch-time dispatch over (epilogue, output form): the five combinations the engine and the op hooks use.
 #define D3D_X3_DISPATCH(LAUNCH)                                                                                          \
@@ -312,8 +322,11 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   D3D_DMA_PLAN(NW, BM);
 #define D3D_QSTAGE_ONE(ST, KT, IT)                                                                                      \
   do {                                                                                                                  \
-    if ((IT) < A_IT) D3D_GLDS(srcA + (size_t)(KT) * 64 + (IT) * it_stride, (ST) * STAGE + dstA + (IT) * NW * 1024);       \
-    else D3D_GLDS(srcB + (size_t)(KT) * 64 + ((IT) - A_IT) * it_stride, (ST) * STAGE + dstB + ((IT) - A_IT) * NW * 1024); \
+    if ((IT) < A_IT)                                                                                                    \
+      D3D_GLDS(sgpr_ptr(ubA + ((size_t)(KT) * 128 + (IT) * it_stride)) + lofs_, (ST) * STAGE + dstA + (IT) * NW * 1024); \
+    else                                                                                                                \
+      D3D_GLDS(sgpr_ptr(ubB + ((size_t)(KT) * 128 + ((IT) - A_IT) * it_stride)) + lofs_,                               \
+               (ST) * STAGE + dstB + ((IT) - A_IT) * NW * 1024);                                                        \
   } while (0)
 
   f32x4 acc[TM][4];
@@ -336,6 +349,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
 #define D3D_QKTILE(KT, PREFETCH)                                                                                         \
   do {                                                                                                                   \
     __syncthreads();                                                                                                     \
+    asm volatile("" : "+v"(lofs_)); /* keeps the lane offset out of the loop's pointer induction (saddr form) */         \
     const int nst = ((KT) + 1) & 1;                                                                                      \
     const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                  \
     h8 bh[4], bl[4], ah[2], al[2];                                                                                       \
@@ -460,52 +474,22 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   return hipGetLastError();
 }
 
-// Tile choice: 256x256 (+ a 64x256 launch for the rows of the last partial round) wherever that fills the chip for a few
-// rounds, else 256x128.
+// Tile choice: 256x256 wherever it fills the chip for a few rounds, else 256x128.
+// Treating the partly filled last round specially was tried twice and dropped: (1) a second launch of 64x256 (or 128x128)
+// tiles for the remainder rows -- rocprofv3 shows the big launch does not run in lock-step rounds (24 exact rounds take
+// 46.5 us per round against 45.2 us for 24.2 rounds), so the tail it removes is not there to win; (2) one launch carrying
+// both shapes (big tiles for blockIdx < n, small ones after) computed wrong, run-to-run different values in its 256x256
+// branch on the MI355X although the same tile function is correct in a launch of its own -- not understood, not used.
 static bool x3q_big(int M, int N) {
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   return N % 256 == 0 && tiles >= 4 * 256;
 }
 int x3q_ntiles(int M, int N) { (void)M; return (N + 63) / 64; }   // statistics partials per row: one per 64 columns
 
-// Large problems run as TWO launches: the first mt_big M-tiles (whole rounds of the 256 CUs) as 256x256 tiles, then the
-// remaining rows as 64x256 tiles (8 waves, LDS padded so that one workgroup owns a CU).  With 256x256 tiles alone the
-// partly filled last round costs a whole tile time (18 of 2066 tiles of the proj / fc2 GEMMs at T=243, B=64: 10 % of those
-// launches).  Both shapes produce identical values for an element (same MFMA, same k order).
-// (One launch carrying both shapes -- big tiles for blockIdx < n, small ones after -- would save the launch gap, but the
-// 256x256 branch of that kernel computed wrong, run-to-run different values on the MI355X while the same tile function
-// is correct in a launch of its own; not understood, not used.  tests/test_gpu_ops.py covers the large-M path.)
-static hipError_t launch_x3q_two(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
-                                 _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
-                                 const X3Fold* fold) {
-  const int ntiles = N / 256;
-  const int mfull = M / 256;
-  const int mt_big = (int)(((long long)mfull * ntiles / 256 * 256) / ntiles) / 8 * 8;   // whole rounds of 256 CUs, whole XCD groups
-  const int rows_big = mt_big * 256;
-  if (mt_big > 0) {
-    hipError_t e = launch_x3q<8, 2, 4>(Ap, Wp, bias, R, C, Ch, Cl, rows_big, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
-    if (e != hipSuccess) return e;
-  }
-  if (rows_big == M) return hipSuccess;
-  const size_t ro = (size_t)rows_big;
-  X3Fold f2{};
-  if (fold) {   // row-indexed side buffers move with the rows
-    f2 = *fold;
-    if (f2.st_in) f2.st_in += 2 * ro * f2.st_np;
-    if (f2.Rp) f2.Rp = (const _Float16*)f2.Rp + ro * 2 * N;
-    if (f2.st_out) f2.st_out += 2 * ro * (size_t)((N + 63) / 64);
-  }
-  return launch_x3q<2, 2, 4>(Ap + ro * 2 * K, Wp, bias, R ? R + ro * N : nullptr, C ? C + ro * N : nullptr,
-                             Ch ? Ch + ro * (outsplit == 2 ? 2 * (size_t)N : (size_t)N) : nullptr, Cl ? Cl + ro * N : nullptr,
-                             M - rows_big, N, K, epi, outsplit, qcols, s, 16 * 1024, nullptr, fold ? &f2 : nullptr);
-}
-
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
                                   _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols,
                                   hipStream_t s, const X3Fold* fold) {
-  static const bool no_split = getenv("D3D_X3_NO_SPLIT") != nullptr;   // experiments: uniform 256x256 launch
-  if (x3q_big(M, N) && no_split) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
-  if (x3q_big(M, N)) return launch_x3q_two(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold);
+  if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
   return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
 }
 

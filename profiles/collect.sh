@@ -5,7 +5,7 @@
 #   profiles/collect.sh r01_f16x3 [bench.py args...]
 set -eo pipefail
 tag=${1:-r01_f16x3}; shift || true
-args="--steps 1 --warmup 1 --no-cpu-baseline $*"
+args="--steps 1 --warmup 1 --no-cpu-baseline --no-selfcheck $*"
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 export TMPDIR=/tmp
