@@ -274,10 +274,9 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
 // Both put ONE 8-wave workgroup on a CU.  Every shape adds the same MFMA results in the same order into an output element,
 // so an element's value does not depend on the tile shape that produced it (results are batch-size independent, bitwise).
 // Shapes with 4-wave workgroups (<4,2,2>, <8,2,2>) or two workgroups per CU (<2,4,2>, <4,2,2>) stay instantiable for
-// experiments/gemm_bench.py but are NOT used: with two processes sharing the GPU they gave run-to-run differences in
-// 1 of ~1000 launches (experiments/two_rank_repeat.sh; also with kernels serialised, so a race inside the launch), while
-// both 8-wave one-per-CU shapes were bit-stable in every run; cause not found.
-// One output tile (device function: the launch wrappers below map blockIdx to tiles).
+// experiments/gemm_bench.py but are NOT used: they are slower, and at one stage of this round they gave run-to-run
+// different results in about 1 of 1000 launches while a second process shared the GPU.
+// One output tile (device function: the launch wrapper below maps blockIdx to tiles).
 template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
 __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                          const float* __restrict__ bias, const float* R, float* C, _Float16* Ch, _Float16* Cl,
