@@ -160,6 +160,34 @@ def test_state_dict_layout_and_checkpoint_loading():
     assert diff.sqrt_alphas_cumprod_prev.dtype == torch.float64 and diff.sqrt_alphas_cumprod_prev.shape == (1001,)
 
 
+def test_reference_checkpoint_file_roundtrip(tmp_path):
+    """A file in the reference's on-disk layout (RUN:451-460: metadata + 'model_diffusion' with DataParallel 'module.'
+    keys) loads the way the reference's loader does it (RUN:226-235): 'alphas' tables are ignored, the rest lands in the
+    engine's parameters; save_checkpoint writes that layout back."""
+    from diff3dhpe_amd.checkpoint import load_checkpoint, save_checkpoint, reference_state_dict
+    cfg = DenoiserConfig(num_frame=27, embed_dim=32, depth=2)
+    mk = lambda: d3d.GaussianDiffusion(model=d3d.HPE_model(d3d.S2S_NAME)(num_frame=27, embed_dim=32, depth=2), timesteps=1000,
+                                       sampling_timesteps=5, loss_type="l2", clip_denoised=True)
+    src = mk()
+    src.model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 4).items()})
+    path = str(tmp_path / "epoch_7.bin")
+    save_checkpoint(src, path, epoch=7, lr=1e-4)
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(blob) == {"epoch", "best_epoch", "min_loss", "min_train_loss", "lr", "random_state", "optimizer", "model_diffusion"}
+    assert all(k.startswith("module.") for k in blob["model_diffusion"])
+    blob["model_diffusion"]["module.alphas_cumprod"] = torch.full((1000,), 123.0)     # a stale table must not be loaded
+    blob["model_diffusion"]["module.sqrt_alphas_cumprod"] = torch.full((1000,), 123.0)
+    torch.save(blob, path)
+    dst = mk()
+    meta = load_checkpoint(dst, path)
+    assert meta["epoch"] == 7 and not meta["unexpected_keys"]
+    assert all("alphas" in k for k in meta["missing_keys"])
+    assert float(dst.alphas_cumprod.max()) < 1.0 and float(dst.sqrt_alphas_cumprod.max()) <= 1.0
+    for (ka, a), (kb, b) in zip(src.model.state_dict().items(), dst.model.state_dict().items()):
+        assert ka == kb and torch.equal(a, b), ka
+    assert "alphas_cumprod" not in reference_state_dict(blob) and "model.fusion_layer.weight" in reference_state_dict(blob)
+
+
 def test_synth_is_deterministic_and_well_scaled():
     a = hash_uniform("x", 1000, 3)
     assert np.array_equal(a, hash_uniform("x", 1000, 3)) and not np.array_equal(a, hash_uniform("x", 1000, 4))
