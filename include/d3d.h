@@ -37,8 +37,10 @@ extern "C" {
 #define D3D_EUNSUP (-5)   /* configuration outside what the kernels support */
 
 #define D3D_PREC_FP32 0     /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 everywhere (parity mode) */
-#define D3D_PREC_F16X3 1    /* fp32-accurate GEMMs from 3 fp16 MFMAs on hi/lo operand splits      */
-#define D3D_PREC_BF16 2     /* bf16 MFMA operands, fp32 accumulate / residual / LN / softmax       */
+#define D3D_PREC_F16X3 1    /* fp32-accurate GEMMs and attention from 3 fp16 MFMAs per product on hi/lo operand splits; the
+                             * residual stream lives in the GEMM operand layout and norm1/norm2 are folded into the qkv/fc1
+                             * GEMMs.  Same 1e-4 parity gate as FP32; the default of the Python layer. */
+#define D3D_PREC_BF16 2     /* reserved (bf16 MFMA operands): d3d_engine_create returns D3D_EUNSUP                    */
 
 typedef struct d3d_engine d3d_engine;
 
@@ -159,10 +161,12 @@ const char* d3d_kernel_class_name(int32_t kernel_class);
  * device: out (n, 2*depth, D) in execution order STE0, TTE0, STE1, ...  scratch: n*(D + 4*D) floats. */
 int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, float* out_dev, float* scratch_dev,
                           void* stream);
-/* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); epi 0 none, 1 exact-erf GELU, 2 add residual R[M,N] (R may alias C). */
+/* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); epi 0 none, 1 erf-GELU (FP32: erff; F16X3: erfc series, |err| < 1e-7 |x|),
+ * 2 add residual R[M,N] (R may alias C). */
 int d3d_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
                   int32_t M, int32_t N, int32_t K, int32_t epi, int32_t precision, void* stream);
-/* d3d_op_linear with a choice of tile variant (F16X3: 0 auto, 1 128x128, 2 256x128, 3 256x256, 9 on-the-fly A split)
+/* d3d_op_linear with a choice of tile variant (F16X3: 0 = the engine's choice, 13 = 256x256, 4 = 256x128, 9 = on-the-fly A
+ * split; 5/7/8/10 = shapes kept for experiments/gemm_bench.py only)
  * and a timing leg: after one untimed call, `reps` back-to-back launches are timed with HIP events on `stream` and the
  * mean written to *avg_ms (nullable).  Operand conversion for F16X3 happens once, outside the timed launches. */
 int d3d_op_linear_bench(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
