@@ -213,6 +213,17 @@ def test_large_batch_kernels_match_the_small_batch_path():
         part = eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous())
         assert torch.equal(part, big[lo:hi]), f"samples {lo}:{hi} differ by {(part - big[lo:hi]).abs().max().item():.3e}"
     assert torch.isfinite(big).all() and big.abs().max().item() <= 1.0
+    # T = 81: three key tiles per unit -- the other instantiation of the persistent attention kernel (needs >= 1024 units)
+    cfg = cfg_full(81)
+    _, diff = build_product(cfg, 8, sampling=2, precision="f16x3")
+    eng = diff._engine(dev)
+    inp = inputs(12, 81, 6)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    big = eng.ddim_sample(x2d, nz).clone()
+    assert torch.equal(big, eng.ddim_sample(x2d, nz))
+    for lo in (0, 5, 10):
+        hi = min(lo + 5, 12)
+        assert torch.equal(eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous()), big[lo:hi])
 
 
 def test_engine_matches_oracle_on_fresh_seeded_inputs():
