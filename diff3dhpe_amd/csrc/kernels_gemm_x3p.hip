@@ -268,6 +268,143 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
   }
 }
 
+// The same epilogue for the forms that touch fp16 planes (plane / pair outputs, plane residual): the read-back side gives a
+// lane EIGHT consecutive columns (8 lanes per row, 8 rows per pass, 2 passes per m-tile), so that every plane access is a
+// 16-byte one (8 fp16): half as many load / store instructions as with 4 columns per lane.
+__device__ __forceinline__ float row8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
+__device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
+                                              float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
+                                              const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
+                                              int M, int N, int qcols) {
+  static_assert(EPI != EPI_RESIDUAL || (FX & FX_RP), "the 8-column epilogue takes its residual from planes");
+  const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
+  const int rrow = lane >> 3, rc8 = lane & 7;          // read side
+  const int n = nt0 + 8 * rc8;
+  const bool ncol_ok = !CHECK || n < N;
+  float bb[8], cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bb[e] = 0.f; cs[e] = 0.f; }
+  if (bias && ncol_ok) {
+    const float4 t0 = *reinterpret_cast<const float4*>(bias + n), t1 = *reinterpret_cast<const float4*>(bias + n + 4);
+    bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
+  }
+  if ((FX & FX_LNF) && ncol_ok) {
+    const float4 t0 = *reinterpret_cast<const float4*>(csum + n), t1 = *reinterpret_cast<const float4*>(csum + n + 4);
+    cs[0] = t0.x; cs[1] = t0.y; cs[2] = t0.z; cs[3] = t0.w; cs[4] = t1.x; cs[5] = t1.y; cs[6] = t1.z; cs[7] = t1.w;
+  }
+  const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
+  const int pc = (int)pair_col(8 * rc8);
+  const float2* srow = reinterpret_cast<const float2*>(lds_x);
+  const int npart = (N + 63) >> 6;
+  constexpr int PFMAX = (FX & FX_SO) ? 3 : 4;                          // (the row-statistics form is 9 registers short of 4)
+  constexpr int PF = (EPI == EPI_RESIDUAL) ? (TM < PFMAX ? TM : PFMAX) : 0;   // residual window, see x3q_epilogue
+  const unsigned ob = (unsigned)(rrow * N + 8 * rc8) * 4u;            // this lane's 8 floats in row rrow (fp32 buffer)
+  const unsigned obh = (unsigned)(rrow * N + 8 * rc8) * 2u;           // ... in an [M][N] fp16 plane
+  const unsigned obp = (unsigned)(rrow * 2 * N + pc) * 2u;            // ... in a pair-layout buffer (hi; lo 64 B on)
+  const unsigned rstep = (unsigned)N * 32u;                            // 8 rows of an fp32 or pair buffer
+  const unsigned rsteph = (unsigned)N * 16u;                           // 8 rows of an fp16 plane
+  const char* Rpb = reinterpret_cast<const char*>(Rpt);
+  char* Cb = reinterpret_cast<char*>(Ct);
+  char* Chb = reinterpret_cast<char*>(Cht);
+  char* Clb = reinterpret_cast<char*>(Clt);
+  uint4 rh[TM][2], rl[TM][2];
+  auto load_res = [&](int i) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = rrow + 8 * p;
+      rh[i][p] = make_uint4(0, 0, 0, 0);
+      rl[i][p] = make_uint4(0, 0, 0, 0);
+      if (!CHECK || (mt0 + 16 * i + row < M && ncol_ok)) {
+        rh[i][p] = *reinterpret_cast<const uint4*>(Rpb + (obp + (unsigned)(2 * i + p) * rstep));
+        rl[i][p] = *reinterpret_cast<const uint4*>(Rpb + (obp + (unsigned)(2 * i + p) * rstep) + 64u);
+      }
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) load_res(i);
+  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = rrow + 8 * p;
+      const float* prow = patch + (i & 1) * 1024 + row * 64;
+      const float4 a0 = *reinterpret_cast<const float4*>(prow + (((2 * rc8) ^ (row & 7)) << 2));
+      const float4 a1 = *reinterpret_cast<const float4*>(prow + (((2 * rc8 + 1) ^ (row & 7)) << 2));
+      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const int m = mt0 + 16 * i + row;
+      const bool ok = !CHECK || (m < M && ncol_ok);
+      if (!(FX & FX_SO) && !ok) continue;
+      float v[8];
+      if (FX & FX_LNF) {
+        const float2 st = srow[rbase + 16 * i + row];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(st.x, a[e] * P_OUT_SCALE, fmaf(st.y, cs[e], bb[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = a[e] * P_OUT_SCALE + bb[e];
+      }
+      if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+      }
+      if (EPI == EPI_RESIDUAL) {
+        const h8 hh = __builtin_bit_cast(h8, rh[i][p]), ll = __builtin_bit_cast(h8, rl[i][p]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((float)hh[e] + (float)ll[e]) * 0.125f + v[e];
+      }
+      if (FX & FX_SO) {
+        float sm = 0.f, sq = 0.f;
+        if (ok) {
+          sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          sq = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        }
+        sm = row8_sum(sm);
+        sq = row8_sum(sq);
+        if (rc8 == 0 && m < M) *reinterpret_cast<float2*>(st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
+        if (!ok) continue;
+      }
+      if (OUTSPLIT) {
+        h8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sc = __builtin_amdgcn_fmed3f(v[e] * osc, -65504.0f, 65504.0f);
+          oh[e] = (_Float16)sc;
+          ol[e] = (_Float16)(sc - (float)oh[e]);
+        }
+        if (OUTSPLIT == 2) {
+          *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep)) = oh;
+          *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep) + 64u) = ol;
+        } else {
+          *reinterpret_cast<h8*>(Chb + (obh + (unsigned)(2 * i + p) * rsteph)) = oh;
+          *reinterpret_cast<h8*>(Clb + (obh + (unsigned)(2 * i + p) * rsteph)) = ol;
+        }
+      } else {
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    if (EPI == EPI_RESIDUAL) {
+      if (i + PF < TM) load_res(i + PF);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if (i & 1) {
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // Tile shapes: BM = 16*TM*WM rows, BN = 64*WN columns, WM x WN waves, each wave (16 TM) x 64 = TM x 4 MFMA tiles.
 //   <8,2,4> 256x256, 8 waves of 128x64, 128 KiB LDS  -- large problems
 //   <4,4,2> 256x128, 8 waves of  64x64,  96 KiB LDS  -- problems too small to fill the chip with 256x256 tiles
@@ -392,12 +529,28 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   if (diag) { st_c1 = __builtin_amdgcn_s_memtime(); st_r1 = __builtin_amdgcn_s_memrealtime(); }
   float* patch = reinterpret_cast<float*>(lds) + wave * (2 * 16 * 64);
   const _Float16* Rpt = (FX & FX_RP) ? fx.Rp + 2 * tbase : nullptr;
-  if (m0 + BM <= M && n0 + BN <= N)
-    x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                      nt0, mt0 - m0, lane, M, N, qcols);
-  else
-    x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                     nt0, mt0 - m0, lane, M, N, qcols);
+  constexpr bool PLANES = (OUTSPLIT != 0 || (FX & FX_RP)) && !(EPI == EPI_RESIDUAL && !(FX & FX_RP));
+  const bool full = m0 + BM <= M && n0 + BN <= N;
+  bool done = false;
+  if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
+    if ((N & 7) == 0) {
+      if (full)
+        x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
+                                                           mt0 - m0, lane, M, N, qcols);
+      else
+        x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
+                                                          mt0 - m0, lane, M, N, qcols);
+      done = true;
+    }
+  }
+  if (!done) {
+    if (full)
+      x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
+                                                        nt0, mt0 - m0, lane, M, N, qcols);
+    else
+      x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
+                                                       nt0, mt0 - m0, lane, M, N, qcols);
+  }
   if (diag) {
     __builtin_amdgcn_s_waitcnt(0);   // the wave's own stores issued and acknowledged
     const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
