@@ -414,11 +414,19 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
 // experiments/gemm_bench.py but are NOT used: they are slower, and at one stage of this round they gave run-to-run
 // different results in about 1 of 1000 launches while a second process shared the GPU.
 // One output tile (device function: the launch wrapper below maps blockIdx to tiles).
-template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
+// PERSIST (k_linear_x3q_persist): the workgroup walks several tiles.  Then (i) the first k-tile of a tile has already been
+// staged (by the caller for the first tile, by the previous tile otherwise), (ii) the LAST k-tile of this tile -- which
+// reads stage 1 when K/32 is even -- stages the first k-tile of the NEXT tile (m0n, n0n) into stage 0, so that it lands
+// under the last MFMAs and the epilogue, (iii) the epilogue's transpose patches live in stage 1.
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool PERSIST = false>
 __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                          const float* __restrict__ bias, const float* R, float* C, _Float16* Ch, _Float16* Cl,
                                          int M, int N, int K, int m0, int n0, int nt, int ntiles, int qcols,
-                                         unsigned long long* diag, const X3Tail& fx) {
+                                         unsigned long long* diag, const X3Tail& fx, bool has_next = false, int m0n = 0,
+                                         int n0n = 0, int tid_in = -1) {
+  // PERSIST passes the thread index behind an opaque barrier so that the per-lane offsets are re-derived in every tile
+  // instead of being hoisted out of the tile loop and held in (spilled) registers
+  const int tidx = PERSIST ? tid_in : (int)threadIdx.x;
   constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
   constexpr int A_REG = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, N_IT = A_IT + B_IT;   // 1-KiB DMA pieces per wave per k-tile
@@ -434,8 +442,8 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   if (diag) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   unsigned char* const lds_x = lds + 2 * STAGE;   // beyond the operand stages (allocated only for the folded forms)
   if (FX & FX_LNF) {   // row statistics of the LayerNorm folded into this GEMM; visible after the first k-tile barrier
-    if ((int)threadIdx.x < BM) {
-      const int row = m0 + (int)threadIdx.x;
+    if (tidx < BM) {
+      const int row = m0 + tidx;
       float sm = 0.f, sq = 0.f;
       if (row < M)
         for (int p = 0; p < fx.st_np; ++p) {
@@ -445,11 +453,11 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       const float mean = sm / (float)K;
       const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
       const float rstd = 1.0f / sqrtf(var + fx.eps);
-      reinterpret_cast<float2*>(lds_x)[threadIdx.x] = make_float2(rstd, -mean * rstd);
+      reinterpret_cast<float2*>(lds_x)[tidx] = make_float2(rstd, -mean * rstd);
     }
   }
 
-  const int tid = threadIdx.x;
+  const int tid = tidx;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -477,8 +485,18 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   const int foff = (q ^ (r16 >> 1)) << 4;
   const int aoff = (wm * 16 * TM + r16) * 128 + foff, boff = A_REG + (wn * 64 + r16) * 128 + foff;
   const int nk = K / PBK;
+  if (!PERSIST) {
 #pragma unroll
-  for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(0, 0, it);
+    for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(0, 0, it);
+  }
+  // next tile's operand bases (PERSIST): same per-lane offset, other uniform bases
+  const char* ubAn = reinterpret_cast<const char*>(Ap) + (size_t)(m0n + wave * 8) * K2_ * 2;
+  const char* ubBn = reinterpret_cast<const char*>(Wp) + (size_t)(n0n + wave * 8) * K2_ * 2;
+#define D3D_QSTAGE_NEXT(IT)                                                                                             \
+  do {                                                                                                                  \
+    if ((IT) < A_IT) D3D_GLDS(sgpr_ptr(ubAn + (IT) * it_stride) + lofs_, dstA + (IT) * NW * 1024);                       \
+    else D3D_GLDS(sgpr_ptr(ubBn + ((IT) - A_IT) * it_stride) + lofs_, dstB + ((IT) - A_IT) * NW * 1024);                 \
+  } while (0)
 
   // one k-tile = TM groups (one 16-row m-tile each): the A fragments of group g+1 are read, and PPG DMA pieces of the
   // next k-tile are issued, before the 12 MFMAs of group g; the 8 W fragments are read once at the top of the k-tile.
@@ -503,6 +521,11 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       if (PREFETCH) {                                                                                                    \
         _Pragma("unroll") for (int pp = 0; pp < PPG; ++pp)                                                               \
           if (g * PPG + pp < N_IT) D3D_QSTAGE_ONE(nst, (KT) + 1, g * PPG + pp);                                          \
+      } else if (PERSIST) {                                                                                              \
+        if (has_next) {                                                                                                  \
+          _Pragma("unroll") for (int pp = 0; pp < PPG; ++pp)                                                             \
+            if (g * PPG + pp < N_IT) D3D_QSTAGE_NEXT(g * PPG + pp);                                                      \
+        }                                                                                                                \
       }                                                                                                                  \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
         acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                        \
@@ -518,6 +541,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   D3D_QKTILE(kt, false);
 #undef D3D_QKTILE
 #undef D3D_QSTAGE_ONE
+#undef D3D_QSTAGE_NEXT
 
   const int mt0 = m0 + wm * 16 * TM, nt0 = n0 + wn * 64;          // wave-uniform
   const size_t tbase = (size_t)mt0 * N + nt0;
@@ -527,7 +551,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   _Float16* Clt = Cl ? Cl + tbase : nullptr;
   unsigned long long st_c1 = 0, st_r1 = 0;
   if (diag) { st_c1 = __builtin_amdgcn_s_memtime(); st_r1 = __builtin_amdgcn_s_memrealtime(); }
-  float* patch = reinterpret_cast<float*>(lds) + wave * (2 * 16 * 64);
+  float* patch = reinterpret_cast<float*>(lds + (PERSIST ? STAGE : 0)) + wave * (2 * 16 * 64);
   const _Float16* Rpt = (FX & FX_RP) ? fx.Rp + 2 * tbase : nullptr;
   constexpr bool PLANES = (OUTSPLIT != 0 || (FX & FX_RP)) && !(EPI == EPI_RESIDUAL && !(FX & FX_RP));
   const bool full = m0 + BM <= M && n0 + BN <= N;
@@ -574,6 +598,53 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   const int nt = slot % ntiles;
   if (mt >= mtiles) return;
   x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, diag, fx);
+}
+
+// Persistent launch of the 256x256 shape: one workgroup per CU walks the (virtual) tile indices blockIdx, blockIdx +
+// gridDim, ... in the order of the uniform launch (so a workgroup stays on its XCD class, gridDim % 8 == 0).  Saves the
+// per-tile workgroup relaunch and hides the first-k-tile staging latency of every tile but the first (x3q_tile, PERSIST).
+template <int EPI, int OUTSPLIT, int FX>
+__global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
+                                                            const float* __restrict__ bias, const float* R, float* C,
+                                                            _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
+                                                            int ntiles, int qcols, int vtiles, X3Tail fx) {
+  constexpr int TM = 8, WM = 2, WN = 4, NW = 8, BM = 256;
+  constexpr int A_IT = 4, N_IT = 8, STAGE = 512 * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int stride = (int)gridDim.x;
+  auto tile_of = [&](int t, int& mt, int& nt) {
+    const int xcd = t & 7, slot = t >> 3;
+    mt = (slot / ntiles) * 8 + xcd;
+    nt = slot % ntiles;
+    return mt < mtiles;
+  };
+  int t = (int)blockIdx.x, mt = 0, nt = 0;
+  while (t < vtiles && !tile_of(t, mt, nt)) t += stride;
+  if (t >= vtiles) return;
+  {   // stage the first k-tile of the first tile (what x3q_tile does for itself in the uniform launch)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int m0 = mt * 256, n0 = nt * 256;
+    D3D_DMA_PLAN(NW, BM);
+#pragma unroll
+    for (int it = 0; it < N_IT; ++it) {
+      if (it < A_IT) D3D_GLDS(sgpr_ptr(ubA + it * it_stride) + lofs_, dstA + it * NW * 1024);
+      else D3D_GLDS(sgpr_ptr(ubB + (it - A_IT) * it_stride) + lofs_, dstB + (it - A_IT) * NW * 1024);
+    }
+    (void)STAGE;
+  }
+  int tid_o = (int)threadIdx.x;
+  while (true) {
+    asm volatile("" : "+v"(tid_o));
+    int tn = t + stride, mtn = 0, ntn = 0;
+    while (tn < vtiles && !tile_of(tn, mtn, ntn)) tn += stride;
+    const bool has_next = tn < vtiles;
+    x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * 256, nt * 256, nt, ntiles, qcols, nullptr,
+                                                  fx, has_next, mtn * 256, ntn * 256, tid_o);
+    if (!has_next) break;
+    t = tn; mt = mtn; nt = ntn;
+    __syncthreads();   // the epilogue's patches (stage 1) are read before the next tile's second k-tile is staged there
+  }
 }
 
 template <int TM, int WM, int WN>
@@ -626,12 +697,67 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   return hipGetLastError();
 }
 
-// Tile choice: 256x256 wherever it fills the chip for a few rounds, else 256x128.
+// Tile choice: 256x256 -- as a persistent walk, one workgroup per CU (k_linear_x3q_persist: +1 % over one workgroup per tile:
+// the next tile's first k-tile lands under the epilogue) -- wherever it fills the chip for a few rounds, else 256x128.
 // Treating the partly filled last round specially was tried twice and dropped: (1) a second launch of 64x256 (or 128x128)
 // tiles for the remainder rows -- rocprofv3 shows the big launch does not run in lock-step rounds (24 exact rounds take
 // 46.5 us per round against 45.2 us for 24.2 rounds), so the tail it removes is not there to win; (2) one launch carrying
 // both shapes (big tiles for blockIdx < n, small ones after) computed wrong, run-to-run different values in its 256x256
 // branch on the MI355X although the same tile function is correct in a launch of its own -- not understood, not used.
+static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C,
+                                     _Float16* Ch, _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols,
+                                     hipStream_t s, const X3Fold* fold) {
+  const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
+  const int vtiles = ((mtiles + 7) / 8) * 8 * ntiles;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  const int grid = vtiles < n_cu ? vtiles : n_cu;
+  size_t lds_bytes = 2 * (size_t)(512 * 128);
+  X3Tail tail{};
+  int fx = 0;
+  if (fold) {
+    if (fold->st_in) fx |= FX_LNF;
+    if (fold->Rp) fx |= FX_RP;
+    if (fold->st_out) fx |= FX_SO;
+    tail.st_in = fold->st_in; tail.st_np = fold->st_np; tail.csum = fold->csum; tail.eps = fold->eps;
+    tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out;
+    if (fx & FX_LNF) lds_bytes += (size_t)256 * 8;
+    if ((fx & FX_LNF) && (!fold->csum || fold->st_np < 1)) return hipErrorInvalidValue;
+  }
+#define D3D_X3P_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
+  do {                                                                                                                    \
+    auto kfn = k_linear_x3q_persist<EPI_, OS_, FX_>;                                                                      \
+    static bool attr_done = false;                                                                                        \
+    if (!attr_done) {                                                                                                     \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds_bytes);                                                                \
+      if (ae != hipSuccess) return ae;                                                                                    \
+      attr_done = true;                                                                                                   \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,     \
+                       qcols, vtiles, tail);                                                                              \
+  } while (0)
+#define D3D_X3P_LAUNCH(EPI_, OS_) D3D_X3P_LAUNCH_FX(EPI_, OS_, 0)
+  if (fx == 0) {
+    D3D_X3_DISPATCH(D3D_X3P_LAUNCH);
+  } else {
+    if (fx == FX_LNF && epi == EPI_NONE && outsplit == 1) D3D_X3P_LAUNCH_FX(EPI_NONE, 1, FX_LNF);
+    else if (fx == (FX_RP | FX_SO) && epi == EPI_RESIDUAL && outsplit == 2) D3D_X3P_LAUNCH_FX(EPI_RESIDUAL, 2, FX_RP | FX_SO);
+    else if (fx == FX_LNF && epi == EPI_GELU && outsplit == 2) D3D_X3P_LAUNCH_FX(EPI_GELU, 2, FX_LNF);
+    else if (fx == FX_RP && epi == EPI_RESIDUAL && outsplit == 0) D3D_X3P_LAUNCH_FX(EPI_RESIDUAL, 0, FX_RP);
+    else return hipErrorInvalidValue;
+  }
+#undef D3D_X3P_LAUNCH
+#undef D3D_X3P_LAUNCH_FX
+  return hipGetLastError();
+}
+
 static bool x3q_big(int M, int N) {
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   return N % 256 == 0 && tiles >= 4 * 256;
@@ -641,6 +767,9 @@ int x3q_ntiles(int M, int N) { (void)M; return (N + 63) / 64; }   // statistics 
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
                                   _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols,
                                   hipStream_t s, const X3Fold* fold) {
+  static const bool persist = getenv("D3D_X3_NO_PERSIST") == nullptr;   // (switch for experiments/)
+  if (x3q_big(M, N) && persist && (K / PBK) % 2 == 0)
+    return launch_x3q_persist(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold);
   if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
   return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
 }
