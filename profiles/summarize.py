@@ -58,10 +58,10 @@ def short(name: str) -> str:
         tm, wm, wn, epi, osp, fx = m.groups()
         tile = "{}x{}".format(16 * int(tm) * int(wm), 64 * int(wn))
     else:
-        m = re.match(r"k_linear_x3q_mix<(\d+), (\d+), (\d+)>", name)
+        m = re.match(r"k_linear_x3q_persist<(\d+), (\d+), (\d+)>", name)
         if m:   # <EPI, OUTSPLIT, FX>
             epi, osp, fx = m.groups()
-            tile = "256x256+64x256"
+            tile = "256x256 persistent"
     if m:
         role = {("0", "0"): "qkv", ("0", "1"): "qkv", ("2", "0"): "proj, fc2" if (fx or "0") == "0" else "fc2", ("2", "2"): "proj",
                 ("1", "2"): "fc1"}.get((epi, osp), "")
