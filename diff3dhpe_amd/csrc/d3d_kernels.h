@@ -43,11 +43,22 @@ void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair
 //                    with outsplit == 2 and Ch == Rp the residual stream is updated in place, plane to plane
 //   st_out != null : (with EPI_RESIDUAL) per row and 64-column block the (sum, sum of squares) of the new row values go to
 //                    st_out[(m * (N/64) + block)] -- the st_in of the next folded GEMM (st_np = x3q_ntiles() = N/64)
+//   pn.g != null   : (with EPI_RESIDUAL, Rp, N == 512) the tile spans whole rows, and the epilogue applies the block's post-norm
+//                    to the new rows before they leave the chip:  y = LN(r + a W^T + b; pn.g, pn.b) [+ pos] [+ tvec]  (the
+//                    operations of launch_layernorm); outsplit == 2: y -> pair planes Ch (may be Rp) and the (sum, sum of
+//                    squares) partials of y -> st_out; outsplit == 0: y -> fp32 C
+struct X3PostNorm {
+  const float* g; const float* b; float eps;
+  const float* pos; int pos_div, pos_mod;                          // nullable, as LnArgs
+  const float* tvec; long long tvec_stride; int rows_per_batch;   // nullable, as LnArgs
+};
 struct X3Fold {
   const float* st_in; int st_np; const float* csum; float eps;
   const void* Rp;
   float* st_out;
+  X3PostNorm pn;
 };
+bool x3q_postnorm_ok(int N, int K);   // shapes the post-norm form exists for
 hipError_t launch_linear_x3p(const void* Apair, const void* Wpair, const float* bias, const float* R, float* C, void* Ch,
                              void* Cl, int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s,
                              const X3Fold* fold = nullptr);

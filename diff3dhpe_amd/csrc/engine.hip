@@ -224,7 +224,7 @@ Workspace carve(const d3d_engine* e, int B, void* base) {
   size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
   size_t oRED = take((size_t)B * e->J * D), oTI = take((size_t)B + 64);
   size_t oXI = take(M * e->cfg.in_chans), oNI = take(M * 3), oOB = take(M * 3);   // graph-mode staging copies
-  size_t oS1 = take(M * 2), oS2 = take(M * 2 * (size_t)((D + 63) / 64));      // row statistics of the LN-folded GEMMs
+  size_t oS1 = take(M * 2 * (size_t)((D + 63) / 64)), oS2 = take(M * 2 * (size_t)((D + 63) / 64));      // row statistics of the LN-folded GEMMs
   w.X = b + oX; w.HN = b + oHN; w.QKV = b + oQKV; w.HID = b + oHID; w.Y0 = b + oY0; w.Y1 = b + oY1;
   w.TEMB = b + oTE; w.TSCR = b + oTS; w.RED = b + oRED; w.TIMES = b + oTI;
   w.XIN = b + oXI; w.NIN = b + oNI; w.OUTB = b + oOB; w.ST1 = b + oS1; w.ST2 = b + oS2;
@@ -285,7 +285,11 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
     HIP_TRY(rowk(a, 1));
   }
-  const int np2 = x3q_ntiles(M, D);                     // statistics partials per row written by the proj epilogue
+  const int np2 = x3q_ntiles(M, D);                     // statistics partials per row written by a GEMM epilogue
+  int np1 = 1;                                          // ... per row in w.ST1 (1 after a row kernel)
+  // post-norm inside the fc2 epilogue (X3PostNorm) where the tile shape for it exists; else fp32 + the row kernel
+  static const bool pn_off = getenv("D3D_NO_PN") != nullptr;   // (switch for experiments/)
+  const bool pn = !pn_off && x3q_postnorm_ok(D, e->Dm);
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
@@ -296,7 +300,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     };
     {  // q, k, v planes = norm1(x) Wqkv^T + b   (LayerNorm folded; q third pre-scaled by dh^-0.5)
       X3Fold f{};
-      f.st_in = w.ST1; f.st_np = 1; f.csum = bw.qkv_cs; f.eps = 1e-6f;
+      f.st_in = w.ST1; f.st_np = np1; f.csum = bw.qkv_cs; f.eps = 1e-6f;
       HIP_TRY(gemm(XP, bw.qkv_f3, bw.qkv_fb, nullptr, QKVh, QKVl, 1, 3 * D, D, EPI_NONE, D, f));
     }
     {
@@ -315,6 +319,24 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       f.st_in = w.ST2; f.st_np = np2; f.csum = bw.fc1_cs; f.eps = 1e-6f;
       HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
     }
+    const float* pn_g = temporal ? e->tn_g : e->sn_g;
+    const float* pn_b = temporal ? e->tn_b : e->sn_b;
+    const bool last = k + 1 == e->nblk;
+    if (pn) {  // x = post_norm(x + hidden W2^T + b2) [+ Temporal_pos_embed] [+ next block's time vector], all in the fc2 epilogue
+      X3Fold f{};
+      f.Rp = XP;
+      f.pn.g = pn_g; f.pn.b = pn_b; f.pn.eps = 1e-6f; f.pn.pos_div = 1; f.pn.pos_mod = 1; f.pn.rows_per_batch = T * J;
+      if (k == 0) { f.pn.pos = e->tpos; f.pn.pos_div = J; f.pn.pos_mod = T; }
+      if (!last && tvec) { f.pn.tvec = tvec + (size_t)(k + 1) * D; f.pn.tvec_stride = tvec_stride; }
+      if (!last) {
+        f.st_out = w.ST1;
+        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, nullptr, XP, nullptr, 2, D, e->Dm, EPI_RESIDUAL, 0, f));
+        np1 = np2;
+      } else {
+        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
+      }
+      continue;
+    }
     {  // x + hidden W2^T + b2 -> fp32 (w.HN) for the post-norm
       X3Fold f{};
       f.Rp = XP;
@@ -323,10 +345,10 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector] -> planes + statistics (or fp32 at the end)
       LnArgs a{};
       a.x = w.HN;
-      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = 1e-6f;
+      a.g1 = pn_g; a.b1 = pn_b; a.eps1 = 1e-6f;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       if (k == 0) { a.pos = e->tpos; a.pos_div = J; a.pos_mod = T; }
-      if (k + 1 < e->nblk) {
+      if (!last) {
         if (tvec) { a.tvec = tvec + (size_t)(k + 1) * D; a.tvec_stride = tvec_stride; }
         a.y_x3 = XP; a.stats = w.ST1;
       } else {

@@ -133,6 +133,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 constexpr int FX_LNF = 1;   // LayerNorm folded into this GEMM: per-row (rstd, -mean rstd) from LDS, csum per column
 constexpr int FX_RP = 2;    // residual from pair-layout planes
 constexpr int FX_SO = 4;    // per-row (sum, sum of squares) of the output rows -> st_out
+constexpr int FX_PN = 8;    // the tile spans whole rows: post-norm of the new rows in the epilogue (X3PostNorm)
 
 // sum over the 16 lanes of a DPP row (all 16 lanes get the total): quad xor 1, xor 2, half-row mirror, row mirror
 __device__ __forceinline__ float row16_sum(float v) {
@@ -147,6 +148,7 @@ struct X3Tail {            // per-launch extras of the folded forms (device copy
   const float* st_in; int st_np; const float* csum; float eps;
   const _Float16* Rp;
   float* st_out;
+  X3PostNorm pn;
 };
 
 // lds_x: the workgroup's LDS beyond the operand stages: [BM] float2 row statistics (FX_LNF)
@@ -405,6 +407,161 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   }
 }
 
+// Post-norm epilogue (FX_PN): the workgroup's tile is BM full rows (WM == 1, N == 64 WN), so the block's post-norm
+//   y = LN(r + a W^T + b) [+ pos] [+ tvec]      (launch_layernorm's operations, two-pass variance)
+// is applied before the rows leave the chip -- the fp32 round trip through HBM and the row kernel's launch are gone.
+// Sweep 1 forms the new rows (8-column read-back as x3q_epilogue8) and keeps them in the registers the accumulators
+// vacate; row statistics go through xch ([BM][WN] float2 of LDS beside the patches: one (sum, M2) partial per wave);
+// sweep 2 normalises and stores planes + the (sum, sum of squares) partials of y for the next folded GEMM
+// (OUTSPLIT 2) or fp32 rows (OUTSPLIT 0, last block).
+template <int TM, int WN, int OUTSPLIT, bool CHECK>
+__device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patch, float* xch, const float* __restrict__ bias,
+                                                float* Ct, _Float16* Cht, const _Float16* Rpt, const X3Tail& fx, int mt0, int nt0,
+                                                int wn, int lane, int M, int N) {
+  static_assert(WN == 8, "row partials are read back as two float4");
+  constexpr int BM = 16 * TM;
+  const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
+  const int rrow = lane >> 3, rc8 = lane & 7;          // read side
+  const int n = nt0 + 8 * rc8;
+  float bb[8];
+  {
+    const float4 t0 = *reinterpret_cast<const float4*>(bias + n), t1 = *reinterpret_cast<const float4*>(bias + n + 4);
+    bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
+  }
+  const int pc = (int)pair_col(8 * rc8);
+  constexpr int PF = TM < 3 ? TM : 3;                                  // residual window, see x3q_epilogue
+  const unsigned ob = (unsigned)(rrow * N + 8 * rc8) * 4u;            // this lane's 8 floats in row rrow (fp32 buffer)
+  const unsigned obp = (unsigned)(rrow * 2 * N + pc) * 2u;            // ... in a pair-layout buffer (hi; lo 64 B on)
+  const unsigned rstep = (unsigned)N * 32u;                            // 8 rows of an fp32 or pair buffer
+  const char* Rpb = reinterpret_cast<const char*>(Rpt);
+  char* Cb = reinterpret_cast<char*>(Ct);
+  char* Chb = reinterpret_cast<char*>(Cht);
+  uint4 rh[TM][2], rl[TM][2];
+  auto load_res = [&](int i) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      rh[i][p] = make_uint4(0, 0, 0, 0);
+      rl[i][p] = make_uint4(0, 0, 0, 0);
+      if (!CHECK || mt0 + 16 * i + rrow + 8 * p < M) {
+        rh[i][p] = *reinterpret_cast<const uint4*>(Rpb + (obp + (unsigned)(2 * i + p) * rstep));
+        rl[i][p] = *reinterpret_cast<const uint4*>(Rpb + (obp + (unsigned)(2 * i + p) * rstep) + 64u);
+      }
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) load_res(i);
+  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+  float vv[TM][2][8];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = rrow + 8 * p;
+      const float* prow = patch + (i & 1) * 1024 + row * 64;
+      const float4 a0 = *reinterpret_cast<const float4*>(prow + (((2 * rc8) ^ (row & 7)) << 2));
+      const float4 a1 = *reinterpret_cast<const float4*>(prow + (((2 * rc8 + 1) ^ (row & 7)) << 2));
+      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const bool ok = !CHECK || mt0 + 16 * i + row < M;
+      const h8 hh = __builtin_bit_cast(h8, rh[i][p]), ll = __builtin_bit_cast(h8, rl[i][p]);
+      float* v = vv[i][p];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = ((float)hh[e] + (float)ll[e]) * 0.125f + (a[e] * P_OUT_SCALE + bb[e]);
+        if (CHECK && !ok) v[e] = 0.0f;
+      }
+      // this wave's 64 columns of the row: sum, and sum of squared deviations from their own mean (combined below by the
+      // pairwise update formula -- as accurate as a two-pass variance, with one exchange)
+      const float sm = row8_sum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+      const float lm = sm * (1.0f / 64.0f);
+      float d[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = v[e] - lm;
+      const float sq = row8_sum(((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) +
+                                ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7])));
+      if (rc8 == 0) *reinterpret_cast<float2*>(xch + 2 * ((16 * i + row) * WN + wn)) = make_float2(sm, sq);
+    }
+    if (i + PF < TM) load_res(i + PF);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float invn = 1.0f / (float)N;
+  float gg[8], be[8], tv[8];
+  {
+    const float4 t0 = *reinterpret_cast<const float4*>(fx.pn.g + n), t1 = *reinterpret_cast<const float4*>(fx.pn.g + n + 4);
+    gg[0] = t0.x; gg[1] = t0.y; gg[2] = t0.z; gg[3] = t0.w; gg[4] = t1.x; gg[5] = t1.y; gg[6] = t1.z; gg[7] = t1.w;
+    const float4 u0 = *reinterpret_cast<const float4*>(fx.pn.b + n), u1 = *reinterpret_cast<const float4*>(fx.pn.b + n + 4);
+    be[0] = u0.x; be[1] = u0.y; be[2] = u0.z; be[3] = u0.w; be[4] = u1.x; be[5] = u1.y; be[6] = u1.z; be[7] = u1.w;
+  }
+  const bool tv_uniform = fx.pn.tvec != nullptr && fx.pn.tvec_stride == 0;
+  const bool tv_rows = fx.pn.tvec != nullptr && fx.pn.tvec_stride != 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) tv[e] = 0.0f;
+  if (tv_uniform) {
+    const float4 t0 = *reinterpret_cast<const float4*>(fx.pn.tvec + n), t1 = *reinterpret_cast<const float4*>(fx.pn.tvec + n + 4);
+    tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
+  }
+  const int npart = N >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 16 * i + rrow + 8 * p;
+      const int m = mt0 + r;
+      const float4* xr = reinterpret_cast<const float4*>(xch + 2 * r * WN);   // (sum, M2) of the row's 8 column blocks
+      const float4 p0 = xr[0], p1 = xr[1], p2 = xr[2], p3 = xr[3];
+      const float mean = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * invn;
+      const float e0 = p0.x * (1.0f / 64.0f) - mean, e1 = p0.z * (1.0f / 64.0f) - mean, e2 = p1.x * (1.0f / 64.0f) - mean,
+                  e3 = p1.z * (1.0f / 64.0f) - mean, e4 = p2.x * (1.0f / 64.0f) - mean, e5 = p2.z * (1.0f / 64.0f) - mean,
+                  e6 = p3.x * (1.0f / 64.0f) - mean, e7 = p3.z * (1.0f / 64.0f) - mean;
+      const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
+                       64.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
+      const float rstd = 1.0f / sqrtf(m2 * invn + fx.pn.eps);
+      float* v = vv[i][p];
+      if (CHECK && m >= M) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+      if (fx.pn.pos) {
+        const float* pr = fx.pn.pos + (size_t)((m / fx.pn.pos_div) % fx.pn.pos_mod) * N + n;
+        const float4 t0 = *reinterpret_cast<const float4*>(pr), t1 = *reinterpret_cast<const float4*>(pr + 4);
+        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+      }
+      if (tv_rows) {
+        const float* tr = fx.pn.tvec + (size_t)(m / fx.pn.rows_per_batch) * fx.pn.tvec_stride + n;
+        const float4 t0 = *reinterpret_cast<const float4*>(tr), t1 = *reinterpret_cast<const float4*>(tr + 4);
+        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+      } else if (tv_uniform) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += tv[e];
+      }
+      if (OUTSPLIT == 2) {
+        float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        float sq = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        sm = row8_sum(sm);
+        sq = row8_sum(sq);
+        if (rc8 == 0) *reinterpret_cast<float2*>(fx.st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
+        h8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sc = __builtin_amdgcn_fmed3f(v[e] * P_A_SCALE, -65504.0f, 65504.0f);
+          oh[e] = (_Float16)sc;
+          ol[e] = (_Float16)(sc - (float)oh[e]);
+        }
+        *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep)) = oh;
+        *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep) + 64u) = ol;
+      } else {
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Tile shapes: BM = 16*TM*WM rows, BN = 64*WN columns, WM x WN waves, each wave (16 TM) x 64 = TM x 4 MFMA tiles.
 //   <8,2,4> 256x256, 8 waves of 128x64, 128 KiB LDS  -- large problems
 //   <4,4,2> 256x128, 8 waves of  64x64,  96 KiB LDS  -- problems too small to fill the chip with 256x256 tiles
@@ -556,7 +713,14 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   constexpr bool PLANES = (OUTSPLIT != 0 || (FX & FX_RP)) && !(EPI == EPI_RESIDUAL && !(FX & FX_RP));
   const bool full = m0 + BM <= M && n0 + BN <= N;
   bool done = false;
-  if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
+  if constexpr ((FX & FX_PN) != 0) {   // whole rows in the tile: post-norm here (the launcher guarantees N == BN)
+    static_assert(WM == 1 && EPI == EPI_RESIDUAL && (FX & FX_RP) && OUTSPLIT != 1, "post-norm form");
+    static_assert(STAGE >= 65536 + 2 * BM * WN * 4, "row-sum exchange beside the patches");
+    float* xch = reinterpret_cast<float*>(lds + STAGE + 65536);
+    // (one instantiation, row checks always on: with a checked and an unchecked copy under a branch the accumulators spill)
+    x3q_epilogue_pn<TM, WN, OUTSPLIT, true>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N);
+    done = true;
+  } else if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
     if ((N & 7) == 0) {
       if (full)
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
@@ -603,13 +767,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
 // Persistent launch of the 256x256 shape: one workgroup per CU walks the (virtual) tile indices blockIdx, blockIdx +
 // gridDim, ... in the order of the uniform launch (so a workgroup stays on its XCD class, gridDim % 8 == 0).  Saves the
 // per-tile workgroup relaunch and hides the first-k-tile staging latency of every tile but the first (x3q_tile, PERSIST).
-template <int EPI, int OUTSPLIT, int FX>
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
 __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                                             const float* __restrict__ bias, const float* R, float* C,
                                                             _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
                                                             int ntiles, int qcols, int vtiles, X3Tail fx) {
-  constexpr int TM = 8, WM = 2, WN = 4, NW = 8, BM = 256;
-  constexpr int A_IT = 4, N_IT = 8, STAGE = 512 * 128;
+  constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
+  constexpr int A_IT = BM / 8 / NW, N_IT = (BM + BN) / 8 / NW;
+  static_assert(NW == 8, "one 8-wave workgroup per CU");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int stride = (int)gridDim.x;
   auto tile_of = [&](int t, int& mt, int& nt) {
@@ -624,14 +789,13 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
   {   // stage the first k-tile of the first tile (what x3q_tile does for itself in the uniform launch)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int m0 = mt * 256, n0 = nt * 256;
+    const int m0 = mt * BM, n0 = nt * BN;
     D3D_DMA_PLAN(NW, BM);
 #pragma unroll
     for (int it = 0; it < N_IT; ++it) {
       if (it < A_IT) D3D_GLDS(sgpr_ptr(ubA + it * it_stride) + lofs_, dstA + it * NW * 1024);
       else D3D_GLDS(sgpr_ptr(ubB + (it - A_IT) * it_stride) + lofs_, dstB + (it - A_IT) * NW * 1024);
     }
-    (void)STAGE;
   }
   int tid_o = (int)threadIdx.x;
   while (true) {
@@ -639,8 +803,8 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
     int tn = t + stride, mtn = 0, ntn = 0;
     while (tn < vtiles && !tile_of(tn, mtn, ntn)) tn += stride;
     const bool has_next = tn < vtiles;
-    x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * 256, nt * 256, nt, ntiles, qcols, nullptr,
-                                                  fx, has_next, mtn * 256, ntn * 256, tid_o);
+    x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, nullptr,
+                                                  fx, has_next, mtn * BM, ntn * BN, tid_o);
     if (!has_next) break;
     t = tn; mt = mtn; nt = ntn;
     __syncthreads();   // the epilogue's patches (stage 1) are read before the next tile's second k-tile is staged there
@@ -732,7 +896,7 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
   }
 #define D3D_X3P_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
   do {                                                                                                                    \
-    auto kfn = k_linear_x3q_persist<EPI_, OS_, FX_>;                                                                      \
+    auto kfn = k_linear_x3q_persist<8, 2, 4, EPI_, OS_, FX_>;                                                                      \
     static bool attr_done = false;                                                                                        \
     if (!attr_done) {                                                                                                     \
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -755,6 +919,71 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
   }
 #undef D3D_X3P_LAUNCH
 #undef D3D_X3P_LAUNCH_FX
+  return hipGetLastError();
+}
+
+// Post-norm form (X3Fold::pn): 128 x 512 tiles (<8,1,8>: eight waves of 128 x 64 side by side, 2 x 80 KiB of LDS -- the whole
+// CU), so that a workgroup owns whole rows.  Per k-tile it stages 80 KiB for the MFMA work a 256x256 tile does on 64 KiB;
+// what it saves is the fp32 round trip of the stream through HBM and the row kernel behind the fc2 GEMM.
+// The same tile function serves every M (persistent walk when the chip is filled for a few rounds, one workgroup per tile
+// otherwise), so the result stays batch-size independent bitwise.
+bool x3q_postnorm_ok(int N, int K) { return N == 512 && K % PBK == 0; }
+
+static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const float* bias, float* C, _Float16* Ch, int M, int N,
+                                int K, int outsplit, hipStream_t s, const X3Fold* fold) {
+  if (!x3q_postnorm_ok(N, K) || !fold->Rp || !fold->pn.b || !bias || (outsplit == 2 ? (!Ch || !fold->st_out) : !C))
+    return hipErrorInvalidValue;
+  if (outsplit != 0 && outsplit != 2) return hipErrorInvalidValue;
+  if (fold->pn.pos && (fold->pn.pos_div < 1 || fold->pn.pos_mod < 1)) return hipErrorInvalidValue;
+  if (fold->pn.tvec && fold->pn.tvec_stride != 0 && fold->pn.rows_per_batch < 1) return hipErrorInvalidValue;
+  const int mtiles = (M + 127) / 128, ntiles = 1;
+  const int vtiles = ((mtiles + 7) / 8) * 8;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  static const bool persist_on = getenv("D3D_X3_NO_PERSIST") == nullptr;
+  const bool persist = persist_on && mtiles >= 4 * n_cu && (K / PBK) % 2 == 0;
+  const size_t lds_bytes = 2 * (size_t)((128 + 512) * 128);
+  X3Tail tail{};
+  tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out; tail.pn = fold->pn;
+  const int qcols = 0;
+  unsigned long long* diag = nullptr;
+  _Float16* Cl = nullptr;
+  const float* R = nullptr;
+#define D3D_X3PN_LAUNCH(OS_)                                                                                              \
+  do {                                                                                                                    \
+    if (persist) {                                                                                                        \
+      auto kfn = k_linear_x3q_persist<8, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                         \
+      static bool attr_done = false;                                                                                      \
+      if (!attr_done) {                                                                                                   \
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)lds_bytes);                                                              \
+        if (ae != hipSuccess) return ae;                                                                                  \
+        attr_done = true;                                                                                                 \
+      }                                                                                                                   \
+      hipLaunchKernelGGL(kfn, dim3(vtiles < n_cu ? vtiles : n_cu), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, \
+                         mtiles, ntiles, qcols, vtiles, tail);                                                            \
+    } else {                                                                                                              \
+      auto kfn = k_linear_x3q<8, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                                 \
+      static bool attr_done = false;                                                                                      \
+      if (!attr_done) {                                                                                                   \
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)lds_bytes);                                                              \
+        if (ae != hipSuccess) return ae;                                                                                  \
+        attr_done = true;                                                                                                 \
+      }                                                                                                                   \
+      hipLaunchKernelGGL(kfn, dim3(vtiles), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles, \
+                         qcols, diag, tail);                                                                              \
+    }                                                                                                                     \
+  } while (0)
+  if (outsplit == 2) D3D_X3PN_LAUNCH(2);
+  else D3D_X3PN_LAUNCH(0);
+#undef D3D_X3PN_LAUNCH
   return hipGetLastError();
 }
 
@@ -793,6 +1022,10 @@ hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias
   if (variant == 0) {
     static const char* ov = getenv("D3D_X3_VARIANT");   // experiments only
     if (ov) variant = atoi(ov);
+  }
+  if (fold && fold->pn.g) {
+    if (epi != EPI_RESIDUAL) return hipErrorInvalidValue;
+    return launch_x3q_pn(ap, wp, bias, C, ch, M, N, K, outsplit, s, fold);
   }
   switch (variant) {
     case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold);
