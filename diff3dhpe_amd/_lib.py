@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "d3d_engine_set_schedule", "d3d_engine_set_sqrt_alphas_cumprod", "d3d_ddim_times", "d3d_workspace_bytes",
     "d3d_denoise", "d3d_ddim_sample", "d3d_q_sample", "d3d_tta_mpjpe", "d3d_op_linear", "d3d_op_layernorm",
     "d3d_op_attention", "d3d_op_time_embedding", "d3d_engine_set_profiling", "d3d_engine_profile_reset",
-    "d3d_engine_profile_read", "d3d_kernel_class_name", "d3d_op_linear_bench", "d3d_engine_set_graph_mode", "d3d_num_windows", "d3d_window_gather",
+    "d3d_engine_profile_read", "d3d_kernel_class_name", "d3d_op_linear_bench", "d3d_op_linear_postnorm", "d3d_engine_set_graph_mode", "d3d_num_windows", "d3d_window_gather",
 ]
 
 
@@ -66,6 +66,8 @@ def _bind(lib: C.CDLL) -> None:
         "d3d_op_time_embedding": (C.c_int, [vp, vp, i32, vp, vp, vp]),
         "d3d_op_linear": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "d3d_op_linear_bench": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp]),
+        "d3d_op_linear_postnorm": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, vp, i64, i32, vp, vp, i32, i32, i32, i32,
+                                             C.POINTER(C.c_float), vp]),
         "d3d_op_layernorm": (C.c_int, [vp, vp, vp, vp, i32, i32, f32, vp]),
         "d3d_op_attention": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     }

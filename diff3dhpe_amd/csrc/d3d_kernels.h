@@ -64,6 +64,8 @@ hipError_t launch_linear_x3p(const void* Apair, const void* Wpair, const float* 
                              const X3Fold* fold = nullptr);
 int x3q_ntiles(int M, int N);   // statistics partials per row an st_out launch writes
 hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
+hipError_t launch_unsplit_x3(const void* pair, float* x, size_t rows, int cols, const float* part, int np, float* stats,
+                             hipStream_t s);   // op hooks only
 // diagnostic launches (variants 13 / 11): per (workgroup, wave) six u64 stamps {clk, 100 MHz} x {start, k-loop end, end}
 void set_linear_x3_diag(unsigned long long* dev_buf);
 

@@ -1078,6 +1078,55 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
   return D3D_OK;
 }
 
+int d3d_op_linear_postnorm(const float* A, const float* W, const float* bias, const float* R, const float* gamma,
+                           const float* beta, float eps, const float* pos, int32_t pos_div, int32_t pos_mod, const float* tvec,
+                           int64_t tvec_stride, int32_t rows_per_batch, float* Y, float* stats, int32_t M, int32_t N, int32_t K,
+                           int32_t reps, float* avg_ms, void* stream) {
+  if (!A || !W || !bias || !R || !gamma || !beta || !Y || M < 1 || reps < 1) return fail(D3D_EINVAL, "bad argument");
+  if (!x3q_postnorm_ok(N, K)) return fail(D3D_EUNSUP, "the post-norm GEMM form exists for N == 512, K % 32 == 0");
+  if ((pos && (pos_div < 1 || pos_mod < 1)) || (tvec && tvec_stride != 0 && rows_per_batch < 1))
+    return fail(D3D_EINVAL, "bad row-class arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  TmpPair ap, wp, rp, yp;
+  int rc = make_pair(wp, W, N, K, true, s);
+  if (!rc) rc = make_pair(ap, A, M, K, false, s);
+  if (!rc) rc = make_pair(rp, R, M, N, false, s);
+  if (!rc && stats) rc = make_pair(yp, R, M, N, false, s);   // (any initialised pair buffer of the output's size)
+  if (rc) return rc;
+  const int np = x3q_ntiles(M, N);
+  float* part = nullptr;
+  if (stats) HIP_TRY(hipMalloc(&part, (size_t)M * np * 2 * sizeof(float)));
+  X3Fold f{};
+  f.Rp = rp.dev;
+  f.pn.g = gamma; f.pn.b = beta; f.pn.eps = eps;
+  f.pn.pos = pos; f.pn.pos_div = pos ? pos_div : 1; f.pn.pos_mod = pos ? pos_mod : 1;
+  f.pn.tvec = tvec; f.pn.tvec_stride = tvec_stride; f.pn.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+  f.st_out = part;
+  auto once = [&]() -> hipError_t {
+    if (stats) return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, nullptr, yp.dev, nullptr, M, N, K, EPI_RESIDUAL, 2, 0, 0, s, &f);
+    return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, Y, nullptr, nullptr, M, N, K, EPI_RESIDUAL, 0, 0, 0, s, &f);
+  };
+  hipError_t le = once();
+  if (le == hipSuccess && avg_ms) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < reps && le == hipSuccess; ++i) le = once();
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = ms / reps;
+  }
+  if (le == hipSuccess && stats) le = launch_unsplit_x3(yp.dev, Y, (size_t)M, N, part, np, stats, s);
+  hipError_t se = hipStreamSynchronize(s);
+  if (part) (void)hipFree(part);
+  HIP_TRY(le);
+  HIP_TRY(se);
+  return D3D_OK;
+}
+
 int d3d_op_layernorm(const float* x, const float* gamma, const float* beta, float* out, int32_t rows, int32_t D, float eps,
                      void* stream) {
   if (!x || !gamma || !beta || !out) return fail(D3D_EINVAL, "null tensor");

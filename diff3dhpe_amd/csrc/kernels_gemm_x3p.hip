@@ -418,8 +418,7 @@ template <int TM, int WN, int OUTSPLIT, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patch, float* xch, const float* __restrict__ bias,
                                                 float* Ct, _Float16* Cht, const _Float16* Rpt, const X3Tail& fx, int mt0, int nt0,
                                                 int wn, int lane, int M, int N) {
-  static_assert(WN == 8, "row partials are read back as two float4");
-  constexpr int BM = 16 * TM;
+  static_assert(WN == 8, "row partials are read back as four float4");
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
   const int n = nt0 + 8 * rc8;
@@ -1064,6 +1063,35 @@ hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hi
   const size_t n4 = rows * cols / 4;
   if (n4 == 0) return hipSuccess;
   hipLaunchKernelGGL(k_split_x3, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, (_Float16*)pair, n4, cols);
+  return hipGetLastError();
+}
+
+// pair layout of 8*x -> fp32 [rows, cols], and the row totals of (sum, sum of squares) partials: read-back side of the
+// plane-form op hooks (d3d_op_linear_postnorm); not on the engine's path
+__global__ __launch_bounds__(256) void k_unsplit_x3(const _Float16* __restrict__ pair, float* __restrict__ x, size_t n, int cols,
+                                                    const float* __restrict__ part, int np, float* __restrict__ stats,
+                                                    size_t rows) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const size_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    const _Float16* p = pair + row * 2 * cols + pair_col(c);
+    x[i] = ((float)p[0] + (float)p[PAIR_LO]) * 0.125f;
+  }
+  if (stats && i < rows) {
+    float sm = 0.f, sq = 0.f;
+    for (int k = 0; k < np; ++k) { sm += part[2 * (i * np + k)]; sq += part[2 * (i * np + k) + 1]; }
+    stats[2 * i] = sm; stats[2 * i + 1] = sq;
+  }
+}
+
+hipError_t launch_unsplit_x3(const void* pair, float* x, size_t rows, int cols, const float* part, int np, float* stats,
+                             hipStream_t s) {
+  if (cols <= 0 || cols % 32) return hipErrorInvalidValue;
+  const size_t n = rows * cols;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unsplit_x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const _Float16*)pair, x, n, cols, part, np,
+                     stats, rows);
   return hipGetLastError();
 }
 

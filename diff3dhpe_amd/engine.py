@@ -230,6 +230,32 @@ def op_linear_bench(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, 
     return out, ms.value
 
 
+def op_linear_postnorm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor,
+                       beta: torch.Tensor, eps: float = 1e-6, pos: Optional[torch.Tensor] = None, pos_div: int = 1,
+                       tvec: Optional[torch.Tensor] = None, rows_per_batch: int = 1, with_stats: bool = False, reps: int = 1):
+    """LayerNorm(residual + A W^T + bias) [+ pos[(m // pos_div) % len(pos)]] [+ tvec[m // rows_per_batch] or the one tvec]
+    through the F16X3 GEMM whose epilogue applies the norm (fc2 + post-norm of a block, S2S:131-135 + 236/245).
+    Returns (Y, stats or None, mean ms per launch); stats = per-row (sum, sum of squares) of Y from the plane form."""
+    M, K = A.shape
+    N = W.shape[0]
+    dev = A.device
+    A, W, bias, residual = _f32c(A, dev), _f32c(W, dev), _f32c(bias, dev), _f32c(residual, dev)
+    gamma, beta = _f32c(gamma, dev), _f32c(beta, dev)
+    pos = _f32c(pos, dev) if pos is not None else None
+    tvec = _f32c(tvec, dev) if tvec is not None else None
+    stride = 0 if tvec is None or tvec.dim() == 1 or tvec.shape[0] == 1 else N
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=dev) if with_stats else None
+    ms = C.c_float(0.0)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_op_linear_postnorm(
+            _ptr(A), _ptr(W), _ptr(bias), _ptr(residual), _ptr(gamma), _ptr(beta), float(eps), _ptr(pos), int(pos_div),
+            int(pos.shape[0]) if pos is not None else 1, _ptr(tvec), stride, int(rows_per_batch), _ptr(out), _ptr(stats), M, N, K,
+            int(reps), C.byref(ms), st))
+    return out, stats, ms.value
+
+
 def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     dev = x.device
     D = x.shape[-1]

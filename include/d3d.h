@@ -172,6 +172,18 @@ int d3d_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev,
 int d3d_op_linear_bench(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
                         int32_t M, int32_t N, int32_t K, int32_t epi, int32_t precision, int32_t variant, int32_t reps,
                         float* avg_ms, void* stream);
+/* Y[M,N] = LayerNorm(R + A[M,K] @ W[N,K]^T + bias; gamma, beta, eps) [+ pos[(m / pos_div) % pos_mod, :]]
+ *           [+ tvec[(m / rows_per_batch) * tvec_stride + :]]
+ * -- the fc2 GEMM of a block with the block's post-norm applied in its epilogue (S2S:131-135 followed by S2S:236 / 245, and
+ * the additions of S2S:238-242 / 113-116), the form the F16X3 engine runs: whole-row tiles, so the sum never leaves the chip
+ * un-normalised.  F16X3 only; N == 512, K % 32 == 0 (anything else: D3D_EUNSUP).  pos / tvec nullable.  stats nullable:
+ * [M,2] = (sum, sum of squares) of every Y row -- when given, the plane-output form runs (the one inside the engine, which
+ * hands these statistics to the next LayerNorm-folded GEMM) and Y is decoded from its planes; otherwise the fp32-output
+ * form (last block).  reps / avg_ms: timing leg as d3d_op_linear_bench. */
+int d3d_op_linear_postnorm(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev,
+                           const float* gamma_dev, const float* beta_dev, float eps, const float* pos_dev, int32_t pos_div,
+                           int32_t pos_mod, const float* tvec_dev, int64_t tvec_stride, int32_t rows_per_batch, float* Y_dev,
+                           float* stats_dev, int32_t M, int32_t N, int32_t K, int32_t reps, float* avg_ms, void* stream);
 /* Row LayerNorm over the last axis (S2S:95,101,236,245 eps 1e-6; S2S:218 eps 1e-5). */
 int d3d_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* out_dev, int32_t rows,
                      int32_t D, float eps, void* stream);

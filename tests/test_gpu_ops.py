@@ -69,6 +69,65 @@ def test_linear_bit_reproducible_and_row_independent(prec):
     assert torch.equal(E.op_linear(A[100:229].contiguous(), W, None, precision=prec), o1[100:229])   # tile position must not matter
 
 
+@pytest.mark.parametrize("M,K,mode", [(128, 2048, "plain"), (300, 512, "pos"), (4131, 2048, "tvec1"), (1000, 64, "tvecrows"),
+                                      (17, 32, "all"), (140000, 512, "big")])
+def test_linear_postnorm_matches_fp64(M, K, mode):
+    """fc2 + post-norm in one GEMM (whole-row 128x512 tiles, LayerNorm in the epilogue; S2S:131-135 + 236/245 with the
+    additions of S2S:238-242 / 113-116): both output forms against fp64 math, the row statistics handed to the next folded
+    GEMM, and bitwise independence of a row from the tile position / launch form (M = 140000 takes the persistent walk)."""
+    E = _eng()
+    N = 512
+    A = hashed(f"pnA{M}", (M, K), 21, 2.0).cuda()
+    W = hashed(f"pnW{K}", (N, K), 22, 1.0 / np.sqrt(K)).cuda()
+    b = hashed("pnb", (N,), 23, 0.5).cuda()
+    R = (hashed(f"pnR{M}", (M, N), 24, 1.5) + 0.3).cuda()
+    g = (1 + 0.2 * hashed("png", (N,), 25)).cuda()
+    be = (0.2 * hashed("pnbe", (N,), 26)).cuda()
+    rows = torch.arange(M, device="cuda")
+    kw, add = {}, torch.zeros((M, N), dtype=torch.float64, device="cuda")
+    if mode in ("pos", "all"):
+        pos = hashed("pnpos", (9, N), 27, 0.5).cuda()
+        kw.update(pos=pos, pos_div=17)
+        add += pos.double()[(rows // 17) % 9]
+    if mode in ("tvec1", "big"):
+        tv = hashed("pntv", (N,), 28, 0.5).cuda()
+        kw.update(tvec=tv)
+        add += tv.double()
+    if mode in ("tvecrows", "all"):
+        rpb = 51
+        tv = hashed("pntvr", ((M + rpb - 1) // rpb, N), 29, 0.5).cuda()
+        kw.update(tvec=tv, rows_per_batch=rpb)
+        if tv.shape[0] > 1:
+            add += tv.double()[rows // rpb]
+        else:
+            add += tv.double()[0]
+    ref = F.layer_norm(R.double() + A.double() @ W.double().t() + b.double(), (N,), g.double(), be.double(), 1e-6) + add
+    tol = 3e-6 * np.sqrt(K / 32) + 2e-6
+    y32, _, _ = E.op_linear_postnorm(A, W, b, R, g, be, 1e-6, **kw)
+    assert maxabs(y32, ref.cpu()) < tol
+    yp, st, _ = E.op_linear_postnorm(A, W, b, R, g, be, 1e-6, with_stats=True, **kw)
+    assert maxabs(yp, ref.cpu()) < tol + 2e-6                     # planes hold 22 bits of y
+    assert maxabs(yp, y32.cpu()) < 2e-6
+    assert maxabs(st[:, 0], ref.sum(1).cpu()) < 2e-3 and maxabs(st[:, 1], (ref * ref).sum(1).cpu()) < 1e-2
+    lo, hi = (100, 229) if M > 229 else (0, M)
+    part, _, _ = E.op_linear_postnorm(A[lo:hi].contiguous(), W, b, R[lo:hi].contiguous(), g, be, 1e-6)
+    if not kw:
+        assert torch.equal(part, y32[lo:hi])
+    else:   # (row classes shift with the slice: compare the normalised part only)
+        part0, _, _ = E.op_linear_postnorm(A[lo:hi].contiguous(), W, b, R[lo:hi].contiguous(), g, be, 1e-6)
+        full0, _, _ = E.op_linear_postnorm(A, W, b, R, g, be, 1e-6)
+        assert torch.equal(part0, full0[lo:hi])
+
+
+def test_linear_postnorm_rejects_other_widths():
+    E = _eng()
+    from diff3dhpe_amd import D3DError
+    A, W, R = torch.zeros(64, 64).cuda(), torch.zeros(256, 64).cuda(), torch.zeros(64, 256).cuda()
+    v = torch.zeros(256).cuda()
+    with pytest.raises(D3DError):
+        E.op_linear_postnorm(A, W, v, R, v, v)
+
+
 @pytest.mark.parametrize("rows,D,eps", [(5, 32, 1e-6), (1000, 512, 1e-6), (333, 512, 1e-5), (64, 1024, 1e-6), (3, 128, 1e-6)])
 def test_layernorm(rows, D, eps):
     E = _eng()
