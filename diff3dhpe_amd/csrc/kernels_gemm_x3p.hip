@@ -156,7 +156,8 @@ template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
                                              const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
                                              const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
-                                             int M, int N, int qcols) {
+                                             int M, int N, int qcols, int gl, int gh) {
+  // [gl, gh): the wave's m-tiles that are computed (all of them except in a split tail tile, x3q_tile)
   // patch: two wave-private 16 rows x 64 floats (alternating, so the LDS round trip of one m-tile overlaps the stores
   // of the previous one), 16-byte chunks XOR-swizzled by (row & 7)
   constexpr int BM = 16 * TM * WM;
@@ -188,6 +189,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
   char* Cb = reinterpret_cast<char*>(Ct);
   float4 rr[TM][4];
   auto load_res = [&](int i) {
+    if (i < gl || i >= gh) return;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = rrow + 4 * p;
@@ -209,6 +211,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
   __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+   if (i >= gl && i < gh) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
@@ -261,6 +264,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
         *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(4 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
+   }
     if (EPI == EPI_RESIDUAL) {   // this m-tile's accumulators and residual registers are dead: refill the residual window
       if (i + PF < TM) load_res(i + PF);
       __builtin_amdgcn_sched_barrier(0);
@@ -284,7 +288,7 @@ template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
                                               float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
                                               const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
-                                              int M, int N, int qcols) {
+                                              int M, int N, int qcols, int gl, int gh) {
   static_assert(EPI != EPI_RESIDUAL || (FX & FX_RP), "the 8-column epilogue takes its residual from planes");
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
@@ -318,6 +322,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   char* Clb = reinterpret_cast<char*>(Clt);
   uint4 rh[TM][2], rl[TM][2];
   auto load_res = [&](int i) {
+    if (i < gl || i >= gh) return;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = rrow + 8 * p;
@@ -335,6 +340,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+   if (i >= gl && i < gh) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
@@ -398,6 +404,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
         *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
+   }
     if (EPI == EPI_RESIDUAL) {
       if (i + PF < TM) load_res(i + PF);
       __builtin_amdgcn_sched_barrier(0);
@@ -417,7 +424,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
 template <int TM, int WN, int OUTSPLIT, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patch, float* xch, const float* __restrict__ bias,
                                                 float* Ct, _Float16* Cht, const _Float16* Rpt, const X3Tail& fx, int mt0, int nt0,
-                                                int wn, int lane, int M, int N) {
+                                                int wn, int lane, int M, int N, int gl, int gh) {
   static_assert(WN == 8, "row partials are read back as four float4");
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
@@ -437,6 +444,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   char* Chb = reinterpret_cast<char*>(Cht);
   uint4 rh[TM][2], rl[TM][2];
   auto load_res = [&](int i) {
+    if (i < gl || i >= gh) return;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       rh[i][p] = make_uint4(0, 0, 0, 0);
@@ -454,6 +462,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   float vv[TM][2][8];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+   if (i >= gl && i < gh) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
@@ -484,6 +493,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
                                 ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7])));
       if (rc8 == 0) *reinterpret_cast<float2*>(xch + 2 * ((16 * i + row) * WN + wn)) = make_float2(sm, sq);
     }
+   }
     if (i + PF < TM) load_res(i + PF);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -507,6 +517,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    if (i < gl || i >= gh) continue;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int r = 16 * i + rrow + 8 * p;
@@ -568,18 +579,22 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
 // so an element's value does not depend on the tile shape that produced it (results are batch-size independent, bitwise).
 // Shapes with 4-wave workgroups (<4,2,2>, <8,2,2>) or two workgroups per CU (<2,4,2>, <4,2,2>) stay instantiable for
 // experiments/gemm_bench.py but are NOT used: they are slower, and at one stage of this round they gave run-to-run
-// different results in about 1 of 1000 launches while a second process shared the GPU.
+// different results in about 1 of 1000 launches while a second process shared the GPU (a k-tile
+// barrier without a vmcnt wait -- see D3D_QKTILE -- would produce exactly that, but the ISA of that stage was not kept).
 // One output tile (device function: the launch wrapper below maps blockIdx to tiles).
 // PERSIST (k_linear_x3q_persist): the workgroup walks several tiles.  Then (i) the first k-tile of a tile has already been
 // staged (by the caller for the first tile, by the previous tile otherwise), (ii) the LAST k-tile of this tile -- which
 // reads stage 1 when K/32 is even -- stages the first k-tile of the NEXT tile (m0n, n0n) into stage 0, so that it lands
 // under the last MFMAs and the epilogue, (iii) the epilogue's transpose patches live in stage 1.
-template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool PERSIST = false>
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool PERSIST = false, bool SUB = false>
 __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                          const float* __restrict__ bias, const float* R, float* C, _Float16* Ch, _Float16* Cl,
                                          int M, int N, int K, int m0, int n0, int nt, int ntiles, int qcols,
                                          unsigned long long* diag, const X3Tail& fx, bool has_next = false, int m0n = 0,
-                                         int n0n = 0, int tid_in = -1) {
+                                         int n0n = 0, int tid_in = -1, int sub_wm = -1, int g_lo = 0, int g_hi = TM) {
+  // SUB -- split tail tile (k_linear_x3q_persist): only the m-tiles [g_lo, g_hi) (g_lo even) of the waves in wave-row sub_wm (-1:
+  // every wave-row) are computed and stored; the other waves still stage W pieces and meet the barriers.  A pieces outside
+  // the computed rows are not staged (after the first k-tile, which the previous tile staged in full).
   // PERSIST passes the thread index behind an opaque barrier so that the per-lane offsets are re-derived in every tile
   // instead of being hoisted out of the tile loop and held in (spilled) registers
   const int tidx = PERSIST ? tid_in : (int)threadIdx.x;
@@ -618,13 +633,26 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, q = lane >> 4;
+  // (a compile-time switch: with run-time ranges in the whole-tile path too, the whole GEMM ran 3.5 % slower)
+  const bool w_act = !SUB || sub_wm < 0 || wm == sub_wm;          // wave-uniform
+  const int gl = SUB ? (w_act ? g_lo : 0) : 0, gh = SUB ? (w_act ? g_hi : 0) : TM;
+  unsigned amask = SUB ? 0u : ~0u;                                // A pieces of this wave that carry computed rows
+  if (SUB) {
+    const int a_lo = (sub_wm < 0 ? 0 : sub_wm) * 16 * TM + g_lo * 16, a_hi = (sub_wm < 0 ? WM - 1 : sub_wm) * 16 * TM + g_hi * 16;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int r0 = (it * NW + wave) * 8;
+      if (r0 + 8 > a_lo && r0 < a_hi) amask |= 1u << it;
+    }
+  }
 
   D3D_DMA_PLAN(NW, BM);
 #define D3D_QSTAGE_ONE(ST, KT, IT)                                                                                      \
   do {                                                                                                                  \
-    if ((IT) < A_IT)                                                                                                    \
-      D3D_GLDS(sgpr_ptr(ubA + ((size_t)(KT) * 128 + (IT) * it_stride)) + lofs_, (ST) * STAGE + dstA + (IT) * NW * 1024); \
-    else                                                                                                                \
+    if ((IT) < A_IT) {                                                                                                  \
+      if ((amask >> (IT)) & 1u)                                                                                         \
+        D3D_GLDS(sgpr_ptr(ubA + ((size_t)(KT) * 128 + (IT) * it_stride)) + lofs_, (ST) * STAGE + dstA + (IT) * NW * 1024); \
+    } else                                                                                                              \
       D3D_GLDS(sgpr_ptr(ubB + ((size_t)(KT) * 128 + ((IT) - A_IT) * it_stride)) + lofs_,                               \
                (ST) * STAGE + dstB + ((IT) - A_IT) * NW * 1024);                                                        \
   } while (0)
@@ -658,6 +686,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   // next k-tile are issued, before the 12 MFMAs of group g; the 8 W fragments are read once at the top of the k-tile.
 #define D3D_QKTILE(KT, PREFETCH)                                                                                         \
   do {                                                                                                                   \
+    /* this wave's DMA pieces of k-tile KT have landed before it meets the barrier: written out, not left to the fence */\
+    /* of __syncthreads() -- in the SUB instantiation (uniform branches around the DMA issues) the compiler emitted no  */\
+    /* vmcnt wait in the k-loop at all, and the slices read stale W rows (the last pieces issued)                        */\
+    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) */                                                                 \
     __syncthreads();                                                                                                     \
     asm volatile("" : "+v"(lofs_)); /* keeps the lane offset out of the loop's pointer induction (saddr form) */         \
     const int nst = ((KT) + 1) & 1;                                                                                      \
@@ -667,10 +699,11 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       bh[j] = *reinterpret_cast<const h8*>(sb + boff + j * 2048);                                                        \
       bl[j] = *reinterpret_cast<const h8*>(sb + ((boff + j * 2048) ^ 64));                                               \
     }                                                                                                                    \
-    ah[0] = *reinterpret_cast<const h8*>(sb + aoff);                                                                     \
-    al[0] = *reinterpret_cast<const h8*>(sb + (aoff ^ 64));                                                              \
+    ah[0] = *reinterpret_cast<const h8*>(sb + aoff + gl * 2048);                                                         \
+    al[0] = *reinterpret_cast<const h8*>(sb + ((aoff + gl * 2048) ^ 64));                                                \
     _Pragma("unroll") for (int g = 0; g < TM; ++g) {                                                                     \
-      if (g + 1 < TM) {                                                                                                  \
+      const bool g_act = g >= gl && g < gh;                                                                              \
+      if (g_act && g + 1 < gh) {                                                                                         \
         ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                      \
         al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                             \
       }                                                                                                                  \
@@ -683,10 +716,12 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
             if (g * PPG + pp < N_IT) D3D_QSTAGE_NEXT(g * PPG + pp);                                                      \
         }                                                                                                                \
       }                                                                                                                  \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
-        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                        \
-        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
-        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                        \
+      if (g_act) {                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                      \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
+        }                                                                                                                \
       }                                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }                                                                                                                    \
@@ -717,26 +752,26 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     static_assert(STAGE >= 65536 + 2 * BM * WN * 4, "row-sum exchange beside the patches");
     float* xch = reinterpret_cast<float*>(lds + STAGE + 65536);
     // (one instantiation, row checks always on: with a checked and an unchecked copy under a branch the accumulators spill)
-    x3q_epilogue_pn<TM, WN, OUTSPLIT, true>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N);
+    x3q_epilogue_pn<TM, WN, OUTSPLIT, true>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N, gl, gh);
     done = true;
   } else if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
     if ((N & 7) == 0) {
       if (full)
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                           mt0 - m0, lane, M, N, qcols);
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh);
       else
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                          mt0 - m0, lane, M, N, qcols);
+                                                          mt0 - m0, lane, M, N, qcols, gl, gh);
       done = true;
     }
   }
   if (!done) {
     if (full)
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                        nt0, mt0 - m0, lane, M, N, qcols);
+                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh);
     else
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                       nt0, mt0 - m0, lane, M, N, qcols);
+                                                       nt0, mt0 - m0, lane, M, N, qcols, gl, gh);
   }
   if (diag) {
     __builtin_amdgcn_s_waitcnt(0);   // the wave's own stores issued and acknowledged
@@ -763,29 +798,61 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, diag, fx);
 }
 
-// Persistent launch of the 256x256 shape: one workgroup per CU walks the (virtual) tile indices blockIdx, blockIdx +
-// gridDim, ... in the order of the uniform launch (so a workgroup stays on its XCD class, gridDim % 8 == 0).  Saves the
-// per-tile workgroup relaunch and hides the first-k-tile staging latency of every tile but the first (x3q_tile, PERSIST).
+// Persistent launch (one 8-wave workgroup per CU): the workgroup walks the tiles blockIdx, blockIdx + gridDim, ... of the
+// uniform launch's order (so it stays on its XCD class, gridDim % 8 == 0).  Saves the per-tile workgroup relaunch and hides
+// the first-k-tile staging latency of every tile but the first (x3q_tile, PERSIST).
+// Tail: tiles = nfull * gridDim + rem.  The rem tiles of the last, partly filled round are cut into `split` (1, 2 or 4) row
+// slices handled by split * rem <= gridDim workgroups (x3q_tile's sub_wm / g_lo / g_hi), so the round that would keep rem CUs
+// busy for a whole tile time keeps split * rem CUs busy for a fraction of it.  A slice runs the same MFMAs in the same
+// order for its rows as the whole tile would: values do not change.
+struct X3Walk { int nfull, rem, split; };
+
 template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
 __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                                             const float* __restrict__ bias, const float* R, float* C,
                                                             _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
-                                                            int ntiles, int qcols, int vtiles, X3Tail fx) {
+                                                            int ntiles, int qcols, X3Walk wk, X3Tail fx) {
   constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
   constexpr int A_IT = BM / 8 / NW, N_IT = (BM + BN) / 8 / NW;
   static_assert(NW == 8, "one 8-wave workgroup per CU");
+  static_assert(TM % 4 == 0 && (WM == 1 || WM == 2), "tail slices");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int stride = (int)gridDim.x;
-  auto tile_of = [&](int t, int& mt, int& nt) {
-    const int xcd = t & 7, slot = t >> 3;
-    mt = (slot / ntiles) * 8 + xcd;
-    nt = slot % ntiles;
-    return mt < mtiles;
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  const int vfull = (mtiles / 8) * 8 * ntiles, mrem = mtiles % 8;
+  // valid-tile ordinal -> tile: the uniform launch's blockIdx order without its padding slots
+  auto tile_of = [&](int o, int& mt, int& nt) {
+    if (o < vfull) {
+      const int xcd = o & 7, slot = o >> 3;
+      mt = (slot / ntiles) * 8 + xcd;
+      nt = slot % ntiles;
+    } else {
+      const int o2 = o - vfull;
+      mt = (mtiles / 8) * 8 + o2 % mrem;
+      nt = o2 / mrem;
+    }
   };
-  int t = (int)blockIdx.x, mt = 0, nt = 0;
-  while (t < vtiles && !tile_of(t, mt, nt)) t += stride;
-  if (t >= vtiles) return;
-  {   // stage the first k-tile of the first tile (what x3q_tile does for itself in the uniform launch)
+  const int nitems = wk.nfull + (b < wk.split * wk.rem ? 1 : 0);
+  if (nitems == 0) return;
+  // item k of this workgroup: a whole tile (k < nfull) or a slice of a tail tile
+  auto item_of = [&](int k, int& mt, int& nt, int& sub_wm, int& g_lo, int& g_hi) {
+    sub_wm = -1; g_lo = 0; g_hi = TM;
+    if (k < wk.nfull) {
+      tile_of(k * G + b, mt, nt);
+      return;
+    }
+    tile_of(wk.nfull * G + b / wk.split, mt, nt);
+    const int sub = b % wk.split;
+    if (wk.split == 2) {
+      if (WM == 2) sub_wm = sub;
+      else { g_lo = sub * (TM / 2); g_hi = g_lo + TM / 2; }
+    } else if (wk.split == 4) {
+      if (WM == 2) { sub_wm = sub >> 1; g_lo = (sub & 1) * (TM / 2); g_hi = g_lo + TM / 2; }
+      else { g_lo = sub * (TM / 4); g_hi = g_lo + TM / 4; }
+    }
+  };
+  int k = 0, mt = 0, nt = 0, sub_wm = -1, g_lo = 0, g_hi = TM;
+  item_of(0, mt, nt, sub_wm, g_lo, g_hi);
+  {   // stage the first k-tile of the first item (what x3q_tile does for itself in the uniform launch)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int m0 = mt * BM, n0 = nt * BN;
@@ -797,17 +864,29 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
     }
   }
   int tid_o = (int)threadIdx.x;
-  while (true) {
+  const int nwhole = (nitems > wk.nfull && wk.split > 1) ? wk.nfull : nitems;   // items run as whole tiles
+  while (k < nwhole) {
     asm volatile("" : "+v"(tid_o));
-    int tn = t + stride, mtn = 0, ntn = 0;
-    while (tn < vtiles && !tile_of(tn, mtn, ntn)) tn += stride;
-    const bool has_next = tn < vtiles;
+    const bool has_next = k + 1 < nitems;
+    int mtn = 0, ntn = 0, swn = -1, gln = 0, ghn = TM;
+    if (has_next) item_of(k + 1, mtn, ntn, swn, gln, ghn);
     x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, nullptr,
                                                   fx, has_next, mtn * BM, ntn * BN, tid_o);
-    if (!has_next) break;
-    t = tn; mt = mtn; nt = ntn;
+    if (!has_next) return;
+    ++k; mt = mtn; nt = ntn; sub_wm = swn; g_lo = gln; g_hi = ghn;
     __syncthreads();   // the epilogue's patches (stage 1) are read before the next tile's second k-tile is staged there
   }
+  asm volatile("" : "+v"(tid_o));
+  x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, nullptr, fx,
+                                                      false, 0, 0, tid_o, sub_wm, g_lo, g_hi);
+}
+
+// walk of `tiles` tiles over `grid` persistent workgroups
+static X3Walk x3q_walk(int tiles, int grid) {
+  static const bool split_on = getenv("D3D_X3_NO_TAILSPLIT") == nullptr;   // (switch for experiments/)
+  X3Walk w{tiles / grid, tiles % grid, 1};
+  if (split_on && w.rem > 0) w.split = 4 * w.rem <= grid ? 4 : (2 * w.rem <= grid ? 2 : 1);
+  return w;
 }
 
 template <int TM, int WM, int WN>
@@ -861,17 +940,18 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
 }
 
 // Tile choice: 256x256 -- as a persistent walk, one workgroup per CU (k_linear_x3q_persist: +1 % over one workgroup per tile:
-// the next tile's first k-tile lands under the epilogue) -- wherever it fills the chip for a few rounds, else 256x128.
-// Treating the partly filled last round specially was tried twice and dropped: (1) a second launch of 64x256 (or 128x128)
-// tiles for the remainder rows -- rocprofv3 shows the big launch does not run in lock-step rounds (24 exact rounds take
-// 46.5 us per round against 45.2 us for 24.2 rounds), so the tail it removes is not there to win; (2) one launch carrying
-// both shapes (big tiles for blockIdx < n, small ones after) computed wrong, run-to-run different values in its 256x256
-// branch on the MI355X although the same tile function is correct in a launch of its own -- not understood, not used.
+// the next tile's first k-tile lands under the epilogue; the tiles of the partly filled last round are cut into row slices,
+// +1 %) -- wherever it fills the chip for a few rounds, else 256x128.
+// History of the tail: a second launch of 64x256 tiles for the remainder rows gained nothing (launch gap); a first single
+// launch carrying two tile shapes computed wrong, run-to-run different values.  Its cause was found later with the slices:
+// in an instantiation whose DMA issues sit behind uniform branches the compiler emits NO vmcnt wait before the k-tile
+// barrier (the fence of __syncthreads() normally provides it), so fragments were read before the last-issued pieces had
+// landed.  D3D_QKTILE now states the wait itself.
 static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C,
                                      _Float16* Ch, _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols,
                                      hipStream_t s, const X3Fold* fold) {
   const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
-  const int vtiles = ((mtiles + 7) / 8) * 8 * ntiles;
+  const int tiles = mtiles * ntiles;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -880,7 +960,9 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
     n_cu = prop.multiProcessorCount / 8 * 8;
     if (n_cu < 8) n_cu = 8;
   }
-  const int grid = vtiles < n_cu ? vtiles : n_cu;
+  const int grid = tiles < n_cu ? tiles / 8 * 8 : n_cu;
+  if (grid < 8) return hipErrorInvalidValue;
+  const X3Walk wk = x3q_walk(tiles, grid);
   size_t lds_bytes = 2 * (size_t)(512 * 128);
   X3Tail tail{};
   int fx = 0;
@@ -904,7 +986,7 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
       attr_done = true;                                                                                                   \
     }                                                                                                                     \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,     \
-                       qcols, vtiles, tail);                                                                              \
+                       qcols, wk, tail);                                                                                  \
   } while (0)
 #define D3D_X3P_LAUNCH(EPI_, OS_) D3D_X3P_LAUNCH_FX(EPI_, OS_, 0)
   if (fx == 0) {
@@ -947,6 +1029,7 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
   }
   static const bool persist_on = getenv("D3D_X3_NO_PERSIST") == nullptr;
   const bool persist = persist_on && mtiles >= 4 * n_cu && (K / PBK) % 2 == 0;
+  const X3Walk wk = x3q_walk(mtiles * ntiles, n_cu);
   const size_t lds_bytes = 2 * (size_t)((128 + 512) * 128);
   X3Tail tail{};
   tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out; tail.pn = fold->pn;
@@ -965,8 +1048,8 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
         if (ae != hipSuccess) return ae;                                                                                  \
         attr_done = true;                                                                                                 \
       }                                                                                                                   \
-      hipLaunchKernelGGL(kfn, dim3(vtiles < n_cu ? vtiles : n_cu), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, \
-                         mtiles, ntiles, qcols, vtiles, tail);                                                            \
+      hipLaunchKernelGGL(kfn, dim3(n_cu), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,   \
+                         qcols, wk, tail);                                                                                \
     } else {                                                                                                              \
       auto kfn = k_linear_x3q<8, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                                 \
       static bool attr_done = false;                                                                                      \

@@ -52,19 +52,16 @@ def short(name: str) -> str:
     name = demangle(name)
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("d3d::", "").strip()
-    _FX = {"0": "", "1": ", LN-folded", "2": ", plane residual", "6": ", plane residual + row stats"}
-    m = re.match(r"k_linear_x3q<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    _FX = {"0": "", "1": ", LN-folded", "2": ", plane residual", "6": ", plane residual + row stats",
+           "10": ", plane residual + post-norm in the epilogue"}
+    m = re.match(r"k_linear_x3q(_persist)?<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
     if m:   # <TM, WM, WN, EPI, OUTSPLIT, FX> -> tile and role
-        tm, wm, wn, epi, osp, fx = m.groups()
-        tile = "{}x{}".format(16 * int(tm) * int(wm), 64 * int(wn))
-    else:
-        m = re.match(r"k_linear_x3q_persist<(\d+), (\d+), (\d+)>", name)
-        if m:   # <EPI, OUTSPLIT, FX>
-            epi, osp, fx = m.groups()
-            tile = "256x256 persistent"
-    if m:
+        per, tm, wm, wn, epi, osp, fx = m.groups()
+        tile = "{}x{}{}".format(16 * int(tm) * int(wm), 64 * int(wn), " persistent" if per else "")
         role = {("0", "0"): "qkv", ("0", "1"): "qkv", ("2", "0"): "proj, fc2" if (fx or "0") == "0" else "fc2", ("2", "2"): "proj",
                 ("1", "2"): "fc1"}.get((epi, osp), "")
+        if fx == "10":
+            role = "fc2 + post-norm" + (", last block" if osp == "0" else "")
         return "k_linear_x3q<{}, {}, {}{}>{}".format(tile, _EPI[epi], _OUT[osp], _FX.get(fx or "0", ", fx" + str(fx)),
                                                    " (" + role + ")" if role else "")
     m = re.match(r"k_attn_temporal_x3<(\d+), (\d+)>", name)
