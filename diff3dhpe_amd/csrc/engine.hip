@@ -1059,6 +1059,41 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
     fprintf(stderr, "[gemm diag] N=%d K=%d v%d: waves %zu, in-kernel clock %.3f GHz, k-loop %.2f us, epilogue %.2f us (medians), "
             "kernel span %.1f us\n", N, K, variant, ghz.size(), med(ghz), med(loop_us), med(epi_us), (double)(rmax - rmin) * 0.01);
   }
+  if (getenv("D3D_GEMM_DIAG") && precision == D3D_PREC_F16X3 && variant == 0) {
+    // diagnostic: start / end stamps (100 MHz) of the persistent walk's workgroups -- how evenly do the CUs finish?
+    unsigned long long* dbuf = nullptr;
+    const size_t nwg = 1024;
+    HIP_TRY(hipMalloc(&dbuf, nwg * 2 * sizeof(unsigned long long)));
+    for (int i = 0; i < 20; ++i) HIP_TRY(once());
+    HIP_TRY(hipMemsetAsync(dbuf, 0, nwg * 2 * sizeof(unsigned long long), s));
+    set_linear_x3_diag(dbuf);
+    hipError_t le = once();
+    set_linear_x3_diag(nullptr);
+    HIP_TRY(le);
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(nwg * 2);
+    HIP_TRY(hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dbuf);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    size_t n = 0;
+    for (size_t i = 0; i < nwg; ++i)
+      if (h[2 * i]) { t0 = std::min(t0, h[2 * i]); t1 = std::max(t1, h[2 * i + 1]); ++n; }
+    if (n) {
+      std::vector<double> endv, xcd_end(8, 0.0);
+      for (size_t i = 0; i < nwg; ++i)
+        if (h[2 * i]) {
+          const double e = (double)(h[2 * i + 1] - t0) * 0.01;
+          endv.push_back(e);
+          xcd_end[i & 7] = std::max(xcd_end[i & 7], e);
+        }
+      std::sort(endv.begin(), endv.end());
+      fprintf(stderr, "[walk diag] N=%d K=%d: %zu workgroups, span %.1f us; workgroup end times (us after the first start): "
+              "min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f; last end per XCD:", N, K, n, (double)(t1 - t0) * 0.01,
+              endv.front(), endv[n / 10], endv[n / 2], endv[n * 9 / 10], endv.back());
+      for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", xcd_end[x]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (avg_ms) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));

@@ -260,7 +260,10 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
 #define D3D_ATTN_SYNC()                                                                     \
   do {                                                                                      \
     if (WAVEP) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
-    else __syncthreads();                                                                   \
+    else {                                                                                  \
+      __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), stated (see D3D_QKTILE in kernels_gemm_x3p.hip) */ \
+      __syncthreads();                                                                      \
+    }                                                                                       \
   } while (0)
   unsigned char* const sKh = lds;
   unsigned char* const sKl = lds + PLANE;

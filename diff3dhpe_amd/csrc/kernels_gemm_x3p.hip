@@ -805,7 +805,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
 // slices handled by split * rem <= gridDim workgroups (x3q_tile's sub_wm / g_lo / g_hi), so the round that would keep rem CUs
 // busy for a whole tile time keeps split * rem CUs busy for a fraction of it.  A slice runs the same MFMAs in the same
 // order for its rows as the whole tile would: values do not change.
-struct X3Walk { int nfull, rem, split; };
+struct X3Walk { int nfull, rem, split; unsigned long long* stamps; };   // stamps: diagnostic (100 MHz start / end per workgroup)
 
 template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
 __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
@@ -833,6 +833,14 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
   };
   const int nitems = wk.nfull + (b < wk.split * wk.rem ? 1 : 0);
   if (nitems == 0) return;
+  const unsigned long long t_begin = wk.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  auto stamp_end = [&]() {
+    if (wk.stamps && threadIdx.x == 0) {
+      __builtin_amdgcn_s_waitcnt(0);
+      wk.stamps[2 * b] = t_begin;
+      wk.stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
   // item k of this workgroup: a whole tile (k < nfull) or a slice of a tail tile
   auto item_of = [&](int k, int& mt, int& nt, int& sub_wm, int& g_lo, int& g_hi) {
     sub_wm = -1; g_lo = 0; g_hi = TM;
@@ -872,20 +880,26 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
     if (has_next) item_of(k + 1, mtn, ntn, swn, gln, ghn);
     x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, nullptr,
                                                   fx, has_next, mtn * BM, ntn * BN, tid_o);
-    if (!has_next) return;
+    if (!has_next) { stamp_end(); return; }
     ++k; mt = mtn; nt = ntn; sub_wm = swn; g_lo = gln; g_hi = ghn;
     __syncthreads();   // the epilogue's patches (stage 1) are read before the next tile's second k-tile is staged there
   }
   asm volatile("" : "+v"(tid_o));
   x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, nullptr, fx,
                                                       false, 0, 0, tid_o, sub_wm, g_lo, g_hi);
+  stamp_end();
 }
+
+// Diagnostic stamp buffer for the next launches (experiments/gemm_bench.py through d3d_op_linear_bench): variant 13 -> per-wave
+// k-loop / epilogue stamps; the persistent walk -> start / end per workgroup.
+static unsigned long long* g_x3_diag = nullptr;
 
 // walk of `tiles` tiles over `grid` persistent workgroups
 static X3Walk x3q_walk(int tiles, int grid) {
   static const bool split_on = getenv("D3D_X3_NO_TAILSPLIT") == nullptr;   // (switch for experiments/)
-  X3Walk w{tiles / grid, tiles % grid, 1};
-  if (split_on && w.rem > 0) w.split = 4 * w.rem <= grid ? 4 : (2 * w.rem <= grid ? 2 : 1);
+  X3Walk w{tiles / grid, tiles % grid, 1, g_x3_diag};
+  static const int max_split = getenv("D3D_X3_TAILSPLIT") ? atoi(getenv("D3D_X3_TAILSPLIT")) : 4;   // (experiments/)
+  if (split_on && w.rem > 0) w.split = (max_split >= 4 && 4 * w.rem <= grid) ? 4 : ((max_split >= 2 && 2 * w.rem <= grid) ? 2 : 1);
   return w;
 }
 
@@ -1085,8 +1099,6 @@ static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const 
   return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, 0, nullptr, fold);
 }
 
-// Diagnostic stamp buffer for the next variant-13 launches (experiments/gemm_bench.py through d3d_op_linear_bench).
-static unsigned long long* g_x3_diag = nullptr;
 void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }
 
 // variant: 0 = auto (launch_x3q_auto).  experiments only (gemm_bench.py, two_rank_repeat.sh via D3D_X3_VARIANT):
