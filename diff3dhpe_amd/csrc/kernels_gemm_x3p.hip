@@ -125,8 +125,67 @@ __device__ __forceinline__ float gelu_fast(float x) {
   p = __builtin_fmaf(p, t, -0.284496736f);
   p = __builtin_fmaf(p, t, 0.254829592f);
   const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
-  const float s = 0.5f * ax * (p * t) * e;
-  return __builtin_fmaxf(x, 0.0f) - s;
+  return __builtin_fmaf(-(0.5f * ax * (p * t)), e, __builtin_fmaxf(x, 0.0f));
+}
+
+// Two elements at a time: the epilogues are VALU-bound (the fc1 one: ~22 VALU instructions per output element, 13 us of a 52 us
+// tile), and gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on register pairs at the rate of the scalar forms.  Every
+// multiply-add is written as an explicit fma, in the order of the scalar code above, so that both give the same bits.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat2(float a) { return (f2)(a); }
+__device__ __forceinline__ f2 gelu_fast2(f2 x) {
+  f2 ax, t, e, m;
+  ax.x = __builtin_fabsf(x.x); ax.y = __builtin_fabsf(x.y);
+  const f2 z = ax * 0.70710678118654752440f;
+  const f2 den = fma2(splat2(0.3275911f), z, splat2(1.0f));
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  f2 p = fma2(splat2(1.061405429f), t, splat2(-1.453152027f));
+  p = fma2(p, t, splat2(1.421413741f));
+  p = fma2(p, t, splat2(-0.284496736f));
+  p = fma2(p, t, splat2(0.254829592f));
+  const f2 zz = z * z * -1.44269504088896340736f;
+  e.x = __builtin_amdgcn_exp2f(zz.x); e.y = __builtin_amdgcn_exp2f(zz.y);
+  m.x = __builtin_fmaxf(x.x, 0.0f); m.y = __builtin_fmaxf(x.y, 0.0f);
+  return fma2(-(splat2(0.5f) * ax * (p * t)), e, m);
+}
+// 8 values -> fp16 (hi, lo) of osc * v, clamped to the fp16 range
+__device__ __forceinline__ void split8_x3(const f2 (&v)[4], float osc, h8& oh, h8& ol) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f2 sc = v[e] * osc;
+    sc.x = __builtin_amdgcn_fmed3f(sc.x, -65504.0f, 65504.0f);
+    sc.y = __builtin_amdgcn_fmed3f(sc.y, -65504.0f, 65504.0f);
+    oh[2 * e] = (_Float16)sc.x;
+    oh[2 * e + 1] = (_Float16)sc.y;
+    f2 back;
+    back.x = (float)oh[2 * e]; back.y = (float)oh[2 * e + 1];
+    const f2 d = sc - back;
+    ol[2 * e] = (_Float16)d.x;
+    ol[2 * e + 1] = (_Float16)d.y;
+  }
+}
+// (sum, sum of squares) of 8 values
+__device__ __forceinline__ void sums8(const f2 (&v)[4], float& sm, float& sq) {
+  const f2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
+  const f2 q2 = fma2(v[0], v[0], v[1] * v[1]) + fma2(v[2], v[2], v[3] * v[3]);
+  sm = s2.x + s2.y;
+  sq = q2.x + q2.y;
+}
+__device__ __forceinline__ void load8(const float* p, f2 (&o)[4]) {
+  const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + 4);
+  o[0].x = t0.x; o[0].y = t0.y; o[1].x = t0.z; o[1].y = t0.w; o[2].x = t1.x; o[2].y = t1.y; o[3].x = t1.z; o[3].y = t1.w;
+}
+// 8 fp16 (hi) + 8 fp16 (lo) of 8 r -> r
+__device__ __forceinline__ void unsplit8(const uint4 rh, const uint4 rl, f2 (&o)[4]) {
+  const h8 hh = __builtin_bit_cast(h8, rh), ll = __builtin_bit_cast(h8, rl);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f2 hf, lf;
+    hf.x = (float)hh[2 * e]; hf.y = (float)hh[2 * e + 1];
+    lf.x = (float)ll[2 * e]; lf.y = (float)ll[2 * e + 1];
+    o[e] = hf + lf;
+  }
 }
 
 // FX flags of the folded forms (X3Fold in d3d_kernels.h)
@@ -294,17 +353,11 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
   const int n = nt0 + 8 * rc8;
   const bool ncol_ok = !CHECK || n < N;
-  float bb[8], cs[8];
+  f2 bb[4], cs[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { bb[e] = 0.f; cs[e] = 0.f; }
-  if (bias && ncol_ok) {
-    const float4 t0 = *reinterpret_cast<const float4*>(bias + n), t1 = *reinterpret_cast<const float4*>(bias + n + 4);
-    bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
-  }
-  if ((FX & FX_LNF) && ncol_ok) {
-    const float4 t0 = *reinterpret_cast<const float4*>(csum + n), t1 = *reinterpret_cast<const float4*>(csum + n + 4);
-    cs[0] = t0.x; cs[1] = t0.y; cs[2] = t0.z; cs[3] = t0.w; cs[4] = t1.x; cs[5] = t1.y; cs[6] = t1.z; cs[7] = t1.w;
-  }
+  for (int e = 0; e < 4; ++e) { bb[e] = splat2(0.f); cs[e] = splat2(0.f); }
+  if (bias && ncol_ok) load8(bias + n, bb);
+  if ((FX & FX_LNF) && ncol_ok) load8(csum + n, cs);
   const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
   const int pc = (int)pair_col(8 * rc8);
   const float2* srow = reinterpret_cast<const float2*>(lds_x);
@@ -351,34 +404,34 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       const float* prow = patch + (i & 1) * 1024 + row * 64;
       const float4 a0 = *reinterpret_cast<const float4*>(prow + (((2 * rc8) ^ (row & 7)) << 2));
       const float4 a1 = *reinterpret_cast<const float4*>(prow + (((2 * rc8 + 1) ^ (row & 7)) << 2));
-      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      f2 a[4];
+      a[0].x = a0.x; a[0].y = a0.y; a[1].x = a0.z; a[1].y = a0.w; a[2].x = a1.x; a[2].y = a1.y; a[3].x = a1.z; a[3].y = a1.w;
       const int m = mt0 + 16 * i + row;
       const bool ok = !CHECK || (m < M && ncol_ok);
       if (!(FX & FX_SO) && !ok) continue;
-      float v[8];
+      f2 v[4];
       if (FX & FX_LNF) {
         const float2 st = srow[rbase + 16 * i + row];
+        const f2 sx = splat2(st.x), sy = splat2(st.y);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaf(st.x, a[e] * P_OUT_SCALE, fmaf(st.y, cs[e], bb[e]));
+        for (int e = 0; e < 4; ++e) v[e] = fma2(sx, a[e] * P_OUT_SCALE, fma2(sy, cs[e], bb[e]));
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = a[e] * P_OUT_SCALE + bb[e];
+        for (int e = 0; e < 4; ++e) v[e] = fma2(a[e], splat2(P_OUT_SCALE), bb[e]);
       }
       if (EPI == EPI_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_fast2(v[e]);
       }
       if (EPI == EPI_RESIDUAL) {
-        const h8 hh = __builtin_bit_cast(h8, rh[i][p]), ll = __builtin_bit_cast(h8, rl[i][p]);
+        f2 r8[4];
+        unsplit8(rh[i][p], rl[i][p], r8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ((float)hh[e] + (float)ll[e]) * 0.125f + v[e];
+        for (int e = 0; e < 4; ++e) v[e] = fma2(r8[e], splat2(0.125f), v[e]);
       }
       if (FX & FX_SO) {
         float sm = 0.f, sq = 0.f;
-        if (ok) {
-          sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-          sq = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
-        }
+        if (ok) sums8(v, sm, sq);
         sm = row8_sum(sm);
         sq = row8_sum(sq);
         if (rc8 == 0 && m < M) *reinterpret_cast<float2*>(st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
@@ -386,12 +439,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       }
       if (OUTSPLIT) {
         h8 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float sc = __builtin_amdgcn_fmed3f(v[e] * osc, -65504.0f, 65504.0f);
-          oh[e] = (_Float16)sc;
-          ol[e] = (_Float16)(sc - (float)oh[e]);
-        }
+        split8_x3(v, osc, oh, ol);
         if (OUTSPLIT == 2) {
           *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep)) = oh;
           *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep) + 64u) = ol;
@@ -400,8 +448,8 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
           *reinterpret_cast<h8*>(Clb + (obh + (unsigned)(2 * i + p) * rsteph)) = ol;
         }
       } else {
-        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep)) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
       }
     }
    }
@@ -429,11 +477,8 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
   const int n = nt0 + 8 * rc8;
-  float bb[8];
-  {
-    const float4 t0 = *reinterpret_cast<const float4*>(bias + n), t1 = *reinterpret_cast<const float4*>(bias + n + 4);
-    bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
-  }
+  f2 bb[4];
+  load8(bias + n, bb);
   const int pc = (int)pair_col(8 * rc8);
   constexpr int PF = TM < 3 ? TM : 3;                                  // residual window, see x3q_epilogue
   const unsigned ob = (unsigned)(rrow * N + 8 * rc8) * 4u;            // this lane's 8 floats in row rrow (fp32 buffer)
@@ -459,7 +504,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
 #pragma unroll
   for (int i = 0; i < PF; ++i) load_res(i);
   __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
-  float vv[TM][2][8];
+  f2 vv[TM][2][4];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
    if (i >= gl && i < gh) {
@@ -473,24 +518,26 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
       const float* prow = patch + (i & 1) * 1024 + row * 64;
       const float4 a0 = *reinterpret_cast<const float4*>(prow + (((2 * rc8) ^ (row & 7)) << 2));
       const float4 a1 = *reinterpret_cast<const float4*>(prow + (((2 * rc8 + 1) ^ (row & 7)) << 2));
-      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      f2 a[4], r8[4];
+      a[0].x = a0.x; a[0].y = a0.y; a[1].x = a0.z; a[1].y = a0.w; a[2].x = a1.x; a[2].y = a1.y; a[3].x = a1.z; a[3].y = a1.w;
       const bool ok = !CHECK || mt0 + 16 * i + row < M;
-      const h8 hh = __builtin_bit_cast(h8, rh[i][p]), ll = __builtin_bit_cast(h8, rl[i][p]);
-      float* v = vv[i][p];
+      unsplit8(rh[i][p], rl[i][p], r8);
+      f2 (&v)[4] = vv[i][p];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = ((float)hh[e] + (float)ll[e]) * 0.125f + (a[e] * P_OUT_SCALE + bb[e]);
-        if (CHECK && !ok) v[e] = 0.0f;
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fma2(r8[e], splat2(0.125f), fma2(a[e], splat2(P_OUT_SCALE), bb[e]));
+        if (CHECK && !ok) v[e] = splat2(0.0f);
       }
       // this wave's 64 columns of the row: sum, and sum of squared deviations from their own mean (combined below by the
       // pairwise update formula -- as accurate as a two-pass variance, with one exchange)
-      const float sm = row8_sum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
-      const float lm = sm * (1.0f / 64.0f);
-      float d[8];
+      const f2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
+      const float sm = row8_sum(s2.x + s2.y);
+      const f2 lm = splat2(sm * (1.0f / 64.0f));
+      f2 d[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d[e] = v[e] - lm;
-      const float sq = row8_sum(((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) +
-                                ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7])));
+      for (int e = 0; e < 4; ++e) d[e] = v[e] - lm;
+      const f2 q2 = fma2(d[0], d[0], d[1] * d[1]) + fma2(d[2], d[2], d[3] * d[3]);
+      const float sq = row8_sum(q2.x + q2.y);
       if (rc8 == 0) *reinterpret_cast<float2*>(xch + 2 * ((16 * i + row) * WN + wn)) = make_float2(sm, sq);
     }
    }
@@ -498,21 +545,14 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
     __builtin_amdgcn_sched_barrier(0);
   }
   const float invn = 1.0f / (float)N;
-  float gg[8], be[8], tv[8];
-  {
-    const float4 t0 = *reinterpret_cast<const float4*>(fx.pn.g + n), t1 = *reinterpret_cast<const float4*>(fx.pn.g + n + 4);
-    gg[0] = t0.x; gg[1] = t0.y; gg[2] = t0.z; gg[3] = t0.w; gg[4] = t1.x; gg[5] = t1.y; gg[6] = t1.z; gg[7] = t1.w;
-    const float4 u0 = *reinterpret_cast<const float4*>(fx.pn.b + n), u1 = *reinterpret_cast<const float4*>(fx.pn.b + n + 4);
-    be[0] = u0.x; be[1] = u0.y; be[2] = u0.z; be[3] = u0.w; be[4] = u1.x; be[5] = u1.y; be[6] = u1.z; be[7] = u1.w;
-  }
+  f2 gg[4], be[4], tv[4];
+  load8(fx.pn.g + n, gg);
+  load8(fx.pn.b + n, be);
   const bool tv_uniform = fx.pn.tvec != nullptr && fx.pn.tvec_stride == 0;
   const bool tv_rows = fx.pn.tvec != nullptr && fx.pn.tvec_stride != 0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) tv[e] = 0.0f;
-  if (tv_uniform) {
-    const float4 t0 = *reinterpret_cast<const float4*>(fx.pn.tvec + n), t1 = *reinterpret_cast<const float4*>(fx.pn.tvec + n + 4);
-    tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
-  }
+  for (int e = 0; e < 4; ++e) tv[e] = splat2(0.0f);
+  if (tv_uniform) load8(fx.pn.tvec + n, tv);
   const int npart = N >> 6;
   __syncthreads();
 #pragma unroll
@@ -530,42 +570,39 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
                   e6 = p3.x * (1.0f / 64.0f) - mean, e7 = p3.z * (1.0f / 64.0f) - mean;
       const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
                        64.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
-      const float rstd = 1.0f / sqrtf(m2 * invn + fx.pn.eps);
-      float* v = vv[i][p];
+      const f2 rstd = splat2(1.0f / sqrtf(m2 * invn + fx.pn.eps)), mean2 = splat2(mean);
+      f2 (&v)[4] = vv[i][p];
       if (CHECK && m >= M) continue;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+      for (int e = 0; e < 4; ++e) v[e] = fma2((v[e] - mean2) * rstd, gg[e], be[e]);
       if (fx.pn.pos) {
-        const float* pr = fx.pn.pos + (size_t)((m / fx.pn.pos_div) % fx.pn.pos_mod) * N + n;
-        const float4 t0 = *reinterpret_cast<const float4*>(pr), t1 = *reinterpret_cast<const float4*>(pr + 4);
-        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+        f2 t[4];
+        load8(fx.pn.pos + (size_t)((m / fx.pn.pos_div) % fx.pn.pos_mod) * N + n, t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += t[e];
       }
       if (tv_rows) {
-        const float* tr = fx.pn.tvec + (size_t)(m / fx.pn.rows_per_batch) * fx.pn.tvec_stride + n;
-        const float4 t0 = *reinterpret_cast<const float4*>(tr), t1 = *reinterpret_cast<const float4*>(tr + 4);
-        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+        f2 t[4];
+        load8(fx.pn.tvec + (size_t)(m / fx.pn.rows_per_batch) * fx.pn.tvec_stride + n, t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += t[e];
       } else if (tv_uniform) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += tv[e];
+        for (int e = 0; e < 4; ++e) v[e] += tv[e];
       }
       if (OUTSPLIT == 2) {
-        float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        float sq = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        float sm, sq;
+        sums8(v, sm, sq);
         sm = row8_sum(sm);
         sq = row8_sum(sq);
         if (rc8 == 0) *reinterpret_cast<float2*>(fx.st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
         h8 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float sc = __builtin_amdgcn_fmed3f(v[e] * P_A_SCALE, -65504.0f, 65504.0f);
-          oh[e] = (_Float16)sc;
-          ol[e] = (_Float16)(sc - (float)oh[e]);
-        }
+        split8_x3(v, P_A_SCALE, oh, ol);
         *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep)) = oh;
         *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep) + 64u) = ol;
       } else {
-        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep)) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -756,7 +793,8 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     done = true;
   } else if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
     if ((N & 7) == 0) {
-      if (full)
+      // (the row-statistics form keeps one, checked, copy: with two copies under the branch its accumulators spill)
+      if (full && !(FX & FX_SO))
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
                                                            mt0 - m0, lane, M, N, qcols, gl, gh);
       else
