@@ -256,7 +256,16 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   constexpr int TP = 32 * NKT;
   constexpr int PLANE = TP * 128;
   constexpr bool WAVEP = MU > 1;
-  unsigned char* const lds = lds_all + (WAVEP ? (int)(threadIdx.x >> 6) * 4 * PLANE : 0);
+  // WAVEP: the V planes are double-buffered (6 planes per wave), so that K, V and Q of unit u+1 are all requested at the
+  // middle of unit u and awaited ONCE, at the top of unit u+1: with 4 planes a wave had one of K / V in flight at a time,
+  // each hidden only by half a unit of arithmetic, and the launch ran at the latency x concurrency limit (3.9 TB/s)
+  // -- and its planes hold T rows, not TP: a fragment read of the pad rows [T, TP) runs on into the next plane (the next
+  // wave's slice, a zeroed tail behind the last one).  That is harmless: whatever finite fp16 values stand there, the
+  // scores of keys >= T are overwritten with -inf before the softmax and their E is an exact 0 in the PV product; the whole
+  // allocation is zeroed once so that nothing non-finite is ever read.  13 KiB per wave instead of 24.
+  constexpr int NPL = WAVEP ? 6 : 4;
+  const int PL = WAVEP ? T * 128 : PLANE;         // plane stride in bytes
+  unsigned char* const lds = lds_all + (WAVEP ? (int)(threadIdx.x >> 6) * NPL * PL : 0);
 #define D3D_ATTN_SYNC()                                                                     \
   do {                                                                                      \
     if (WAVEP) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
@@ -266,9 +275,10 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     }                                                                                       \
   } while (0)
   unsigned char* const sKh = lds;
-  unsigned char* const sKl = lds + PLANE;
-  unsigned char* const sVh = lds + 2 * PLANE;
-  unsigned char* const sVl = lds + 3 * PLANE;
+  unsigned char* const sKl = lds + PL;
+  unsigned char* sVh = lds + 2 * PL;
+  unsigned char* sVl = lds + 3 * PL;
+  int vb = 0;                                     // WAVEP: V buffer of the current unit
   const int tid = WAVEP ? (int)(threadIdx.x & 63) : (int)threadIdx.x;     // thread index within the unit
   const int wave = WAVEP ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // 32-query tile of the unit
   // lane index behind an opaque barrier, refreshed every iteration: all per-lane LDS / global offsets are then re-derived
@@ -279,26 +289,34 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   const int D3 = 3 * D;
   int u = WAVEP ? (int)(blockIdx.x * MU + (threadIdx.x >> 6)) : (int)blockIdx.x;
   const int ustep = (int)gridDim.x * MU;
+  if (WAVEP) {   // zero the whole allocation (all waves, before any of them leaves or reads)
+    const int total16 = (MU * NPL * PL + (TP - T) * 128) >> 4;
+    for (int idx = (int)threadIdx.x; idx < total16; idx += 64 * MU) reinterpret_cast<uint4*>(lds_all)[idx] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
   if (u >= units) return;     // wave-uniform (workgroup-uniform when MU == 1)
 
-  // pad rows [T, TP) of all four planes: zero once, the DMA never writes them (their lanes are masked off)
-  for (int idx = tid; idx < (TP - T) * 8 * 4; idx += 64 * NKT) {   // (the unit's own threads: 64 * NKT)
-    const int pl = idx / ((TP - T) * 8), rem = idx % ((TP - T) * 8);
-    *reinterpret_cast<uint4*>(lds + pl * PLANE + (T + (rem >> 3)) * 128 + ((rem & 7) << 4)) = make_uint4(0, 0, 0, 0);
+  if (!WAVEP) {   // pad rows [T, TP) of all four planes: zero once, the DMA never writes them (their lanes are masked off)
+    for (int idx = tid; idx < (TP - T) * 8 * NPL; idx += 64 * NKT) {   // (the unit's own threads: 64 * NKT)
+      const int pl = idx / ((TP - T) * 8), rem = idx % ((TP - T) * 8);
+      *reinterpret_cast<uint4*>(lds + pl * PLANE + (T + (rem >> 3)) * 128 + ((rem & 7) << 4)) = make_uint4(0, 0, 0, 0);
+    }
   }
 
   // DMA plan: a plane is TP/8 = 4*NKT pieces of 8 rows x 128 B; wave w moves pieces w, w + NKT, w + 2 NKT, w + 3 NKT of each
   // plane.  Lane l serves row 8*piece + l/8, LDS slot l%8, and fetches the source chunk the swizzle maps to that slot.
-  auto dma = [&](int which, size_t tok0, int hd) {   // which: 1 = K, 2 = V
+  auto dma = [&](int which, size_t tok0, int hd, int vbuf = 0) {   // which: 1 = K, 2 = V (into V buffer vbuf)
     const int drow = lane >> 3, dslot = lane & 7;
+    unsigned char* const dVh = lds + (2 + 2 * vbuf) * PL;
+    unsigned char* const dVl = dVh + PL;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int piece = wave + NKT * it;
       const int row = 8 * piece + drow;
       const int chunk = (which == 1) ? (dslot ^ ((row >> 1) & 7)) : (dslot ^ vkey(row));
       const size_t o = (tok0 + (size_t)row * J) * D3 + (size_t)which * D + hd * XDH + chunk * 8;
-      unsigned char* dh = (which == 1 ? sKh : sVh) + piece * 1024;
-      unsigned char* dl = (which == 1 ? sKl : sVl) + piece * 1024;
+      unsigned char* dh = (which == 1 ? sKh : dVh) + piece * 1024;
+      unsigned char* dl = (which == 1 ? sKl : dVl) + piece * 1024;
       if (row < T) {
         __builtin_amdgcn_global_load_lds(Ph + o, (__attribute__((address_space(3))) void*)(uintptr_t)dh, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(Pl + o, (__attribute__((address_space(3))) void*)(uintptr_t)dl, 16, 0, 0);
@@ -325,6 +343,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   size_t tok0;
   unit_of(u, hd, tok0);
   dma(1, tok0, hd);
+  if (WAVEP) dma(2, tok0, hd, 0);
   load_q(tok0, hd);
   h4 po_h[8], po_l[8];          // packed outputs of the previous unit, stored one barrier later
   size_t po_off = 0;
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     D3D_ATTN_SYNC();            // K(u), Q(u) landed; V region free
     asm volatile("" : "+v"(lane));
     r = lane & 31; h = lane >> 5; tq = 32 * wave + r;
-    dma(2, tok0, hd);
+    if (!WAVEP) dma(2, tok0, hd);
     if (po_valid && tq < T) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -388,7 +407,8 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
       }
     l += __shfl_xor(l, 32, 64);
 
-    D3D_ATTN_SYNC();            // V(u) landed (and the stores above acknowledged); everybody is done with K
+    if (WAVEP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's K fragments are in registers
+    else D3D_ATTN_SYNC();       // V(u) landed (and the stores above acknowledged); everybody is done with K
     const int un = u + ustep;
     const bool has_next = un < units;     // workgroup-uniform
     int hd_n = 0;
@@ -396,6 +416,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     if (has_next) {
       unit_of(un, hd_n, tok0_n);
       dma(1, tok0_n, hd_n);
+      if (WAVEP) dma(2, tok0_n, hd_n, vb ^ 1);   // (that buffer was last read by unit u-1)
     }
 
     // ---- O^T[d][query] = sum_key V^T[d][key] E^T[key][query]
@@ -470,6 +491,11 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     }
     if (!has_next) break;
     u = un; hd = hd_n; tok0 = tok0_n;
+    if (WAVEP) {
+      vb ^= 1;
+      sVh = lds + (2 + 2 * vb) * PL;
+      sVl = sVh + PL;
+    }
   }
 #undef D3D_ATTN_SYNC
   // outputs of the last unit
@@ -508,12 +534,13 @@ static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16
 template <int NKT, int MU = 1>
 static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H,
                                  hipStream_t s) {
-  const size_t lds_bytes = (size_t)MU * 4 * 32 * NKT * 128;
+  // wave-private units (MU > 1, NKT == 1): 6 planes of T rows per wave (V double-buffered) + one zeroed pad behind the last
+  const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 : (size_t)4 * 32 * NKT * 128;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, MU > 1 ? 160 * 1024 : (int)lds_bytes);
     if (e != hipSuccess) return e;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -522,7 +549,7 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
     attr_set = true;
   }
   const long long units = (long long)B * J * H;
-  if (units > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (units > 0x7fffffffLL || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;   // resident workgroups per CU
   const long long wgs = (units + MU - 1) / MU;
   const long long grid = wgs < (long long)n_cu * per_cu ? wgs : (long long)n_cu * per_cu;
@@ -544,7 +571,11 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
     case 1:   // groups of <= 32 tokens (spatial blocks: the 17 joints of a frame).  8 units per workgroup = the 8 heads of one
               // frame at H = 8, so a workgroup reads whole token rows; measured 0.61 ms per launch at T=243, B=64 against
               // 0.82 / 0.68 / 0.69 ms with 1 / 2 / 4 units per workgroup.
-      if ((long long)B * J * H >= 4096 && !no_persist) return launch_x3p_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
+      if ((long long)B * J * H >= 4096 && !no_persist && (size_t)8 * 6 * T * 128 + (size_t)(32 - T) * 128 <= 160 * 1024) {
+        static const int mu = getenv("D3D_ATTN_MU") ? atoi(getenv("D3D_ATTN_MU")) : 8;   // (experiments/)
+        if (mu == 12 && (size_t)12 * 6 * T * 128 + (size_t)(32 - T) * 128 <= 160 * 1024) return launch_x3p_nkt<1, 12>(ph, pl, ox, B, T, J, D, H, s);
+        return launch_x3p_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
+      }
       if ((long long)B * J * H >= 4096) return launch_x3_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
       return launch_x3_nkt<1, 1>(ph, pl, ox, B, T, J, D, H, s);
     case 2: return launch_x3_nkt<2>(ph, pl, ox, B, T, J, D, H, s);

@@ -4,7 +4,7 @@
 other=$1; reps=${2:-2}
 cur=diff3dhpe_amd/libd3d_hip.so
 cp $cur /tmp/_lib_cur.so
-run() { python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-selfcheck | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['by_kernel_ms_per_step']['linear'])"; }
+run() { python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-selfcheck | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline']['by_kernel_ms_per_step']; print(d['value'], k['linear'], k['attn_spatial'], k['attn_temporal'])"; }
 for r in $(seq $reps); do
   cp /tmp/_lib_cur.so $cur; a=$(run)
   cp $other $cur; b=$(run)
