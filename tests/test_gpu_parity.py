@@ -240,6 +240,25 @@ def test_engine_matches_oracle_on_fresh_seeded_inputs():
         assert maxabs(y0, ref) <= GATE
 
 
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_engine_matches_oracle_on_other_widths(prec):
+    """Widths and ratios the golden fixtures do not hold.  In F16X3 mode D=256 / 4 heads runs the plane-resident, LayerNorm-folded
+    flow WITHOUT the post-norm GEMM form (that exists for D=512 only: fc2 -> fp32 -> row kernel); D=512 with mlp_ratio 4
+    runs the post-norm form over K=2048; 2 heads of 64 is the narrowest width the fp16-MFMA attention takes."""
+    from oracle import d3d_oracle as orc
+    from diff3dhpe_amd.spec import DenoiserConfig
+    for cfg, B, S in ((DenoiserConfig(num_frame=27, embed_dim=256, depth=4, num_heads=4), 3, 3),
+                      (DenoiserConfig(num_frame=9, embed_dim=512, depth=2, mlp_ratio=4.0), 2, 2),
+                      (DenoiserConfig(num_frame=27, embed_dim=128, depth=2, num_heads=2), 2, 3)):
+        _, diff = build_product(cfg, 47, sampling=S, precision=prec)
+        inp = inputs(B, cfg.num_frame, 556)
+        _, y0 = diff(clean_3d_pose=torch.zeros_like(inp["noise"]).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False,
+                     init_noise=inp["noise"].cuda())
+        ref = orc.ddim_sample_loop(torch_sd(cfg, 47), orc.diffusion_tables("cosine", 1000), inp["x2d"], inp["noise"],
+                                   num_timesteps=1000, sampling_timesteps=S, depth=cfg.depth, heads=cfg.num_heads)
+        assert maxabs(y0, ref) <= GATE, (cfg.embed_dim, cfg.num_heads, cfg.mlp_ratio)
+
+
 def test_evaluate_harness_flip_tta():
     from diff3dhpe_amd.evaluate import evaluate, flip_2d, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
     from oracle import d3d_oracle as orc
