@@ -16,6 +16,13 @@ enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 //   hi at r * 2K + pair_col(c),   lo at r * 2K + pair_col(c) + PAIR_LO.
 constexpr int PAIR_LO = 32;
 __host__ __device__ __forceinline__ size_t pair_col(int c) { return (size_t)((c >> 5) << 6) + (size_t)(c & 31); }
+// "Accumulator order" variant of the pair layout (the hidden activation fc1 -> fc2 only): inside every 32-column group
+// column 16 jj + 4 q + r sits in slot 8 q + 4 jj + r, so that the 8 values a lane of the C^T accumulator layout holds of a
+// group (q = lane / 16) are one 16-byte piece.  Legal for a GEMM operand because the consumer's weight uses the same order.
+__host__ __device__ __forceinline__ size_t pair_col_acc(int c) {
+  const int w = c & 31;
+  return (size_t)((c >> 5) << 6) + (size_t)(8 * ((w & 15) >> 2) + 4 * (w >> 4) + (w & 3));
+}
 
 // ---- kernels_gemm.hip -------------------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); all row-major fp32, K % 32 == 0.
@@ -27,7 +34,7 @@ hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, 
 // split_weight_f16x3() ([rows][2*cols] fp16 of 4096*w).
 hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* bias, const float* R, float* C, int M, int N,
                                int K, int epi, hipStream_t s);
-void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair);
+void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order = false);
 
 // ---- kernels_gemm_x3p.hip ---------------------------------------------------------------------------------------
 // F16X3 with pre-split operands in the pair layout: A (>= ceil(M/256)*256 rows allocated), W (>= ceil(N/256)*256 rows).

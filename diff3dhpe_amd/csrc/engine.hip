@@ -617,9 +617,9 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     size_t o = 0;
     for (int k = 0; k < e->nblk; ++k) {
       const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2);
-      auto pair = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& dst) {
+      auto pair = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& dst, bool acc_order = false) {
         const WeightSlot& ws = e->slots[e->index[name]];
-        split_weight_f16x3(ws.host.data(), rows, cols, host.data() + o);
+        split_weight_f16x3(ws.host.data(), rows, cols, host.data() + o, acc_order);
         dst = e->arena16 + o;
         o += 2 * pad256(rows) * cols;
       };
@@ -627,7 +627,7 @@ int d3d_engine_commit_weights(d3d_engine* e) {
       pair(p + ".attn.qkv.weight", 3 * D, D, b.qkv_x3);
       pair(p + ".attn.proj.weight", D, D, b.proj_x3);
       pair(p + ".mlp.fc1.weight", Dm, D, b.fc1_x3);
-      pair(p + ".mlp.fc2.weight", D, Dm, b.fc2_x3);
+      pair(p + ".mlp.fc2.weight", D, Dm, b.fc2_x3, true);   // its A operand (the hidden activation) is in accumulator order
       // LayerNorm folded into the consuming GEMM: LN(x) W^T + b = rstd (x (W diag g)^T) - rstd mean csum + (b + W beta)
       auto folded = [&](const std::string& wname, const std::string& bname, const std::string& norm, size_t rows, size_t cols,
                         const uint16_t*& w3, const float*& cs, const float*& fb) {

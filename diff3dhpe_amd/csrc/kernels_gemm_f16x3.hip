@@ -210,7 +210,9 @@ hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* b
 
 // Host-side weight split: w [rows, cols] -> pair layout (d3d_kernels.h) of hi/lo fp16 of s*w with s = 2^12
 // (round-to-nearest-even both times).
-void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair) {
+// acc_order: the k index of every 32-column group is stored in the order pair_slot_acc() gives it (the layout of the
+// hidden activation that the fc1 epilogue writes straight from its accumulators, kernels_gemm_x3p.hip)
+void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order) {
   for (size_t r = 0; r < rows; ++r)
     for (size_t c = 0; c < cols; ++c) {
       float s = w[r * cols + c] * 4096.0f;
@@ -218,7 +220,7 @@ void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair
       if (s < -65504.0f) s = -65504.0f;
       const _Float16 h = (_Float16)s;
       const _Float16 l = (_Float16)(s - (float)h);
-      uint16_t* o = pair + r * 2 * cols + pair_col((int)c);
+      uint16_t* o = pair + r * 2 * cols + (acc_order ? pair_col_acc((int)c) : pair_col((int)c));
       __builtin_memcpy(o, &h, 2);
       __builtin_memcpy(o + PAIR_LO, &l, 2);
     }

@@ -462,6 +462,73 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   }
 }
 
+// GELU + pair output straight from the accumulators (fc1 -> hidden activation).  The hidden activation is only ever the A
+// operand of the fc2 GEMM, so its k order inside a 32-column group is free: "accumulator order" (pair_col_acc, d3d_kernels.h;
+// the fc2 weight is split in the same order at commit) makes the 8 values a lane holds of a group one 16-byte piece.  No LDS
+// transpose, no barrier: lane (m = lane & 15, q = lane >> 4) owns row 16 i + m of m-tile i and columns 16 j + 4 q + r.
+template <int TM, int WM, int WN, int FX, bool CHECK>
+__device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned char* lds_x, const float* __restrict__ bias,
+                                                 _Float16* Cht, const float* __restrict__ csum, int mt0, int nt0, int rbase, int lane,
+                                                 int M, int N, int gl, int gh) {
+  const int m16 = lane & 15, q4 = lane >> 4;
+  f2 bb[4][2], cs[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = nt0 + 16 * j + 4 * q4;
+    bb[j][0] = bb[j][1] = cs[j][0] = cs[j][1] = splat2(0.f);
+    if (!CHECK || n < N) {
+      if (bias) {
+        const float4 t = *reinterpret_cast<const float4*>(bias + n);
+        bb[j][0].x = t.x; bb[j][0].y = t.y; bb[j][1].x = t.z; bb[j][1].y = t.w;
+      }
+      if (FX & FX_LNF) {
+        const float4 t = *reinterpret_cast<const float4*>(csum + n);
+        cs[j][0].x = t.x; cs[j][0].y = t.y; cs[j][1].x = t.z; cs[j][1].y = t.w;
+      }
+    }
+  }
+  const float2* srow = reinterpret_cast<const float2*>(lds_x);
+  char* Chb = reinterpret_cast<char*>(Cht);
+  const unsigned ob = (unsigned)(m16 * 2 * N + 8 * q4) * 2u;        // row m16, piece q4 of the wave's first group (hi; lo 64 B on)
+  const unsigned rstep = (unsigned)N * 64u;                          // 16 rows of the pair buffer
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i < gl || i >= gh) continue;
+    const int row = 16 * i + m16;
+    if (CHECK && mt0 + row >= M) continue;
+    f2 sx = splat2(1.f), sy = splat2(0.f);
+    if (FX & FX_LNF) {
+      const float2 st = srow[rbase + row];
+      sx = splat2(st.x); sy = splat2(st.y);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (CHECK && nt0 + 32 * c >= N) continue;
+      f2 v[4];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * c + jj;
+        f2 a0, a1;
+        a0.x = acc[i][j][0]; a0.y = acc[i][j][1]; a1.x = acc[i][j][2]; a1.y = acc[i][j][3];
+        if (FX & FX_LNF) {   // LN(x) W^T + b = rstd (x W'^T) - rstd mean csum + b'
+          v[2 * jj] = fma2(sx, a0 * P_OUT_SCALE, fma2(sy, cs[j][0], bb[j][0]));
+          v[2 * jj + 1] = fma2(sx, a1 * P_OUT_SCALE, fma2(sy, cs[j][1], bb[j][1]));
+        } else {
+          v[2 * jj] = fma2(a0, splat2(P_OUT_SCALE), bb[j][0]);
+          v[2 * jj + 1] = fma2(a1, splat2(P_OUT_SCALE), bb[j][1]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_fast2(v[e]);
+      h8 oh, ol;
+      split8_x3(v, P_A_SCALE, oh, ol);
+      *reinterpret_cast<h8*>(Chb + (ob + (unsigned)i * rstep + (unsigned)c * 128u)) = oh;
+      *reinterpret_cast<h8*>(Chb + (ob + (unsigned)i * rstep + (unsigned)c * 128u) + 64u) = ol;
+    }
+    if (i & 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Post-norm epilogue (FX_PN): the workgroup's tile is BM full rows (WM == 1, N == 64 WN), so the block's post-norm
 //   y = LN(r + a W^T + b) [+ pos] [+ tvec]      (launch_layernorm's operations, two-pass variance)
 // is applied before the rows leave the chip -- the fp32 round trip through HBM and the row kernel's launch are gone.
@@ -790,6 +857,13 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     float* xch = reinterpret_cast<float*>(lds + STAGE + 65536);
     // (one instantiation, row checks always on: with a checked and an unchecked copy under a branch the accumulators spill)
     x3q_epilogue_pn<TM, WN, OUTSPLIT, true>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N, gl, gh);
+    done = true;
+  } else if constexpr (EPI == EPI_GELU && OUTSPLIT == 2) {   // hidden activation, accumulator order: no transpose
+    static_assert(!(FX & (FX_RP | FX_SO)), "fc1 form");
+    if (full)
+      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
+    else
+      x3q_epilogue_acc<TM, WM, WN, FX, true>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
     done = true;
   } else if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
     if ((N & 7) == 0) {
