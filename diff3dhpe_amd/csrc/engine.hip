@@ -258,8 +258,9 @@ int attention(d3d_engine* e, const float* qkv, float* out, void* out_x3, int B, 
 // F16X3 production flow ("plane-resident, LayerNorm-folded"): the residual stream lives in the GEMM operand (pair) layout
 // in w.X, so it is at once the A operand of the qkv / fc1 GEMMs and the residual input of the proj / fc2 epilogues; norm1
 // and norm2 are folded into those two GEMMs (X3Fold), their row statistics coming from the producer of the stream (the
-// post-norm kernel, resp. the proj epilogue).  Per block only ONE stand-alone row kernel remains (post-norm of the fc2
-// output, read as fp32 from w.HN), against two LayerNorm kernels and three extra passes over the stream before.
+// fc2 epilogue, resp. the proj epilogue).  The block's post-norm runs inside the fc2 epilogue (X3PostNorm: whole-row tiles,
+// D == 512); for other widths the fc2 output goes to w.HN as fp32 and one stand-alone row kernel per block applies it.
+// The hidden activation (w.HID) is in "accumulator order" (pair_col_acc), matched by the fc2 weight split at commit.
 // Same op sequence as run_blocks (S2S:222-247, 111-135); leaves the final Temporal_norm output as fp32 in w.X.
 int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast, const float* tvec, int64_t tvec_stride,
                     int B, const Workspace& w, hipStream_t s) {

@@ -219,8 +219,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
   // [gl, gh): the wave's m-tiles that are computed (all of them except in a split tail tile, x3q_tile)
   // patch: two wave-private 16 rows x 64 floats (alternating, so the LDS round trip of one m-tile overlaps the stores
   // of the previous one), 16-byte chunks XOR-swizzled by (row & 7)
-  constexpr int BM = 16 * TM * WM;
-  const int m16 = lane & 15, q4 = lane >> 4;
+    const int m16 = lane & 15, q4 = lane >> 4;
   const int rrow = lane >> 4, rc4 = lane & 15;         // read side: 16 lanes per row, 4 rows per pass
   const int n = nt0 + 4 * rc4;
   const bool ncol_ok = !CHECK || n < N;
