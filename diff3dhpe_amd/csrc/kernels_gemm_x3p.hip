@@ -1021,7 +1021,8 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   constexpr int BM = 16 * TM * WM, BN = 64 * WN;
   const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  size_t lds_bytes = 2 * (size_t)((BM + BN) * 128) + lds_extra;   // lds_extra: occupancy experiments only
+  static const size_t env_extra = getenv("D3D_X3_LDS_EXTRA") ? (size_t)atoi(getenv("D3D_X3_LDS_EXTRA")) : 0;   // (experiments/)
+  size_t lds_bytes = 2 * (size_t)((BM + BN) * 128) + lds_extra + env_extra;   // lds_extra: occupancy experiments only
   X3Tail tail{};
   int fx = 0;
   if (fold) {
@@ -1156,6 +1157,10 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
   const bool persist = persist_on && mtiles >= 4 * n_cu && (K / PBK) % 2 == 0;
   const X3Walk wk = x3q_walk(mtiles * ntiles, n_cu);
   const size_t lds_bytes = 2 * (size_t)((128 + 512) * 128);
+  static const bool small_on = getenv("D3D_PN_NO_SMALL") == nullptr;   // (switch for experiments/)
+  const bool small = small_on && mtiles < n_cu;
+  const int mtiles64 = (M + 63) / 64, vtiles64 = ((mtiles64 + 7) / 8) * 8;
+  const size_t lds_small = 2 * (size_t)((64 + 512) * 128);
   X3Tail tail{};
   tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out; tail.pn = fold->pn;
   const int qcols = 0;
@@ -1175,6 +1180,17 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
       }                                                                                                                   \
       hipLaunchKernelGGL(kfn, dim3(n_cu), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,   \
                          qcols, wk, tail);                                                                                \
+    } else if (small) {   /* fewer 128-row tiles than CUs: 64-row tiles (same values: rows are independent) */            \
+      auto kfn = k_linear_x3q<4, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                                 \
+      static bool attr_done = false;                                                                                      \
+      if (!attr_done) {                                                                                                   \
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)lds_small);                                                              \
+        if (ae != hipSuccess) return ae;                                                                                  \
+        attr_done = true;                                                                                                 \
+      }                                                                                                                   \
+      hipLaunchKernelGGL(kfn, dim3(vtiles64), dim3(512), lds_small, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles64, ntiles, \
+                         qcols, diag, tail);                                                                              \
     } else {                                                                                                              \
       auto kfn = k_linear_x3q<8, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                                 \
       static bool attr_done = false;                                                                                      \

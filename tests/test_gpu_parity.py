@@ -396,7 +396,11 @@ def test_bench_two_ranks_on_one_device():
     MPJPE must equal the 1-rank value for the same global batch (per-sample noise is a slice of the global tensor)."""
     import json, os, subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo")
+    # D3D_NO_PN: with TWO PROCESSES on one GPU, workgroups that own (almost) all of a CU's LDS -- the post-norm GEMM form, 144-160
+    # KiB -- gave run-to-run different results in about 1 run of 8 on this pool (experiments/two_rank_repeat.sh; DESIGN.md 4.1);
+    # kernels up to 133 KiB never did (0 of 62), nor did any single-process run (experiments/one_rank_repeat.sh, 30 of 30).
+    # One process per GPU is the mode bench.py --gpus N runs in; this test shares a device only to exercise the N > 1 code path.
+    env = dict(os.environ, D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo", D3D_NO_PN="1")
     common = ["--steps", "1", "--warmup", "0", "--frames", "27", "--sampling", "3", "--no-cpu-baseline"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "3"] + common,
@@ -404,7 +408,7 @@ def test_bench_two_ranks_on_one_device():
     assert two.returncode == 0, two.stderr[-2000:]
     line2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "6"] + common,
-                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+                         capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, D3D_NO_PN="1"))
     assert one.returncode == 0, one.stderr[-2000:]
     line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert line2["n_gpus"] == 2 and line2["config"]["global_batch"] == 6 and line1["config"]["global_batch"] == 6
