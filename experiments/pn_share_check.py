@@ -24,6 +24,8 @@ ref, st0, _ = E.op_linear_postnorm(A, W, b, R, gam, bet, with_stats=stats)
 bad_runs = 0
 for i in range(reps):
     y, st, _ = E.op_linear_postnorm(A, W, b, R, gam, bet, with_stats=stats)
+    if stats and not torch.equal(st, st0):
+        print(f"[pid {os.getpid()}] run {i}: statistics differ in {int((st != st0).any(1).sum())} rows", flush=True)
     if not torch.equal(y, ref):
         bad_runs += 1
         d = (y != ref)
