@@ -32,13 +32,15 @@ def flops_per_seq_step(T, D=512, J=17):
     return J * T * (256 * D * D + 544 * D + 32 * T * D)       # F(T)
 
 
-def cpu_baseline(T, S, seed, budget_s=30.0):
+def cpu_baseline(T, S, seed, budget_s=40.0):
     """The oracle (port of the reference's eager op sequence) on the host cores, bounded to ~budget_s of CPU work.
 
-    Every DDIM step costs the same, so throughput is measured on whole steps: first a thread-count sweep on 1-step
-    samples (big hosts are much slower with one thread per logical CPU than with a few dozen), then the best setting is
-    timed on as many of the S steps as fit the budget and scaled to S steps.  The best B in {1, 2} is reported
-    (the reference's CPU path gets slower per sequence as B grows)."""
+    Every DDIM step costs the same, so throughput is measured on whole steps and scaled to S steps where the budget does not
+    allow all of them: (1) thread-count sweep on one step at B=1 (big hosts are much slower with one thread per logical CPU
+    than with a few dozen); (2) one step at each B in {1, 2, 4, 8} -- a larger B is skipped, and
+    reported as skipped, when its projected time does not fit the budget (the reference's CPU path gets slower per sequence
+    as B grows); (3) the best B is timed three times on as many of the S steps as fit (all S when
+    they do): the minimum is reported, with the max/min spread of the three."""
     import torch
     from oracle import d3d_oracle as orc
     from diff3dhpe_amd.spec import DenoiserConfig
@@ -59,27 +61,82 @@ def cpu_baseline(T, S, seed, budget_s=30.0):
         return time.time() - t0
 
     t_start = time.time()
+    left = lambda: budget_s - (time.time() - t_start)
     sweep = {}
-    for th in sorted({t for t in (8, 16, 32, 64, avail) if t <= avail}):
+    for th in sorted({t for t in (8, 16, 32, 64) if t <= avail} | ({avail} if avail <= 64 else set())):
         torch.set_num_threads(th)
         sweep[th] = run(1, 1)
-        if time.time() - t_start > budget_s * 0.4:
+        if left() < budget_s * 0.75:
             break
     best_th = min(sweep, key=sweep.get)
     torch.set_num_threads(best_th)
-    left = budget_s - (time.time() - t_start)
-    n1 = max(1, min(S, int(left * 0.5 / sweep[best_th])))
-    d1 = run(1, n1) / n1
-    results = {1: 1.0 / (d1 * S)}
-    left = budget_s - (time.time() - t_start)
-    if left > 3.0 * d1:
-        d2 = run(2, 1)
-        results[2] = 2.0 / (d2 * S)
-    bestB = max(results, key=results.get)
-    return {"value": round(results[bestB], 4), "unit": "pose-seq/s", "cores": best_th, "kind": "port",
-            "sample": f"fp32 eager CPU oracle (port of the reference op sequence), T={T}: thread sweep on 1 DDIM step "
-                      f"{ {k: round(v, 2) for k, v in sweep.items()} } s; then {n1} of {S} steps at B=1 "
-                      f"({d1:.2f} s/step) and 1 step at B=2, scaled to {S} steps; best B={bestB}; host has {avail} usable CPUs"}
+    per_step = {1: sweep[best_th]}          # seconds per DDIM step, by B
+    skipped = []
+    for B in (2, 4, 8):
+        proj = per_step[max(per_step)] * (B / max(per_step)) * 1.5      # at least linear in B on this path
+        if proj > left() * 0.35:
+            skipped.append(B)
+            continue
+        per_step[B] = run(B, 1)
+    bestB = min(per_step, key=lambda b: per_step[b] / b)
+    n = max(1, min(S, int(left() / 3.0 / per_step[bestB])))
+    reps = [run(bestB, n) / n for _ in range(3)]
+    d = min(reps)
+    return {"value": round(bestB / (d * S), 4), "unit": "pose-seq/s", "cores": best_th, "kind": "port",
+            "spread_max_over_min": round(max(reps) / d, 3),
+            "sample": f"fp32 eager CPU oracle (port of the reference op sequence; cross-timed against the imported reference in the "
+                      f"build container: profiles/r02_cpu_oracle_vs_reference.json), T={T}: thread sweep on 1 DDIM step at B=1 "
+                      f"{ {k: round(v, 2) for k, v in sweep.items()} } s; 1 step at B in {sorted(per_step)}: "
+                      f"{ {b: round(v, 2) for b, v in per_step.items()} } s (B {skipped} skipped: projected beyond the "
+                      f"{budget_s:.0f} s budget); best B={bestB} timed 3x on {n} of {S} steps "
+                      f"({', '.join(f'{r:.2f}' for r in reps)} s/step; min reported, scaled to {S} steps); "
+                      f"host has {avail} usable CPUs"}
+
+
+def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
+    """Short legs after the timed region, so that the numbers DESIGN.md quotes beside the headline are observed by whoever
+    runs bench.py (single GPU only; each leg: 1 warm call, then 2 timed calls between device synchronisations):
+      graph_vs_eager              the same sampling with profiling off, as eager launches and as ONE hipGraph replay of the whole
+                                  S-step loop (BASELINE configs[3]: d3d_engine_set_graph_mode), outputs compared bit for bit
+      evaluate_equiv_frames_per_s the reference evaluate() unit (RUN:575-621): two samplings per window (flip-TTA) + un-flip /
+                                  average + masked MPJPE, frames of the batch per wall second
+      fp32_mode                   the exact-fp32 engine (v_mfma_f32_32x32x2_f32) on the same batch: value and MFMA roofline fraction"""
+    import torch
+    from diff3dhpe_amd.evaluate import evaluate
+    out = {}
+
+    def timed(fn, n=2):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n, r
+
+    te, ye = timed(lambda: eng.ddim_sample(x2d, noise))
+    eng.set_graph_mode(True)
+    tg, yg = timed(lambda: eng.ddim_sample(x2d, noise))
+    eng.set_graph_mode(False)
+    out["graph_vs_eager"] = {"eager_ms": round(te * 1e3, 3), "graph_ms": round(tg * 1e3, 3), "graph_over_eager": round(tg / te, 4),
+                             "bit_identical": bool(torch.equal(ye, yg)),
+                             "note": "whole S-step loop captured once per (B, workspace), replayed with one hipGraphLaunch; profiling off in both"}
+    batch = {"inputs_2d": x2d, "inputs_3d": gt[:x2d.shape[0]], "init_noise": noise, "init_noise_flip": noise}
+    tv, res = timed(lambda: evaluate(diff, [batch], scale=1.0, device=dev, verbose=False), n=1)
+    out["evaluate_equiv_frames_per_s"] = {"value": round(Bl * T / tv, 1), "unit": "frames/s", "windows_per_s": round(Bl / tv, 3),
+                                          "mpjpe_mm_vs_synthetic_gt": round(res["mpjpe_mm"], 3),
+                                          "note": "evaluate(): 2 DDIM samplings per window (normal + flipped 2D) + merge + MPJPE (RUN:575-621)"}
+    if a.precision != "fp32":
+        net.precision = "fp32"
+        e32 = diff._engine(dev)
+        t32, _ = timed(lambda: e32.ddim_sample(x2d, noise), n=1)
+        net.precision = a.precision
+        v32 = Bl / t32
+        out["fp32_mode"] = {"value": round(v32, 3), "unit": "pose-seq/s", "ms_per_step": round(t32 * 1e3, 3),
+                            "whole_step_tflops": round(flops_per_seq_step(T) * S * v32 / 1e12, 2),
+                            "frac_of_fp32_mfma_peak": round(flops_per_seq_step(T) * S * v32 / 1e12 / PEAK_TFLOPS["fp32"], 4),
+                            "note": "exact-fp32 companion (D3D_PREC_FP32), whole path against the 157.3 TFLOP/s fp32 MFMA peak"}
+    return out
 
 
 def main():
@@ -95,6 +152,12 @@ def main():
     ap.add_argument("--seq2frame", action="store_true", help="BASELINE configs[4]: ...S2F... model, (B,1,J,3) targets")
     ap.add_argument("--no-time-emb", action="store_true", help="with_time_emb=False (3DHP command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the companion legs after the timed region (fp32 mode, hipGraph replay, evaluate()-equivalent)")
+    ap.add_argument("--graph", action="store_true",
+                    help="time the main leg with hipGraph replay of the whole S-step loop (BASELINE configs[3]); per-kernel event "
+                         "timing is off then, so the roofline object carries the whole-path figure only")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the bitwise batch-vs-pair check (profiling passes: keeps the kernel tables to the timed workload)")
     a = ap.parse_args()
 
@@ -113,8 +176,14 @@ def main():
     backend = os.environ.get("D3D_DIST_BACKEND", "nccl")
     if os.environ.get("D3D_BENCH_ONE_DEVICE"):
         local = 0
-    if world > 1:
+    # D3D_FORCE_DIST=1: form the process group even at world size 1, so that `torchrun --nproc-per-node 1 bench.py --gpus 1`
+    # executes init_process_group("nccl", device_id=...), all_gather_into_tensor, all_reduce(MAX) and barrier on a one-rank
+    # RCCL communicator -- the N > 1 code path on a one-GPU box (tests/test_gpu_parity.py)
+    force_dist = bool(os.environ.get("D3D_FORCE_DIST"))
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -147,19 +216,21 @@ def main():
 
     def step():
         pred = eng.ddim_sample(x2d, noise)
-        pred = parallel.all_gather_pred(pred, Bg)          # RCCL all-gather (no-op at N=1)
+        pred = parallel.all_gather_pred(pred, Bg, force=force_dist)          # RCCL all-gather (no-op at N=1 unless forced)
         return tta_mpjpe(pred, None, gt if world > 1 else gt[lo:hi], None, 1.0, [], [])
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if a.graph:
+        eng.set_graph_mode(True)
     for _ in range(a.warmup):
         step()
     eng.profile_reset()
-    eng.set_profiling(True)
+    eng.set_profiling(not a.graph)      # graph replay and per-kernel event timing exclude each other (include/d3d.h)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -167,11 +238,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
     prof = eng.profile_read()
+    if a.graph:
+        eng.set_graph_mode(False)
     # self-check of the timed configuration (no oracle runs at this size): the first two sequences of the batch, sampled
     # again as a batch of two (the small-problem kernels the golden-vector tests cover), must come out bit-identical
     selfcheck = None
@@ -198,12 +271,18 @@ def main():
         roof.update({"kernel": dom, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                      "share_of_gpu_time": round(d["ms"] / tot_ms, 4), "traffic": None,
                      "by_kernel_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in prof.items() if v["launches"]}})
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # per-launch PMC bytes from a separate rocprofv3 run
+        # HBM bytes per launch cannot be counted from inside the process: they come from the separate rocprofv3 --pmc passes of
+        # profiles/collect.sh (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE) and are labelled as such
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 key = f"{dom}:T{T}:B{Bl}:{a.precision}"
                 roof["traffic"] = tj.get(key)
+                if roof["traffic"] is not None:
+                    roof["traffic_source"] = ("profiles/hbm_traffic.json: mean bytes per launch of this kernel class from the "
+                                              f"rocprofv3 --pmc passes of profiles/collect.sh ({tj.get('_collected', 'date not recorded')}), "
+                                              "NOT measured in this run")
             except Exception:
                 pass
         whole = flops_per_seq_step(T) * S * value / 1e12
@@ -223,11 +302,32 @@ def main():
             "selfcheck_batch_vs_pair_bit_identical": selfcheck,
             "roofline": roof,
         }
+        if a.precision == "f16x3":
+            line["precision_note"] = ("f16x3 = fp32-accurate arithmetic from three fp16 MFMAs per product (same 1e-4 parity gate as fp32); "
+                                      "it also serves BASELINE configs[1], whose 'bf16' cannot meet that gate (SURVEY appendix B) "
+                                      "and is not implemented -- no number of this repository is a bf16 number")
+        if a.graph:
+            line["graph_replay"] = True
+            roof["note"] = (roof.get("note", "") + "; main leg timed under hipGraph replay: per-kernel event timing is off, "
+                            "'achieved' is the whole-path figure").lstrip("; ")
+            roof.update({"kernel": "whole path (graph replay)", "achieved": round(whole, 2), "frac": round(whole / PEAK_TFLOPS[a.precision], 4),
+                         "launches": a.steps, "avg_launch_ms": round(elapsed / a.steps * 1e3, 3), "share_of_gpu_time": 1.0,
+                         "by_kernel_ms_per_step": {}, "traffic": None})
+            roof.pop("traffic_source", None)
+        if use_dist:
+            line["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_single_rank_group": force_dist,
+                            "collectives": ["barrier", "all_gather_into_tensor", "all_reduce(MAX)"]}
+    extras = None
+    if world == 1 and not a.no_extras and not a.seq2frame:
+        extras = companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl)
+    if rank == 0:
+        if extras:
+            line.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(T, S, 0)
+            line["cpu_baseline"] = cpu_baseline(T, S, 0, a.cpu_budget)
             line["speedup_vs_cpu_baseline"] = round(value / max(line["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -5,7 +5,35 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace d3d {
+
+// ---- per-device launch state ----------------------------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's function object, and the CU count is a
+// property of a device: both are cached per device (one process may drive several GPUs -- nn.DataParallel, RUN:216-218 --
+// from several threads).  `done` holds one bit per device ordinal; racing threads at worst repeat the idempotent call.
+inline hipError_t lds_optin(const void* fn, size_t bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+// compute units of the current device; 0 on error
+inline int device_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int n = cache[dev & 63].load(std::memory_order_acquire);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+  cache[dev & 63].store(n, std::memory_order_release);
+  return n;
+}
 
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 
@@ -24,6 +52,17 @@ __host__ __device__ __forceinline__ size_t pair_col_acc(int c) {
   return (size_t)((c >> 5) << 6) + (size_t)(8 * ((w & 15) >> 2) + 4 * (w >> 4) + (w & 3));
 }
 
+// ---- F16X3 range guard -------------------------------------------------------------------------------------------------
+// An fp16 plane holds 8*x (activations; the q third of a qkv output 1*x) or 4096*w (weights), clamped to +-65504: |x| > 8188
+// or |w| > 15.99 saturates silently.  Every device-side plane writer therefore tracks max |scaled value| per lane and ORs
+// bit 0 into its translation unit's sticky per-device word when a clamp fired (one atomic per lane that saw one: none in a
+// healthy run).  range_flags_*: read (and optionally clear) the word of the current device; the caller synchronises first.
+constexpr float X3_HALF_MAX = 65504.0f;
+hipError_t range_flags_gemm(unsigned* flags, bool clear);     // kernels_gemm_x3p.hip
+hipError_t range_flags_elem(unsigned* flags, bool clear);     // kernels_elem.hip
+hipError_t range_flags_attn(unsigned* flags, bool clear);     // kernels_attn_x3.hip
+hipError_t range_flags_attn32(unsigned* flags, bool clear);   // kernels_attn.hip (fp32 kernels writing planes)
+
 // ---- kernels_gemm.hip -------------------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); all row-major fp32, K % 32 == 0.
 hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N,
@@ -34,7 +73,8 @@ hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, 
 // split_weight_f16x3() ([rows][2*cols] fp16 of 4096*w).
 hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* bias, const float* R, float* C, int M, int N,
                                int K, int epi, hipStream_t s);
-void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order = false);
+// returns false when a weight left the fp16 range of 4096*w (|w| > 15.99) and was clamped
+bool split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order = false);
 
 // ---- kernels_gemm_x3p.hip ---------------------------------------------------------------------------------------
 // F16X3 with pre-split operands in the pair layout: A (>= ceil(M/256)*256 rows allocated), W (>= ceil(N/256)*256 rows).
@@ -141,6 +181,9 @@ hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const flo
 
 hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const int32_t* perm_dev, int n, int T, int J, int C,
                                 int flip, hipStream_t s);
+
+// debug trace: *out += position-weighted 64-bit sum of the buffer's 32-bit words (order-independent)
+hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, int rot, hipStream_t s);
 
 // ---- kernels_attn.hip -------------------------------------------------------------------------------------------
 // qkv: (B*T*J, 3*D) -> out (B*T*J, D), GRAND core  O = softmax(q k^T * dh^-0.5) v - v

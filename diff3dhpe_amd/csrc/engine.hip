@@ -60,6 +60,8 @@ struct d3d_engine {
   std::vector<float> freqs_host;
   bool freqs_set = false;
   bool committed = false;
+  bool weights_clamped = false;   // F16X3: a GEMM weight left the fp16 range of 4096*w at commit (range guard)
+  int device = -1;                // ordinal of the device the weights were committed on
 
   float* arena = nullptr;  // all weights, device
   size_t arena_floats = 0;
@@ -102,8 +104,15 @@ struct d3d_engine {
   double prof_ms[D3D_KC_COUNT] = {0}, prof_flops[D3D_KC_COUNT] = {0}, prof_bytes[D3D_KC_COUNT] = {0};
   int64_t prof_launches[D3D_KC_COUNT] = {0};
 
+  // debug trace (d3d_engine_set_trace): one checksum per buffer a kernel of the F16X3 block flow has just written
+  bool tracing = false;
+  unsigned long long* trace_dev = nullptr;
+  int trace_cap = 0, trace_n = 0, trace_fwd = 0, trace_views = 1;
+  std::vector<uint32_t> trace_tags;
+
   ~d3d_engine() {
     drop_graphs();
+    (void)hipFree(trace_dev);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
@@ -201,6 +210,27 @@ struct Prof {
   }
 };
 
+// debug trace: tag = view << 28 | forward << 16 | block << 8 | kernel << 4 | buffer
+//   kernel: 0 embed, 1 stream entry, 2 qkv, 3 attention, 4 proj, 5 fc1, 6 fc2 (+ post-norm), 7 post-norm row kernel, 8 head
+//   buffer: 0 = the kernel's main output (rows < M only), 1 = row-statistics partials
+int trace(d3d_engine* e, int blk, int kernel, int buf, const void* p, size_t bytes, hipStream_t s) {
+  if (!e->tracing) return D3D_OK;
+  for (int v = 0; v < e->trace_views && e->trace_n < e->trace_cap; ++v) {
+    HIP_TRY(launch_checksum(p, bytes, e->trace_dev + e->trace_n, v, s));
+    e->trace_tags.push_back(((uint32_t)v << 28) | ((uint32_t)(e->trace_fwd & 0xFFF) << 16) | ((uint32_t)blk << 8) |
+                            ((uint32_t)kernel << 4) | (uint32_t)buf);
+    ++e->trace_n;
+  }
+  return D3D_OK;
+}
+#define TRACE(blk, kernel, buf, p, bytes)                                  \
+  do {                                                                     \
+    if (e->tracing) {                                                      \
+      int _t = trace(e, (blk), (kernel), (buf), (p), (bytes), s);          \
+      if (_t) return _t;                                                   \
+    }                                                                      \
+  } while (0)
+
 // Workspace carve-up (float offsets).  AO (attention output) aliases HN: norm1(x) is dead once the qkv GEMM has run.
 struct Workspace {
   float *X, *HN, *QKV, *HID, *Y0, *Y1, *TEMB, *TSCR, *RED, *TIMES, *XIN, *NIN, *OUTB, *ST1, *ST2;
@@ -276,6 +306,8 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
     HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.HN, B, T, J, D, e->cfg.in_chans, y_bcast, s));
   }
+  const size_t MDb = (size_t)M * D * 4;                 // bytes of an (M, D) fp32 tensor = of its pair-layout planes
+  TRACE(0, 0, 0, w.HN, MDb);
   auto rowk = [&](LnArgs a, int outs) -> hipError_t {
     Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + outs), s);
     return launch_layernorm(a, s);
@@ -286,6 +318,8 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
     HIP_TRY(rowk(a, 1));
   }
+  TRACE(0, 1, 0, XP, MDb);
+  TRACE(0, 1, 1, w.ST1, (size_t)M * 8);
   const int np2 = x3q_ntiles(M, D);                     // statistics partials per row written by a GEMM epilogue
   int np1 = 1;                                          // ... per row in w.ST1 (1 after a row kernel)
   // post-norm inside the fc2 epilogue (X3PostNorm) where the tile shape for it exists; else fp32 + the row kernel
@@ -304,22 +338,27 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       f.st_in = w.ST1; f.st_np = np1; f.csum = bw.qkv_cs; f.eps = 1e-6f;
       HIP_TRY(gemm(XP, bw.qkv_f3, bw.qkv_fb, nullptr, QKVh, QKVl, 1, 3 * D, D, EPI_NONE, D, f));
     }
+    TRACE(k, 2, 0, QKVh, 3 * MDb);
     {
       const int N = temporal ? T : J;
       Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD4, s);
       if (temporal) HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, AOx, B, T, J, D, e->H, s));
       else HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, AOx, B * T, J, 1, D, e->H, s));
     }
+    TRACE(k, 3, 0, AOx, MDb);
     {  // x += attn Wproj^T + b, plane to plane in place; row statistics of the new x for the folded norm2
       X3Fold f{};
       f.Rp = XP; f.st_out = w.ST2;
       HIP_TRY(gemm(AOx, bw.proj_x3, bw.projb, nullptr, XP, nullptr, 2, D, D, EPI_RESIDUAL, 0, f));
     }
+    TRACE(k, 4, 0, XP, MDb);
+    TRACE(k, 4, 1, w.ST2, (size_t)M * 8 * np2);
     {  // hidden = gelu(norm2(x) W1^T + b1), LayerNorm folded
       X3Fold f{};
       f.st_in = w.ST2; f.st_np = np2; f.csum = bw.fc1_cs; f.eps = 1e-6f;
       HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
     }
+    TRACE(k, 5, 0, HIDx, (size_t)M * e->Dm * 4);
     const float* pn_g = temporal ? e->tn_g : e->sn_g;
     const float* pn_b = temporal ? e->tn_b : e->sn_b;
     const bool last = k + 1 == e->nblk;
@@ -333,9 +372,11 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
         f.st_out = w.ST1;
         HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, nullptr, XP, nullptr, 2, D, e->Dm, EPI_RESIDUAL, 0, f));
         np1 = np2;
+        TRACE(k, 6, 1, w.ST1, (size_t)M * 8 * np2);
       } else {
         HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
       }
+      TRACE(k, 6, 0, w.X, MDb);
       continue;
     }
     {  // x + hidden W2^T + b2 -> fp32 (w.HN) for the post-norm
@@ -343,6 +384,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       f.Rp = XP;
       HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, w.HN, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
     }
+    TRACE(k, 6, 0, w.HN, MDb);
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector] -> planes + statistics (or fp32 at the end)
       LnArgs a{};
       a.x = w.HN;
@@ -357,6 +399,8 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       }
       HIP_TRY(rowk(a, 1));
     }
+    TRACE(k, 7, 0, w.X, MDb);
+    if (!last) TRACE(k, 7, 1, w.ST1, (size_t)M * 8);
   }
   return D3D_OK;
 }
@@ -470,6 +514,12 @@ int prep_head(d3d_engine* e, HeadArgs& h, int B, const Workspace& w, hipStream_t
 int check_ready(const d3d_engine* e, int B, const void* ws, size_t ws_bytes) {
   if (!e) return fail(D3D_EINVAL, "null engine");
   if (!e->committed) return fail(D3D_ESTATE, "weights not committed (d3d_engine_commit_weights)");
+  {   // one engine per device: its weights, tables and per-device kernel attributes belong to the device it was committed on
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != e->device)
+      return fail(D3D_ESTATE, "engine was committed on device " + std::to_string(e->device) + " but the current device is " +
+                                  std::to_string(dev) + " (one engine per device; make its device current before calling)");
+  }
   if (B <= 0) return fail(D3D_EINVAL, "B must be positive");
   if ((long long)B * e->T * e->J > 0x7fffffffLL / 4) return fail(D3D_EINVAL, "batch too large for 32-bit token index");
   if (!ws) return fail(D3D_EINVAL, "null workspace");
@@ -600,6 +650,8 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     e->blk.push_back(blockw("STEblocks." + std::to_string(i)));
     e->blk.push_back(blockw("TTEblocks." + std::to_string(i)));
   }
+  e->weights_clamped = false;
+  HIP_TRY(hipGetDevice(&e->device));
   if (e->cfg.precision == D3D_PREC_F16X3) {
     // fp16 hi/lo pair layout of the four GEMM weights of every block, rows padded to a multiple of 256 (zero rows) so
     // the LDS-DMA of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
@@ -620,7 +672,7 @@ int d3d_engine_commit_weights(d3d_engine* e) {
       const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2);
       auto pair = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& dst, bool acc_order = false) {
         const WeightSlot& ws = e->slots[e->index[name]];
-        split_weight_f16x3(ws.host.data(), rows, cols, host.data() + o, acc_order);
+        if (!split_weight_f16x3(ws.host.data(), rows, cols, host.data() + o, acc_order)) e->weights_clamped = true;
         dst = e->arena16 + o;
         o += 2 * pad256(rows) * cols;
       };
@@ -648,7 +700,7 @@ int d3d_engine_commit_weights(d3d_engine* e) {
           fold[fo + r] = (float)c;
           fold[fo + rows + r] = (float)bsum;
         }
-        split_weight_f16x3(wg.data(), rows, cols, host.data() + o);
+        if (!split_weight_f16x3(wg.data(), rows, cols, host.data() + o)) e->weights_clamped = true;
         w3 = e->arena16 + o;
         o += 2 * pad256(rows) * cols;
         cs = e->arena_fold + fo;
@@ -809,6 +861,17 @@ int ddim_loop(d3d_engine* e, const float* x2d, const float* init_noise, const fl
       Prof p(e, D3D_KC_HEAD, 14.0 * h.rows * e->D, 4.0 * h.rows * e->D, s);
       HIP_TRY(launch_head(h, s));
     }
+    TRACE(0, 8, 0, y_next, yel * sizeof(float));
+    if (e->tracing) {   // the head once more from the same inputs into scratch (kernel 9), and its y input (kernel 8, buffer 1)
+      TRACE(0, 8, 1, y_cur, yel * sizeof(float));
+      HeadArgs h2 = h;
+      h2.y_next = w.OUTB; h2.traj_rev = nullptr; h2.traj_x0 = nullptr;
+      if (h2.y_cur != h2.y_next) {
+        HIP_TRY(launch_head(h2, s));
+        TRACE(0, 9, 0, w.OUTB, yel * sizeof(float));
+      }
+      ++e->trace_fwd;
+    }
   }
   return D3D_OK;
 }
@@ -823,7 +886,7 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
   if (e->eta != 0.0f && !step_noise) return fail(D3D_EINVAL, "step_noise required when eta != 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Workspace w = carve(e, B, ws);
-  const bool use_graph = e->graph_mode && !traj_rev && !traj_x0 && e->eta == 0.0f && !e->profiling;
+  const bool use_graph = e->graph_mode && !traj_rev && !traj_x0 && e->eta == 0.0f && !e->profiling && !e->tracing;
   if (!use_graph) return ddim_loop(e, x2d, init_noise, step_noise, out, traj_rev, traj_x0, B, w, s);
 
   // Graph replay: the captured launch sequence reads its inputs from / writes its result to fixed staging buffers
@@ -930,6 +993,52 @@ int d3d_window_gather(const float* seq, int32_t n_frames, int32_t T, int32_t J, 
   hipError_t le = launch_window_gather(seq, out, mask, perm_dev, n_frames, T, J, C, flip ? 1 : 0, s);
   if (perm_dev) { (void)hipStreamSynchronize(s); (void)hipFree(perm_dev); }
   HIP_TRY(le);
+  return D3D_OK;
+}
+
+// ---- F16X3 range guard ----------------------------------------------------------------------------------------------
+int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* stream) {
+  if (!e || !flags) return fail(D3D_EINVAL, "null argument");
+  if (!e->committed) return fail(D3D_ESTATE, "weights not committed");
+  HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  unsigned a = 0, b = 0, c = 0, d = 0;
+  HIP_TRY(range_flags_gemm(&a, clear != 0));
+  HIP_TRY(range_flags_elem(&b, clear != 0));
+  HIP_TRY(range_flags_attn(&c, clear != 0));
+  HIP_TRY(range_flags_attn32(&d, clear != 0));
+  *flags = ((a | b | c | d) ? D3D_RANGE_ACT : 0u) | (e->weights_clamped ? D3D_RANGE_WEIGHT : 0u);
+  return D3D_OK;
+}
+
+// ---- debug trace ----------------------------------------------------------------------------------------------------
+int d3d_engine_set_trace(d3d_engine* e, int32_t capacity, int32_t views) {
+  if (!e || capacity < 0 || views < 1 || views > 8) return fail(D3D_EINVAL, "bad argument");
+  e->trace_views = views;
+  (void)hipFree(e->trace_dev);
+  e->trace_dev = nullptr;
+  e->trace_cap = e->trace_n = e->trace_fwd = 0;
+  e->trace_tags.clear();
+  e->tracing = capacity > 0;
+  if (e->tracing) {
+    HIP_TRY(hipMalloc(&e->trace_dev, (size_t)capacity * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(e->trace_dev, 0, (size_t)capacity * sizeof(unsigned long long)));
+    e->trace_cap = capacity;
+  }
+  return D3D_OK;
+}
+
+int d3d_engine_trace_read(d3d_engine* e, uint64_t* sums_host, uint32_t* tags_host, int32_t cap, int32_t* n, void* stream) {
+  if (!e || !sums_host || !tags_host || !n || cap < 0) return fail(D3D_EINVAL, "bad argument");
+  if (!e->tracing) return fail(D3D_ESTATE, "trace is off (d3d_engine_set_trace)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(hipStreamSynchronize(s));
+  const int cnt = std::min(e->trace_n, (int)cap);
+  if (cnt) HIP_TRY(hipMemcpy(sums_host, e->trace_dev, (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int i = 0; i < cnt; ++i) tags_host[i] = e->trace_tags[i];
+  *n = cnt;
+  HIP_TRY(hipMemset(e->trace_dev, 0, (size_t)e->trace_cap * sizeof(unsigned long long)));
+  e->trace_n = e->trace_fwd = 0;
+  e->trace_tags.clear();
   return D3D_OK;
 }
 
@@ -1160,6 +1269,16 @@ int d3d_op_linear_postnorm(const float* A, const float* W, const float* bias, co
   if (part) (void)hipFree(part);
   HIP_TRY(le);
   HIP_TRY(se);
+  return D3D_OK;
+}
+
+int d3d_op_head(d3d_engine* e, const float* X, float* x0, int32_t rows, void* stream) {
+  if (!e || !X || !x0 || rows < 1) return fail(D3D_EINVAL, "bad argument");
+  if (!e->committed) return fail(D3D_ESTATE, "weights not committed");
+  HeadArgs h{};
+  h.g = e->hd_g; h.b = e->hd_b; h.eps = 1e-5f; h.Wh = e->hd_w; h.bh = e->hd_bias; h.D = e->D;
+  h.X = X; h.rows = rows; h.x0_raw = x0; h.mode = 0;
+  HIP_TRY(launch_head(h, reinterpret_cast<hipStream_t>(stream)));
   return D3D_OK;
 }
 

@@ -20,8 +20,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h4a __attribute__((ext_vector_type(4)));
 typedef _Float16 h8a __attribute__((ext_vector_type(8)));
 
+// F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = a clamp fired
+__device__ unsigned g_range_attn32;
+
 // fp32 -> (hi, lo) fp16 pair of 8*x: the operand format of the F16X3 GEMM (kernels_gemm_x3p.hip)
 __device__ __forceinline__ void split1_x3(float x, _Float16& hi, _Float16& lo) {
+  if (fabsf(x) > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn32, 1u);   // (fp32-mode kernels feeding an F16X3 GEMM: not the hot path)
   const float s = __builtin_amdgcn_fmed3f(x * 8.0f, -65504.0f, 65504.0f);
   hi = (_Float16)s;
   lo = (_Float16)(s - (float)hi);
@@ -307,19 +311,21 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __r
   }
 }
 
+hipError_t range_flags_attn32(unsigned* flags, bool clear) {
+  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_attn32), sizeof(unsigned));
+  const unsigned zero = 0;
+  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_attn32), &zero, sizeof(unsigned));
+  return e;
+}
+
 bool attn_temporal_fast_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * TP_DH; }
 
 template <int NKT>
 static hipError_t launch_temporal_nkt(const float* qkv, float* out, void* out_x3, int B, int T, int J, int D, int H,
                                       hipStream_t s) {
   const size_t lds_bytes = (size_t)32 * NKT * (K_LD + V_LD) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_f32<NKT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_f32<NKT>), lds_bytes, attr_set)) return e;
   const long long grid = (long long)B * J * H;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_attn_temporal_f32<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, qkv, out,

@@ -35,6 +35,9 @@ __device__ __forceinline__ int vkey(int row) { return (((row >> 1) & 1) << 2) ^ 
 __device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ vkey(row)) << 4); }
 typedef short s4v __attribute__((ext_vector_type(4)));
 
+// F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = an output clamp fired
+__device__ unsigned g_range_attn;
+
 // MU > 1 (only with NKT == 1, i.e. groups of <= 32 tokens: the spatial blocks): one workgroup carries MU independent
 // (group, head) units, one per wave, each in its own LDS slice -- a 64-thread workgroup per unit is bound by the
 // workgroup launch rate (124k launches per call at T=243, B=64), not by HBM.
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
 
   // ---- O = O^T / (2^13 l) - v_query, written as hi/lo planes of 8*o for the proj GEMM
   if (tq < T && unit_ok) {
+    float amax = 0.0f;   // range guard
     const float inv = 1.0f / (8192.0f * l);
     const size_t tokq = tok0 + (size_t)tq * J;
     const size_t vo = tokq * D3 + 2 * D + hd * XDH;
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
         for (int e = 0; e < 4; ++e) {
           const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
           const float o = oacc[dt][4 * g4 + e] * inv - vq;
+          amax = fmaxf(amax, fabsf(o));
           const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
           oh[e] = (_Float16)sc;
           ol[e] = (_Float16)(sc - (float)oh[e]);
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
         *reinterpret_cast<h4*>(out_x3 + oo + pair_col(d)) = oh;
         *reinterpret_cast<h4*>(out_x3 + oo + pair_col(d) + PAIR_LO) = ol;
       }
+    if (amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
   }
 }
 
@@ -467,6 +473,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     {
       const float inv = 1.0f / (8192.0f * l);
       const int tqc = tq < T ? tq : 0;
+      float amax = 0.0f;   // range guard (rows tq >= T are never stored)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -479,6 +486,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
           for (int e = 0; e < 4; ++e) {
             const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
             const float o = oacc[dt][4 * g4 + e] * inv - vq;
+            amax = fmaxf(amax, fabsf(o));
             const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
             oh[e] = (_Float16)sc;
             ol[e] = (_Float16)(sc - (float)oh[e]);
@@ -486,6 +494,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
           po_h[dt * 4 + g4] = oh;
           po_l[dt * 4 + g4] = ol;
         }
+      if (tq < T && amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
       po_off = (tok0 + (size_t)tqc * J) * 2 * D + hd * 2 * XDH;
       po_valid = true;
     }
@@ -511,19 +520,21 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   }
 }
 
+hipError_t range_flags_attn(unsigned* flags, bool clear) {
+  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_attn), sizeof(unsigned));
+  const unsigned zero = 0;
+  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_attn), &zero, sizeof(unsigned));
+  return e;
+}
+
 bool attn_temporal_x3_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * XDH; }
 
 template <int NKT, int MU = 1>
 static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D,
                                 int H, hipStream_t s) {
   const size_t lds_bytes = (size_t)MU * 4 * 32 * NKT * 128;   // per unit: K_hi, K_lo, V_hi, V_lo planes of TP rows x 128 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3<NKT, MU>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3<NKT, MU>), lds_bytes, attr_set)) return e;
   const long long units = (long long)B * J * H;
   if (units > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL((k_attn_temporal_x3<NKT, MU>), dim3((unsigned)((units + MU - 1) / MU)), dim3(64 * NKT * MU), lds_bytes, s, ph,
@@ -536,18 +547,12 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
                                  hipStream_t s) {
   // wave-private units (MU > 1, NKT == 1): 6 planes of T rows per wave (V double-buffered) + one zeroed pad behind the last
   const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 : (size_t)4 * 32 * NKT * 128;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, MU > 1 ? 160 * 1024 : (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU>), MU > 1 ? (size_t)160 * 1024 : lds_bytes,
+                               attr_set))
+    return e;
+  const int n_cu = device_cu_count();
+  if (n_cu <= 0) return hipErrorUnknown;
   const long long units = (long long)B * J * H;
   if (units > 0x7fffffffLL || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;   // resident workgroups per CU

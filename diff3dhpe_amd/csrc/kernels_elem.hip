@@ -2,17 +2,22 @@
 // regression head + DDIM update, seq2frame frame reduce, q_sample, flip-TTA merge + MPJPE.
 // One 64-lane wave owns one token row (D floats as float4 per lane) so every reduction is a wave shuffle tree and
 // every HBM access is a 16-byte-per-lane coalesced stream.
+#include <cstdlib>
 #include "d3d_kernels.h"
 
 namespace d3d {
 
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
+// F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = a plane writer's clamp fired
+__device__ unsigned g_range_elem;
+
 // fp32 -> (hi, lo) fp16 pair of 8*x: the operand format of the F16X3 GEMM (kernels_gemm_x3p.hip)
-__device__ __forceinline__ void split4_x3(const float4 v, h4v& hi, h4v& lo) {
+__device__ __forceinline__ void split4_x3(const float4 v, h4v& hi, h4v& lo, float& amax) {
   const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    amax = fmaxf(amax, fabsf(f[j] * 8.0f));
     const float s = __builtin_amdgcn_fmed3f(f[j] * 8.0f, -65504.0f, 65504.0f);
     hi[j] = (_Float16)s;
     lo[j] = (_Float16)(s - (float)hi[j]);
@@ -22,10 +27,19 @@ __device__ __forceinline__ void split4_x3(const float4 v, h4v& hi, h4v& lo) {
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int LN_MAXV = 4;  // float4 per lane -> D <= 1024
 
+// Sum over the 64 lanes of a wave, the total in every lane.  In-row (16 lanes) butterfly by DPP -- quad xor 1, xor 2,
+// half-row mirror, row mirror --, then the four row totals through v_readlane: no ds_bpermute (what __shfl_xor compiles to).
+// History: with the __shfl_xor butterfly, three of which the head kernel issues back to back, single outputs of the head
+// changed from run to run while a second process used the GPU.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -74,6 +88,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
   if (row >= a.rows) return;
   const int D = a.D;
   float4 v[NV];
+  float amax = 0.0f;   // range guard of the plane outputs
   const float* xr = a.x + (size_t)row * D;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -112,11 +127,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
       const int c = 4 * (lane + 64 * i);
       if (c < D) {
         h4v hi, lo;
-        split4_x3(v[i], hi, lo);
+        split4_x3(v[i], hi, lo, amax);
         *reinterpret_cast<h4v*>(yp + pair_col(c)) = hi;
         *reinterpret_cast<h4v*>(yp + pair_col(c) + PAIR_LO) = lo;
       }
     }
+    if (amax > X3_HALF_MAX) atomicOr(&g_range_elem, 1u);
   }
   if (a.stats) {
     float sm = 0.f, sq = 0.f;
@@ -139,11 +155,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
         const int c = 4 * (lane + 64 * i);
         if (c < D) {
           h4v hi, lo;
-          split4_x3(v[i], hi, lo);
+          split4_x3(v[i], hi, lo, amax);
           *reinterpret_cast<h4v*>(hp + pair_col(c)) = hi;
           *reinterpret_cast<h4v*>(hp + pair_col(c) + PAIR_LO) = lo;
         }
       }
+      if (amax > X3_HALF_MAX) atomicOr(&g_range_elem, 1u);
     } else {
       float* hr = a.h + (size_t)row * D;
 #pragma unroll
@@ -153,6 +170,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
       }
     }
   }
+}
+
+hipError_t range_flags_elem(unsigned* flags, bool clear) {
+  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_elem), sizeof(unsigned));
+  const unsigned zero = 0;
+  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_elem), &zero, sizeof(unsigned));
+  return e;
 }
 
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
@@ -321,70 +345,109 @@ hipError_t launch_frame_reduce(const float* X, const float* w, const float* bias
 // ------------------------------------------------------------------------------------------------ head + DDIM update
 // head = LayerNorm(eps 1e-5) + Linear(D -> 3) (S2S:217-220); clamp (DIFF:252,256); DDIM update (DIFF:287-297) with the
 // reference's `alpha * x_start` term (DIFF:296) and its fp32 operation order (no fma contraction: __f*_rn).
-template <int NV>
+//
+// A workgroup owns HEAD_ROWS = 32 consecutive rows: 32 rows x 3 floats = 384 bytes = three WHOLE 128-byte lines of every
+// (rows, 3) output, written by one wave-instruction of lanes 0..95 after the row results have met in LDS.  With one row per
+// wave and four rows per workgroup (the first form of this kernel) a line of y_next was shared by three or four
+// workgroups on different XCDs, each storing 12-byte pieces of it -- and exactly those stores were what changed from run
+// to run when a second process used the GPU (found with the per-kernel trace of
+// experiments/bisect_two_proc.py; experiments/false_share_probe.hip shows the same without any kernel of this library).
+// Rule kept everywhere in this library since: no two workgroups ever store into the same 128-byte line.
+constexpr int HEAD_ROWS = 32;
+template <int NV, int VAR = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
+  static_assert(HEAD_ROWS % WAVES_PER_BLOCK == 0 && (HEAD_ROWS * 3 * 4) % 128 == 0, "whole lines per workgroup");
+  __shared__ float so[HEAD_ROWS * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * HEAD_ROWS;
   const int D = a.D;
-  float4 v[NV];
-  const float* xr = a.X + (size_t)row * D;
+#pragma unroll 1
+  for (int r = 0; r < HEAD_ROWS / WAVES_PER_BLOCK; ++r) {
+    const int lr = wave * (HEAD_ROWS / WAVES_PER_BLOCK) + r, row = row0 + lr;
+    if (row >= a.rows) break;
+    float4 v[NV];
+    const float* xr = a.X + (size_t)row * D;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = 4 * (lane + 64 * i);
-    v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
-  }
-  ln_row<NV>(v, D, lane, a.g, a.b, a.eps);
-  float o[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+    }
+    ln_row<NV>(v, D, lane, a.g, a.b, a.eps);
+    float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = 4 * (lane + 64 * i);
-    if (c < D) {
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) {
+        if (VAR == 1) {        // experiment: all three weight loads waited for together (vmcnt(0)) before any is used
+          float4 w[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
-        o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+          for (int k = 0; k < 3; ++k) w[k] = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0].x), "+v"(w[0].y), "+v"(w[0].z), "+v"(w[0].w), "+v"(w[1].x), "+v"(w[1].y), "+v"(w[1].z),
+                       "+v"(w[1].w), "+v"(w[2].x), "+v"(w[2].y), "+v"(w[2].z), "+v"(w[2].w));
+#pragma unroll
+          for (int k = 0; k < 3; ++k) o[k] += (v[i].x * w[k].x + v[i].y * w[k].y) + (v[i].z * w[k].z + v[i].w * w[k].w);
+        } else if (VAR == 2) { // experiment: rows of Wh visited 2, 1, 0
+#pragma unroll
+          for (int k = 2; k >= 0; --k) {
+            const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
+            o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
+            o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+          }
+        }
       }
     }
-  }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) o[k] = wave_sum(o[k]);
-  if (lane < 3) {
-    const int k = lane;
-    float x0 = (k == 0 ? o[0] : (k == 1 ? o[1] : o[2])) + a.bh[k];
-    const size_t idx = (size_t)row * 3 + k;
-    if (a.x0_raw) a.x0_raw[idx] = x0;
-    if (a.mode != 0) {
-      if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-      if (a.traj_x0) a.traj_x0[idx * a.traj_x0_stride + a.traj_idx] = x0;
-      float yn;
-      if (a.mode == 2) {
-        yn = x0;  // DIFF:283-285: the last step returns the (clamped) x_start
-      } else {
-        const float al = a.alpha, an = a.alpha_next;
-        // sigma = eta * sqrt((1 - a/an) * (1 - an) / (1 - a));  c = sqrt(1 - an - sigma^2)
-        const float sigma = __fmul_rn(a.eta, __fsqrt_rn(__fdiv_rn(__fmul_rn(__fsub_rn(1.0f, __fdiv_rn(al, an)),
-                                                                             __fsub_rn(1.0f, an)),
-                                                                    __fsub_rn(1.0f, al))));
-        const float cc = __fsqrt_rn(__fsub_rn(__fsub_rn(1.0f, an), __fmul_rn(sigma, sigma)));
-        const float yc = a.y_cur[idx];
-        const float t1 = __fmul_rn(x0, __fsqrt_rn(an));
-        const float t4 = __fdiv_rn(__fsub_rn(yc, __fmul_rn(al, x0)), a.somac);
-        yn = __fadd_rn(t1, __fmul_rn(cc, t4));
-        const float nz = a.noise ? a.noise[idx] : 0.0f;
-        yn = __fadd_rn(yn, __fmul_rn(sigma, nz));
-      }
-      a.y_next[idx] = yn;
-      if (a.traj_rev) a.traj_rev[idx * a.traj_rev_stride + a.traj_idx] = yn;
+    for (int k = 0; k < 3; ++k) o[k] = wave_sum(o[k]);
+    if (lane < 3) so[lr * 3 + lane] = (lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]));
+  }
+  __syncthreads();
+  const int t = threadIdx.x;                      // lanes 0..95: (local row, k) = (t / 3, t % 3), consecutive 4-byte words
+  if (t >= HEAD_ROWS * 3 || row0 + t / 3 >= a.rows) return;
+  const int k = t % 3;
+  float x0 = so[t] + a.bh[k];
+  const size_t idx = (size_t)row0 * 3 + t;
+  if (a.x0_raw) a.x0_raw[idx] = x0;
+  if (a.mode != 0) {
+    if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    if (a.traj_x0) a.traj_x0[idx * a.traj_x0_stride + a.traj_idx] = x0;
+    float yn;
+    if (a.mode == 2) {
+      yn = x0;  // DIFF:283-285: the last step returns the (clamped) x_start
+    } else {
+      const float al = a.alpha, an = a.alpha_next;
+      // sigma = eta * sqrt((1 - a/an) * (1 - an) / (1 - a));  c = sqrt(1 - an - sigma^2)
+      const float sigma = __fmul_rn(a.eta, __fsqrt_rn(__fdiv_rn(__fmul_rn(__fsub_rn(1.0f, __fdiv_rn(al, an)),
+                                                                           __fsub_rn(1.0f, an)),
+                                                                  __fsub_rn(1.0f, al))));
+      const float cc = __fsqrt_rn(__fsub_rn(__fsub_rn(1.0f, an), __fmul_rn(sigma, sigma)));
+      const float yc = a.y_cur[idx];
+      const float t1 = __fmul_rn(x0, __fsqrt_rn(an));
+      const float t4 = __fdiv_rn(__fsub_rn(yc, __fmul_rn(al, x0)), a.somac);
+      yn = __fadd_rn(t1, __fmul_rn(cc, t4));
+      const float nz = a.noise ? a.noise[idx] : 0.0f;
+      yn = __fadd_rn(yn, __fmul_rn(sigma, nz));
     }
+    a.y_next[idx] = yn;
+    if (a.traj_rev) a.traj_rev[idx * a.traj_rev_stride + a.traj_idx] = yn;
   }
 }
 
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
   if (a.rows <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
-  const int grid = (a.rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int grid = (a.rows + HEAD_ROWS - 1) / HEAD_ROWS;
+  static const int var = getenv("D3D_HEAD_VARIANT") ? atoi(getenv("D3D_HEAD_VARIANT")) : 0;   // (experiments/)
   if (a.D <= 256)
     hipLaunchKernelGGL(k_head<1>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else if (a.D <= 512 && var == 1)
+    hipLaunchKernelGGL((k_head<2, 1>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else if (a.D <= 512 && var == 2)
+    hipLaunchKernelGGL((k_head<2, 2>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else if (a.D <= 512)
     hipLaunchKernelGGL(k_head<2>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else
@@ -489,6 +552,31 @@ hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, con
   const long long total = (long long)nc * T * J;
   hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, seq, out, mask, perm_dev, n, T, J, C,
                      nc, flip);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ debug trace
+// 64-bit position-weighted sum of the 32-bit words of a buffer (d3d_engine_set_trace): commutative, so the grid's
+// atomic adds give the same value whatever their order; a changed, moved or swapped word changes it.
+__global__ __launch_bounds__(256) void k_checksum(const uint32_t* __restrict__ p, size_t nwords, unsigned long long* out, int rot) {
+  // rot: block b does the work of block (b + rot) % gridDim -- with workgroups dealt round-robin over the 8 XCDs, the
+  // launches rot = 0..7 read every line once through each XCD's L2 ("views": they must all agree)
+  const size_t vb = ((size_t)blockIdx.x + (size_t)rot) % gridDim.x;
+  unsigned long long acc = 0;
+  for (size_t i = vb * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256)
+    acc += (unsigned long long)p[i] * ((i * 0x9E3779B97F4A7C15ull) | 1ull);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, int rot, hipStream_t s) {
+  const size_t nwords = bytes / 4;
+  if (nwords == 0) return hipSuccess;
+  size_t blocks = (nwords + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  blocks = (blocks + 7) / 8 * 8;
+  hipLaunchKernelGGL(k_checksum, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)p, nwords, out, rot);
   return hipGetLastError();
 }
 

@@ -212,10 +212,12 @@ hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* b
 // (round-to-nearest-even both times).
 // acc_order: the k index of every 32-column group is stored in the order pair_slot_acc() gives it (the layout of the
 // hidden activation that the fc1 epilogue writes straight from its accumulators, kernels_gemm_x3p.hip)
-void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order) {
+bool split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order) {
+  bool in_range = true;
   for (size_t r = 0; r < rows; ++r)
     for (size_t c = 0; c < cols; ++c) {
       float s = w[r * cols + c] * 4096.0f;
+      if (!(s <= 65504.0f && s >= -65504.0f)) in_range = false;
       if (s > 65504.0f) s = 65504.0f;
       if (s < -65504.0f) s = -65504.0f;
       const _Float16 h = (_Float16)s;
@@ -224,6 +226,7 @@ void split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair
       __builtin_memcpy(o, &h, 2);
       __builtin_memcpy(o + PAIR_LO, &l, 2);
     }
+  return in_range;
 }
 
 }  // namespace d3d

@@ -41,15 +41,25 @@ constexpr int PBK = 32;                          // k-tile depth (fp16 elements)
 constexpr float P_OUT_SCALE = 1.0f / 32768.0f;   // 2^-(3+12)
 constexpr float P_A_SCALE = 8.0f;
 
+// F16X3 range guard (d3d_kernels.h): every plane writer tracks max |scaled value| per lane; a lane whose value left the fp16
+// range (the clamp below fired: |x| > 8188) ORs bit 0 into this sticky per-device word once, at the end of its epilogue.
+__device__ unsigned g_range_x3p;
+__device__ __forceinline__ void range_note(float amax) {
+  if (amax > X3_HALF_MAX) atomicOr(&g_range_x3p, 1u);
+}
+
 // OUTSPLIT: 0 = fp32 C; 1 = hi/lo PLANES of C (two [M][N] fp16 matrices: the temporal attention kernel reads q/k/v
 // that way); 2 = PAIR layout (the consumer is another x3 GEMM).  Both carry 8*c (columns < qcols: 1*c, the q third
 // of a temporal qkv GEMM, which absorbs the dh^-0.5 = 2^-3 attention scale).
 template <int OUTSPLIT>
-__device__ __forceinline__ void store_split4(const float (&v)[4], float osc, _Float16* Cht, _Float16* Clt, int off, int poff) {
+__device__ __forceinline__ void store_split4(const float (&v)[4], float osc, _Float16* Cht, _Float16* Clt, int off, int poff,
+                                             float& amax) {
   h4 hh, ll;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float sc = __builtin_amdgcn_fmed3f(v[e] * osc, -65504.0f, 65504.0f);
+    const float raw = v[e] * osc;
+    amax = __builtin_fmaxf(amax, __builtin_fabsf(raw));
+    const float sc = __builtin_amdgcn_fmed3f(raw, -65504.0f, 65504.0f);
     hh[e] = (_Float16)sc;
     ll[e] = (_Float16)(sc - (float)hh[e]);
   }
@@ -150,10 +160,11 @@ __device__ __forceinline__ f2 gelu_fast2(f2 x) {
   return fma2(-(splat2(0.5f) * ax * (p * t)), e, m);
 }
 // 8 values -> fp16 (hi, lo) of osc * v, clamped to the fp16 range
-__device__ __forceinline__ void split8_x3(const f2 (&v)[4], float osc, h8& oh, h8& ol) {
+__device__ __forceinline__ void split8_x3(const f2 (&v)[4], float osc, h8& oh, h8& ol, float& amax) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     f2 sc = v[e] * osc;
+    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(sc.x)), __builtin_fabsf(sc.y));
     sc.x = __builtin_amdgcn_fmed3f(sc.x, -65504.0f, 65504.0f);
     sc.y = __builtin_amdgcn_fmed3f(sc.y, -65504.0f, 65504.0f);
     oh[2 * e] = (_Float16)sc.x;
@@ -246,6 +257,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
   const char* Rpb = reinterpret_cast<const char*>(Rpt);
   char* Cb = reinterpret_cast<char*>(Ct);
   float4 rr[TM][4];
+  float amax = 0.0f;   // range guard
   auto load_res = [&](int i) {
     if (i < gl || i >= gh) return;
 #pragma unroll
@@ -317,7 +329,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       }
       if (OUTSPLIT) {
         const int off = (16 * i + row) * N + 4 * rc4;
-        store_split4<OUTSPLIT>(v, osc, Cht, Clt, off, (16 * i + row) * 2 * N + pc);
+        store_split4<OUTSPLIT>(v, osc, Cht, Clt, off, (16 * i + row) * 2 * N + pc, amax);
       } else {
         *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(4 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -330,6 +342,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       __builtin_amdgcn_sched_barrier(0);   // two m-tiles (two patches) in flight at a time
     }
   }
+  if (OUTSPLIT) range_note(amax);
 }
 
 // The same epilogue for the forms that touch fp16 planes (plane / pair outputs, plane residual): the read-back side gives a
@@ -361,7 +374,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   const int pc = (int)pair_col(8 * rc8);
   const float2* srow = reinterpret_cast<const float2*>(lds_x);
   const int npart = (N + 63) >> 6;
-  constexpr int PFMAX = (FX & FX_SO) ? 3 : 4;                          // (the row-statistics form is 9 registers short of 4)
+  constexpr int PFMAX = (FX & FX_SO) ? 2 : 4;   // (row-statistics form: a window of 3 spills 26-82 accumulator registers around the last k-tile)
   constexpr int PF = (EPI == EPI_RESIDUAL) ? (TM < PFMAX ? TM : PFMAX) : 0;   // residual window, see x3q_epilogue
   const unsigned ob = (unsigned)(rrow * N + 8 * rc8) * 4u;            // this lane's 8 floats in row rrow (fp32 buffer)
   const unsigned obh = (unsigned)(rrow * N + 8 * rc8) * 2u;           // ... in an [M][N] fp16 plane
@@ -373,6 +386,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   char* Chb = reinterpret_cast<char*>(Cht);
   char* Clb = reinterpret_cast<char*>(Clt);
   uint4 rh[TM][2], rl[TM][2];
+  float amax = 0.0f;   // range guard
   auto load_res = [&](int i) {
     if (i < gl || i >= gh) return;
 #pragma unroll
@@ -438,7 +452,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       }
       if (OUTSPLIT) {
         h8 oh, ol;
-        split8_x3(v, osc, oh, ol);
+        split8_x3(v, osc, oh, ol, amax);
         if (OUTSPLIT == 2) {
           *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep)) = oh;
           *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep) + 64u) = ol;
@@ -459,6 +473,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (OUTSPLIT) range_note(amax);
 }
 
 // GELU + pair output straight from the accumulators (fc1 -> hidden activation).  The hidden activation is only ever the A
@@ -490,6 +505,7 @@ __device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned c
   char* Chb = reinterpret_cast<char*>(Cht);
   const unsigned ob = (unsigned)(m16 * 2 * N + 8 * q4) * 2u;        // row m16, piece q4 of the wave's first group (hi; lo 64 B on)
   const unsigned rstep = (unsigned)N * 64u;                          // 16 rows of the pair buffer
+  float amax = 0.0f;   // range guard
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i < gl || i >= gh) continue;
@@ -520,12 +536,13 @@ __device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned c
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_fast2(v[e]);
       h8 oh, ol;
-      split8_x3(v, P_A_SCALE, oh, ol);
+      split8_x3(v, P_A_SCALE, oh, ol, amax);
       *reinterpret_cast<h8*>(Chb + (ob + (unsigned)i * rstep + (unsigned)c * 128u)) = oh;
       *reinterpret_cast<h8*>(Chb + (ob + (unsigned)i * rstep + (unsigned)c * 128u) + 64u) = ol;
     }
     if (i & 1) __builtin_amdgcn_sched_barrier(0);
   }
+  range_note(amax);
 }
 
 // Post-norm epilogue (FX_PN): the workgroup's tile is BM full rows (WM == 1, N == 64 WN), so the block's post-norm
@@ -620,6 +637,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   for (int e = 0; e < 4; ++e) tv[e] = splat2(0.0f);
   if (tv_uniform) load8(fx.pn.tvec + n, tv);
   const int npart = N >> 6;
+  float amax = 0.0f;   // range guard
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -663,7 +681,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
         sq = row8_sum(sq);
         if (rc8 == 0) *reinterpret_cast<float2*>(fx.st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
         h8 oh, ol;
-        split8_x3(v, P_A_SCALE, oh, ol);
+        split8_x3(v, P_A_SCALE, oh, ol, amax);
         *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep)) = oh;
         *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep) + 64u) = ol;
       } else {
@@ -673,6 +691,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (OUTSPLIT == 2) range_note(amax);
 }
 
 // Tile shapes: BM = 16*TM*WM rows, BN = 64*WN columns, WM x WN waves, each wave (16 TM) x 64 = TM x 4 MFMA tiles.
@@ -689,7 +708,11 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
 // staged (by the caller for the first tile, by the previous tile otherwise), (ii) the LAST k-tile of this tile -- which
 // reads stage 1 when K/32 is even -- stages the first k-tile of the NEXT tile (m0n, n0n) into stage 0, so that it lands
 // under the last MFMAs and the epilogue, (iii) the epilogue's transpose patches live in stage 1.
-template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool PERSIST = false, bool SUB = false>
+// FULL: the caller guarantees a whole tile inside the matrix (m0 + BM <= M, n0 + BN <= N): only the unchecked epilogue is
+// instantiated -- the persistent walk sends ragged tiles through the SUB instantiation, so that its whole-tile path carries ONE
+// branch-free epilogue (the row-statistics form used to run the checked copy -- an exec-mask branch around every residual load
+// and store -- for every tile, because two copies under a run-time branch spilled accumulators).
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool PERSIST = false, bool SUB = false, bool FULL = false>
 __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                          const float* __restrict__ bias, const float* R, float* C, _Float16* Ch, _Float16* Cl,
                                          int M, int N, int K, int m0, int n0, int nt, int ntiles, int qcols,
@@ -848,26 +871,31 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   float* patch = reinterpret_cast<float*>(lds + (PERSIST ? STAGE : 0)) + wave * (2 * 16 * 64);
   const _Float16* Rpt = (FX & FX_RP) ? fx.Rp + 2 * tbase : nullptr;
   constexpr bool PLANES = (OUTSPLIT != 0 || (FX & FX_RP)) && !(EPI == EPI_RESIDUAL && !(FX & FX_RP));
-  const bool full = m0 + BM <= M && n0 + BN <= N;
+  const bool full = FULL || (m0 + BM <= M && n0 + BN <= N);
   bool done = false;
   if constexpr ((FX & FX_PN) != 0) {   // whole rows in the tile: post-norm here (the launcher guarantees N == BN)
     static_assert(WM == 1 && EPI == EPI_RESIDUAL && (FX & FX_RP) && OUTSPLIT != 1, "post-norm form");
     static_assert(STAGE >= 65536 + 2 * BM * WN * 4, "row-sum exchange beside the patches");
     float* xch = reinterpret_cast<float*>(lds + STAGE + 65536);
-    // (one instantiation, row checks always on: with a checked and an unchecked copy under a branch the accumulators spill)
-    x3q_epilogue_pn<TM, WN, OUTSPLIT, true>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N, gl, gh);
+    // (one copy per instantiation: with a checked and an unchecked copy under a branch the accumulators spill)
+    x3q_epilogue_pn<TM, WN, OUTSPLIT, !FULL>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N, gl, gh);
     done = true;
   } else if constexpr (EPI == EPI_GELU && OUTSPLIT == 2) {   // hidden activation, accumulator order: no transpose
     static_assert(!(FX & (FX_RP | FX_SO)), "fc1 form");
-    if (full)
+    if constexpr (FULL)
+      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
+    else if (full)
       x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
     else
       x3q_epilogue_acc<TM, WM, WN, FX, true>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
     done = true;
   } else if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
     if ((N & 7) == 0) {
-      // (the row-statistics form keeps one, checked, copy: with two copies under the branch its accumulators spill)
-      if (full && !(FX & FX_SO))
+      // (the row-statistics form keeps one copy per instantiation: with two copies under the branch its accumulators spill)
+      if constexpr (FULL)
+        x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh);
+      else if (full && !(FX & FX_SO))
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
                                                            mt0 - m0, lane, M, N, qcols, gl, gh);
       else
@@ -877,7 +905,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     }
   }
   if (!done) {
-    if (full)
+    if constexpr (FULL)
+      x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
+                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh);
+    else if (full)
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
                                                         nt0, mt0 - m0, lane, M, N, qcols, gl, gh);
     else
@@ -892,6 +923,18 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       d[0] = st_c0; d[1] = st_r0; d[2] = st_c1; d[3] = st_r1; d[4] = c2; d[5] = r2;
     }
   }
+}
+
+// The SUB instantiation (tail slices, ragged edge tiles) as a real function: one copy per kernel, register-allocated on its
+// own, so that what it spills (it carries the checked epilogues) stays out of the whole-tile path of the persistent walk.
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
+__device__ __attribute__((noinline)) void x3q_tile_sub(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
+                                                       const float* __restrict__ bias, const float* R, float* C, _Float16* Ch,
+                                                       _Float16* Cl, int M, int N, int K, int m0, int n0, int nt, int ntiles,
+                                                       int qcols, const X3Tail& fx, bool has_next, int m0n, int n0n, int tid_in,
+                                                       int sub_wm, int g_lo, int g_hi) {
+  x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, m0, n0, nt, ntiles, qcols, nullptr, fx,
+                                                      has_next, m0n, n0n, tid_in, sub_wm, g_lo, g_hi);
 }
 
 // Uniform launch: every workgroup one BM x BN tile; blockIdx -> tile keeps all N-tiles of an M-tile on one XCD.
@@ -989,15 +1032,19 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
     const bool has_next = k + 1 < nitems;
     int mtn = 0, ntn = 0, swn = -1, gln = 0, ghn = TM;
     if (has_next) item_of(k + 1, mtn, ntn, swn, gln, ghn);
-    x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, nullptr,
-                                                  fx, has_next, mtn * BM, ntn * BN, tid_o);
+    if ((mt + 1) * BM <= M && (nt + 1) * BN <= N)   // (wave-uniform) whole tile inside the matrix: the unchecked instantiation
+      x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true, false, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols,
+                                                                 nullptr, fx, has_next, mtn * BM, ntn * BN, tid_o);
+    else                                            // ragged edge tile: the checked epilogue lives in the SUB instantiation
+      x3q_tile_sub<TM, WM, WN, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, fx, has_next,
+                                                  mtn * BM, ntn * BN, tid_o, -1, 0, TM);
     if (!has_next) { stamp_end(); return; }
     ++k; mt = mtn; nt = ntn; sub_wm = swn; g_lo = gln; g_hi = ghn;
     __syncthreads();   // the epilogue's patches (stage 1) are read before the next tile's second k-tile is staged there
   }
   asm volatile("" : "+v"(tid_o));
-  x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, nullptr, fx,
-                                                      false, 0, 0, tid_o, sub_wm, g_lo, g_hi);
+  x3q_tile_sub<TM, WM, WN, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, fx, false, 0, 0,
+                                              tid_o, sub_wm, g_lo, g_hi);
   stamp_end();
 }
 
@@ -1037,13 +1084,8 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
 #define D3D_X3Q_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
   do {                                                                                                                    \
     auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_, FX_>;                                                                  \
-    static bool attr_done = false;                                                                                        \
-    if (!attr_done) {                                                                                                     \
-      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          (int)lds_bytes);                                                                \
-      if (ae != hipSuccess) return ae;                                                                                    \
-      attr_done = true;                                                                                                   \
-    }                                                                                                                     \
+    static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */                                       \
+    if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;                   \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WM * WN), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles,    \
                        ntiles, qcols, diag, tail);                                                                        \
   } while (0)
@@ -1078,14 +1120,8 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
                                      hipStream_t s, const X3Fold* fold) {
   const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
   const int tiles = mtiles * ntiles;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu = prop.multiProcessorCount / 8 * 8;
-    if (n_cu < 8) n_cu = 8;
-  }
+  int n_cu = device_cu_count() / 8 * 8;   // (per device)
+  if (n_cu < 8) n_cu = 8;
   const int grid = tiles < n_cu ? tiles / 8 * 8 : n_cu;
   if (grid < 8) return hipErrorInvalidValue;
   const X3Walk wk = x3q_walk(tiles, grid);
@@ -1104,13 +1140,8 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
 #define D3D_X3P_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
   do {                                                                                                                    \
     auto kfn = k_linear_x3q_persist<8, 2, 4, EPI_, OS_, FX_>;                                                                      \
-    static bool attr_done = false;                                                                                        \
-    if (!attr_done) {                                                                                                     \
-      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          (int)lds_bytes);                                                                \
-      if (ae != hipSuccess) return ae;                                                                                    \
-      attr_done = true;                                                                                                   \
-    }                                                                                                                     \
+    static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */                                       \
+    if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;                   \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,     \
                        qcols, wk, tail);                                                                                  \
   } while (0)
@@ -1145,14 +1176,8 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
   if (fold->pn.tvec && fold->pn.tvec_stride != 0 && fold->pn.rows_per_batch < 1) return hipErrorInvalidValue;
   const int mtiles = (M + 127) / 128, ntiles = 1;
   const int vtiles = ((mtiles + 7) / 8) * 8;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu = prop.multiProcessorCount / 8 * 8;
-    if (n_cu < 8) n_cu = 8;
-  }
+  int n_cu = device_cu_count() / 8 * 8;   // (per device)
+  if (n_cu < 8) n_cu = 8;
   static const bool persist_on = getenv("D3D_X3_NO_PERSIST") == nullptr;
   const bool persist = persist_on && mtiles >= 4 * n_cu && (K / PBK) % 2 == 0;
   const X3Walk wk = x3q_walk(mtiles * ntiles, n_cu);
@@ -1171,35 +1196,20 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
   do {                                                                                                                    \
     if (persist) {                                                                                                        \
       auto kfn = k_linear_x3q_persist<8, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                         \
-      static bool attr_done = false;                                                                                      \
-      if (!attr_done) {                                                                                                   \
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)lds_bytes);                                                              \
-        if (ae != hipSuccess) return ae;                                                                                  \
-        attr_done = true;                                                                                                 \
-      }                                                                                                                   \
+      static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */                                     \
+      if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;                 \
       hipLaunchKernelGGL(kfn, dim3(n_cu), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,   \
                          qcols, wk, tail);                                                                                \
     } else if (small) {   /* fewer 128-row tiles than CUs: 64-row tiles (same values: rows are independent) */            \
       auto kfn = k_linear_x3q<4, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                                 \
-      static bool attr_done = false;                                                                                      \
-      if (!attr_done) {                                                                                                   \
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)lds_small);                                                              \
-        if (ae != hipSuccess) return ae;                                                                                  \
-        attr_done = true;                                                                                                 \
-      }                                                                                                                   \
+      static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */                                     \
+      if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_small, attr_done)) return ae;                 \
       hipLaunchKernelGGL(kfn, dim3(vtiles64), dim3(512), lds_small, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles64, ntiles, \
                          qcols, diag, tail);                                                                              \
     } else {                                                                                                              \
       auto kfn = k_linear_x3q<8, 1, 8, EPI_RESIDUAL, OS_, FX_RP | FX_PN>;                                                 \
-      static bool attr_done = false;                                                                                      \
-      if (!attr_done) {                                                                                                   \
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)lds_bytes);                                                              \
-        if (ae != hipSuccess) return ae;                                                                                  \
-        attr_done = true;                                                                                                 \
-      }                                                                                                                   \
+      static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */                                     \
+      if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;                 \
       hipLaunchKernelGGL(kfn, dim3(vtiles), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles, \
                          qcols, diag, tail);                                                                              \
     }                                                                                                                     \
@@ -1227,6 +1237,13 @@ static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const 
 }
 
 void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }
+
+hipError_t range_flags_gemm(unsigned* flags, bool clear) {
+  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_x3p), sizeof(unsigned));
+  const unsigned zero = 0;
+  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_x3p), &zero, sizeof(unsigned));
+  return e;
+}
 
 // variant: 0 = auto (launch_x3q_auto).  experiments only (gemm_bench.py, two_rank_repeat.sh via D3D_X3_VARIANT):
 // 13 = 256x256, 4 = 256x128 (8 waves), 5 = 128x128 (8 waves, 2/CU), 7 = 256x128 (4 waves), 10 = 128x128 (4 waves, 2/CU),
@@ -1269,12 +1286,15 @@ __global__ __launch_bounds__(256) void k_split_x3(const float* __restrict__ x, _
   const int c = (int)(4 * i - row * cols);
   const float f[4] = {v.x, v.y, v.z, v.w};
   h4 a, b;
+  float amax = 0.0f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    amax = __builtin_fmaxf(amax, __builtin_fabsf(f[j] * P_A_SCALE));
     const float s = __builtin_amdgcn_fmed3f(f[j] * P_A_SCALE, -65504.0f, 65504.0f);
     a[j] = (_Float16)s;
     b[j] = (_Float16)(s - (float)a[j]);
   }
+  range_note(amax);
   _Float16* p = pair + row * 2 * cols + pair_col(c);
   *reinterpret_cast<h4*>(p) = a;
   *reinterpret_cast<h4*>(p + PAIR_LO) = b;

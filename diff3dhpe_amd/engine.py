@@ -155,6 +155,35 @@ class Engine:
         """Replay the whole DDIM loop as one hipGraph per (B, workspace) (eta == 0, no trajectory capture)."""
         _lib.check(_lib.lib().d3d_engine_set_graph_mode(self._h, int(on)))
 
+    def range_flags(self, clear: bool = True) -> int:
+        """F16X3 range guard (include/d3d.h): _lib.RANGE_ACT | _lib.RANGE_WEIGHT bits; synchronises the current stream."""
+        f = C.c_uint32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_engine_range_flags(self._h, C.byref(f), int(clear), self._stream()))
+        return int(f.value)
+
+    def check_range(self) -> None:
+        """Raise D3DError if an F16X3 operand left the fp16 range since the last check (use precision='fp32' then)."""
+        f = self.range_flags(clear=True)
+        if f:
+            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a GEMM weight (|w| > 15.99)")) if f & b]
+            raise _lib.D3DError("F16X3 operand range exceeded by " + " and ".join(what) +
+                                ": results are not fp32-accurate for this checkpoint/input -- use precision='fp32'")
+
+    def set_trace(self, capacity: int, views: int = 1) -> None:
+        """Debug trace: checksum every buffer the block-flow kernels write (0 turns it off); views: see include/d3d.h."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_engine_set_trace(self._h, int(capacity), int(views)))
+        self._trace_cap = int(capacity)
+
+    def trace_read(self):
+        """[(tag, checksum)] in launch order since the last read; tag fields: see include/d3d.h."""
+        cap = getattr(self, "_trace_cap", 0)
+        sums, tags, n = (C.c_uint64 * cap)(), (C.c_uint32 * cap)(), C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_engine_trace_read(self._h, sums, tags, cap, C.byref(n), self._stream()))
+        return [(int(tags[i]), int(sums[i])) for i in range(n.value)]
+
     def set_profiling(self, on: bool) -> None:
         _lib.check(_lib.lib().d3d_engine_set_profiling(self._h, int(on)))
 
@@ -169,6 +198,14 @@ class Engine:
             ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
             _lib.check(L.d3d_engine_profile_read(self._h, c, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
             out[L.d3d_kernel_class_name(c).decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+    def head(self, X: torch.Tensor) -> torch.Tensor:
+        """Regression head (LayerNorm eps 1e-5 + Linear D -> 3, S2S:217-220) on (rows, D) rows: (rows, 3), raw."""
+        X = _f32c(X, self.device).reshape(-1, self.cfg.embed_dim)
+        out = torch.empty((X.shape[0], 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_op_head(self._h, _ptr(X), _ptr(out), X.shape[0], self._stream()))
         return out
 
     def time_embedding(self, times: torch.Tensor) -> torch.Tensor:

@@ -25,9 +25,10 @@ def shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return t[lo:hi]
 
 
-def all_gather_pred(pred_local: torch.Tensor, B_total: int) -> torch.Tensor:
-    """Assemble (B_total, ...) on every rank from per-rank shards produced with shard_bounds()."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+def all_gather_pred(pred_local: torch.Tensor, B_total: int, force: bool = False) -> torch.Tensor:
+    """Assemble (B_total, ...) on every rank from per-rank shards produced with shard_bounds().
+    force: run the collective on a one-rank group too (bench.py with D3D_FORCE_DIST=1: RCCL path on a one-GPU box)."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return pred_local
     world, rank = dist.get_world_size(), dist.get_rank()
     if pred_local.is_cuda and dist.get_backend() == "gloo":

@@ -156,6 +156,32 @@ int d3d_engine_profile_read(d3d_engine* e, int32_t kernel_class, double* total_m
                             double* bytes);
 const char* d3d_kernel_class_name(int32_t kernel_class);
 
+/* ---- F16X3 range guard.  The F16X3 operand planes hold fp16 (hi, lo) pairs of 8*x (activations: residual stream, q/k/v,
+ * attention output, MLP hidden) and 4096*w (GEMM weights); values beyond the fp16 range are clamped: |x| > 8188, |w| > 15.99.
+ * Every kernel that writes such planes raises a sticky per-device flag when its clamp fired (no cost in a healthy run), and
+ * d3d_engine_commit_weights notes clamped weights.  d3d_engine_range_flags synchronises `stream` and returns
+ *   D3D_RANGE_ACT    an activation was clamped on this device since the flag was last cleared (any engine of the process)
+ *   D3D_RANGE_WEIGHT a weight of this engine was clamped at commit
+ * clear != 0 resets the activation flag.  A set flag means the F16X3 result is NOT fp32-accurate for this checkpoint / input:
+ * run the engine with D3D_PREC_FP32 (RUN:226-235 loads arbitrary checkpoints; random-init and LayerNorm-ed streams stay far
+ * inside the range). */
+#define D3D_RANGE_ACT 1u
+#define D3D_RANGE_WEIGHT 2u
+int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* stream);
+
+/* ---- debug trace: while on (capacity > 0 slots), every kernel of the F16X3 block flow and the head is followed on `stream`
+ * by a checksum launch over the rows it has just written (64-bit position-weighted word sums, order-independent), so two runs
+ * of the same call can be compared kernel by kernel (experiments/bisect_two_proc.py).  d3d_engine_trace_read synchronises
+ * `stream`, copies out up to cap (sum, tag) pairs in launch order and clears the log;
+ * views (1..8): every buffer is summed `views` times, launch v reading each line through a different XCD's L2 (workgroup ->
+ * data mapping rotated by v): the views of one buffer must agree -- a cross-XCD coherence check that needs no reference run.
+ * tag = view << 28 | forward << 16 | block << 8 | kernel << 4 | buffer (kernel: 0 embed, 1 stream entry, 2 qkv, 3 attention, 4 proj,
+ * 5 fc1, 6 fc2 [+ post-norm], 7 post-norm row kernel, 8 head / DDIM update [buffer 1: its y input], 9 the head launched a second
+ * time from the same inputs into scratch; buffer: 0 output, 1 row statistics).
+ * Graph replay is bypassed while tracing.  capacity 0 turns it off. */
+int d3d_engine_set_trace(d3d_engine* e, int32_t capacity, int32_t views);
+int d3d_engine_trace_read(d3d_engine* e, uint64_t* sums_host, uint32_t* tags_host, int32_t cap, int32_t* n, void* stream);
+
 /* ---- single-op hooks: the same kernels the engine launches, exposed for the parity tests -------------------------- */
 /* Time-embedding table (S2S:29-36,169-174 trunk, then every Block.time_mlp S2S:104-107) for n fp32 timesteps on the
  * device: out (n, 2*depth, D) in execution order STE0, TTE0, STE1, ...  scratch: n*(D + 4*D) floats. */
@@ -184,6 +210,9 @@ int d3d_op_linear_postnorm(const float* A_dev, const float* W_dev, const float* 
                            const float* gamma_dev, const float* beta_dev, float eps, const float* pos_dev, int32_t pos_div,
                            int32_t pos_mod, const float* tvec_dev, int64_t tvec_stride, int32_t rows_per_batch, float* Y_dev,
                            float* stats_dev, int32_t M, int32_t N, int32_t K, int32_t reps, float* avg_ms, void* stream);
+/* Regression head of the engine's weights (S2S:217-220: LayerNorm eps 1e-5 + Linear D -> 3) on rows x D fp32 rows:
+ * x0 (rows, 3), raw (no clamp, no DDIM update). */
+int d3d_op_head(d3d_engine* e, const float* X_dev, float* x0_dev, int32_t rows, void* stream);
 /* Row LayerNorm over the last axis (S2S:95,101,236,245 eps 1e-6; S2S:218 eps 1e-5). */
 int d3d_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* out_dev, int32_t rows,
                      int32_t D, float eps, void* stream);

@@ -393,22 +393,24 @@ def test_c_abi_error_behaviour_on_device():
 def test_bench_two_ranks_on_one_device():
     """The N>1 code path of bench.py (sharding, all-gather of predictions, max-over-ranks timing, rank-0 JSON) run as two
     torch.distributed ranks that share cuda:0 through gloo (RCCL cannot form a communicator on one device).  The gathered
-    MPJPE must equal the 1-rank value for the same global batch (per-sample noise is a slice of the global tensor)."""
+    MPJPE must equal the 1-rank value for the same global batch (per-sample noise is a slice of the global tensor).
+    Runs the DEFAULT kernels (post-norm GEMM form included): the run-to-run differences two processes on one GPU used to show
+    were single outputs of the head kernel's __shfl_xor (ds_bpermute) butterflies, not the GEMM (DESIGN.md section 4.1;
+    experiments/bisect_two_proc.py); the row kernels reduce by DPP + v_readlane since."""
     import json, os, subprocess, sys
     from conftest import ROOT
-    # D3D_NO_PN: with TWO PROCESSES on one GPU, workgroups that own (almost) all of a CU's LDS -- the post-norm GEMM form, 144-160
-    # KiB -- gave run-to-run different results in about 1 run of 8 on this pool (experiments/two_rank_repeat.sh; DESIGN.md 4.1);
-    # kernels up to 133 KiB never did (0 of 62), nor did any single-process run (experiments/one_rank_repeat.sh, 30 of 30).
-    # One process per GPU is the mode bench.py --gpus N runs in; this test shares a device only to exercise the N > 1 code path.
-    env = dict(os.environ, D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo", D3D_NO_PN="1")
-    common = ["--steps", "1", "--warmup", "0", "--frames", "27", "--sampling", "3", "--no-cpu-baseline"]
+    env = dict(os.environ, D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo")
+    env.pop("D3D_NO_PN", None)
+    common = ["--steps", "1", "--warmup", "0", "--frames", "27", "--sampling", "3", "--no-cpu-baseline", "--no-extras"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "3"] + common,
                          capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
     line2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    env1 = dict(os.environ)
+    env1.pop("D3D_NO_PN", None)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "6"] + common,
-                         capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, D3D_NO_PN="1"))
+                         capture_output=True, text=True, cwd=ROOT, timeout=600, env=env1)
     assert one.returncode == 0, one.stderr[-2000:]
     line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert line2["n_gpus"] == 2 and line2["config"]["global_batch"] == 6 and line1["config"]["global_batch"] == 6
@@ -416,3 +418,26 @@ def test_bench_two_ranks_on_one_device():
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline"):
         assert key in line2
+
+
+def test_bench_rccl_collectives_on_a_one_rank_group():
+    """bench.py's N > 1 communication path on RCCL itself, on a one-GPU box: `torchrun --nproc-per-node 1 bench.py --gpus 1`
+    with D3D_FORCE_DIST=1 executes init_process_group("nccl", device_id=...), barrier, all_gather_into_tensor and
+    all_reduce(MAX) on a one-rank communicator (RUN:216-218 replacement; the launcher starts before any GPU call of the child)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, D3D_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("D3D_DIST_BACKEND", None)
+    common = ["--steps", "2", "--warmup", "1", "--frames", "27", "--sampling", "3", "--no-cpu-baseline", "--no-extras"]
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "4"] + common,
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1 and line["dist"]["forced_single_rank_group"]
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "4"] + common,
+                           capture_output=True, text=True, cwd=ROOT, timeout=600, env={k: v for k, v in os.environ.items() if k != "D3D_FORCE_DIST"})
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert "dist" not in ref
+    assert line["mpjpe_vs_synthetic_gt"] == ref["mpjpe_vs_synthetic_gt"]        # the gathered prediction is the local one
