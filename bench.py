@@ -255,6 +255,8 @@ def main():
 
     if rank == 0:
         value = Bg * a.steps / elapsed
+        gemm_kinds = {k: v for k, v in prof.items() if k.startswith("linear_")}     # sub-classes of "linear": not added to the total
+        prof = {k: v for k, v in prof.items() if not k.startswith("linear_")}
         tot_ms = sum(v["ms"] for v in prof.values()) or 1.0
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
@@ -271,6 +273,11 @@ def main():
         roof.update({"kernel": dom, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                      "share_of_gpu_time": round(d["ms"] / tot_ms, 4), "traffic": None,
                      "by_kernel_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in prof.items() if v["launches"]}})
+        if any(v["launches"] for v in gemm_kinds.values()):
+            pk = PEAK_TFLOPS[a.precision]
+            roof["by_gemm"] = {k[7:]: {"avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                                       "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / pk, 4)}
+                               for k, v in gemm_kinds.items() if v["launches"]}
         # HBM bytes per launch cannot be counted from inside the process: they come from the separate rocprofv3 --pmc passes of
         # profiles/collect.sh (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE) and are labelled as such
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -176,10 +176,12 @@ hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 hipError_t launch_q_sample(const float* x_start, const float* noise, const int32_t* t, const float* sqrt_ac,
                            const float* somac, float* out, int B, int64_t n, hipStream_t s);
 
+// joint permutation of the horizontal flip, passed by value as a kernel argument (no device allocation, no copy, no sync)
+struct JointPerm { static constexpr int MAXJ = 64; int32_t p[MAXJ]; };
 hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, const uint8_t* mask, float scale,
-                            const int32_t* perm_dev, float* merged, double* sums, int B, int T, int J, hipStream_t s);
+                            const JointPerm& perm, float* merged, double* sums, int B, int T, int J, hipStream_t s);
 
-hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const int32_t* perm_dev, int n, int T, int J, int C,
+hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const JointPerm& perm, int n, int T, int J, int C,
                                 int flip, hipStream_t s);
 
 // debug trace: *out += position-weighted 64-bit sum of the buffer's 32-bit words (order-independent)

@@ -97,7 +97,7 @@ struct d3d_engine {
   }
 
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg)
-  struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+  struct ProfRec { int cls, cls2; hipEvent_t a, b; double flops, bytes; };
   bool profiling = false;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> ev_pool;
@@ -191,7 +191,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // RAII bracket: records an event pair around one kernel launch when profiling is on (no-op otherwise).
 struct Prof {
   d3d_engine* e; hipStream_t s; bool on; d3d_engine::ProfRec r{};
-  Prof(d3d_engine* e_, int cls, double flops, double bytes, hipStream_t s_) : e(e_), s(s_), on(e_->profiling) {
+  Prof(d3d_engine* e_, int cls, double flops, double bytes, hipStream_t s_, int cls2 = -1) : e(e_), s(s_), on(e_->profiling) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t ev = nullptr;
@@ -199,7 +199,7 @@ struct Prof {
       else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
       return ev;
     };
-    r.cls = cls; r.flops = flops; r.bytes = bytes; r.a = get(); r.b = get();
+    r.cls = cls; r.cls2 = cls2; r.flops = flops; r.bytes = bytes; r.a = get(); r.b = get();
     if (!r.a || !r.b) { on = false; return; }
     (void)hipEventRecord(r.a, s);
   }
@@ -330,7 +330,8 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     const bool temporal = (k & 1) != 0;
     auto gemm = [&](const uint16_t* A, const uint16_t* W, const float* bias, float* C, uint16_t* Ch, uint16_t* Cl, int outsplit,
                     int N, int K, int epi, int qcols, const X3Fold& f) -> hipError_t {
-      Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s);
+      const int sub = f.st_in ? (epi == EPI_GELU ? D3D_KC_LINEAR_FC1 : D3D_KC_LINEAR_QKV) : (K == D ? D3D_KC_LINEAR_PROJ : D3D_KC_LINEAR_FC2);
+      Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s, sub);
       return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f);
     };
     {  // q, k, v planes = norm1(x) Wqkv^T + b   (LayerNorm folded; q third pre-scaled by dh^-0.5)
@@ -950,23 +951,17 @@ int d3d_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, co
                   const int32_t* jl, const int32_t* jr, int32_t n_lr, float* merged, double* sums, int32_t B, int32_t T,
                   int32_t J, void* stream) {
   if (!pred || !gt || !sums || B <= 0 || T <= 0 || J <= 0) return fail(D3D_EINVAL, "bad argument");
+  if (J > JointPerm::MAXJ) return fail(D3D_EUNSUP, "more than 64 joints");
   if (pred_flip && n_lr > 0 && (!jl || !jr)) return fail(D3D_EINVAL, "joint lists required");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  std::vector<int32_t> perm(J);
-  for (int j = 0; j < J; ++j) perm[j] = j;
+  JointPerm perm{};
+  for (int j = 0; j < J; ++j) perm.p[j] = j;
   for (int i = 0; i < n_lr; ++i) {  // RUN:584-585: pf[:, :, left+right] = pf[:, :, right+left]
     if (jl[i] < 0 || jl[i] >= J || jr[i] < 0 || jr[i] >= J) return fail(D3D_EINVAL, "joint index out of range");
-    perm[jl[i]] = jr[i];
-    perm[jr[i]] = jl[i];
+    perm.p[jl[i]] = jr[i];
+    perm.p[jr[i]] = jl[i];
   }
-  int32_t* perm_dev = nullptr;
-  HIP_TRY(hipMalloc(&perm_dev, J * sizeof(int32_t)));
-  hipError_t e1 = hipMemcpyAsync(perm_dev, perm.data(), J * sizeof(int32_t), hipMemcpyHostToDevice, s);
-  hipError_t e2 = (e1 == hipSuccess) ? launch_tta_mpjpe(pred, pred_flip, gt, mask, scale, perm_dev, merged, sums, B, T, J, s) : e1;
-  hipError_t e3 = hipStreamSynchronize(s);
-  (void)hipFree(perm_dev);
-  HIP_TRY(e2);
-  HIP_TRY(e3);
+  HIP_TRY(launch_tta_mpjpe(pred, pred_flip, gt, mask, scale, perm, merged, sums, B, T, J, s));   // asynchronous on `stream`
   return D3D_OK;
 }
 
@@ -975,24 +970,17 @@ int d3d_num_windows(int32_t n_frames, int32_t T) { return (n_frames < 1 || T < 1
 int d3d_window_gather(const float* seq, int32_t n_frames, int32_t T, int32_t J, int32_t C, int32_t flip, const int32_t* jl,
                       const int32_t* jr, int32_t n_lr, float* out, uint8_t* mask, void* stream) {
   if (!seq || !out || n_frames < 1 || T < 1 || J < 1 || C < 1) return fail(D3D_EINVAL, "bad argument");
+  if (J > JointPerm::MAXJ) return fail(D3D_EUNSUP, "more than 64 joints");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int32_t* perm_dev = nullptr;
-  if (flip) {
-    std::vector<int32_t> perm(J);
-    for (int j = 0; j < J; ++j) perm[j] = j;
+  JointPerm perm{};
+  for (int j = 0; j < J; ++j) perm.p[j] = j;
+  if (flip)
     for (int i = 0; i < n_lr; ++i) {  // GEN:274-275: batch[:, left+right] = batch[:, right+left]
       if (!jl || !jr || jl[i] < 0 || jl[i] >= J || jr[i] < 0 || jr[i] >= J) return fail(D3D_EINVAL, "joint index out of range");
-      perm[jl[i]] = jr[i];
-      perm[jr[i]] = jl[i];
+      perm.p[jl[i]] = jr[i];
+      perm.p[jr[i]] = jl[i];
     }
-    HIP_TRY(hipMalloc(&perm_dev, J * sizeof(int32_t)));
-    hipError_t ce = hipMemcpyAsync(perm_dev, perm.data(), J * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    if (ce != hipSuccess) { (void)hipFree(perm_dev); HIP_TRY(ce); }
-    (void)hipStreamSynchronize(s);   // perm is a host temporary
-  }
-  hipError_t le = launch_window_gather(seq, out, mask, perm_dev, n_frames, T, J, C, flip ? 1 : 0, s);
-  if (perm_dev) { (void)hipStreamSynchronize(s); (void)hipFree(perm_dev); }
-  HIP_TRY(le);
+  HIP_TRY(launch_window_gather(seq, out, mask, perm, n_frames, T, J, C, flip ? 1 : 0, s));
   return D3D_OK;
 }
 
@@ -1064,6 +1052,9 @@ int d3d_engine_profile_read(d3d_engine* e, int32_t cls, double* total_ms, int64_
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
     e->prof_ms[r.cls] += ms; e->prof_flops[r.cls] += r.flops; e->prof_bytes[r.cls] += r.bytes; e->prof_launches[r.cls] += 1;
+    if (r.cls2 >= 0) {   // the same launch under its GEMM sub-class (qkv / proj / fc1 / fc2)
+      e->prof_ms[r.cls2] += ms; e->prof_flops[r.cls2] += r.flops; e->prof_bytes[r.cls2] += r.bytes; e->prof_launches[r.cls2] += 1;
+    }
     e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b);
   }
   e->recs.clear();
@@ -1075,7 +1066,8 @@ int d3d_engine_profile_read(d3d_engine* e, int32_t cls, double* total_ms, int64_
 }
 
 const char* d3d_kernel_class_name(int32_t cls) {
-  static const char* names[D3D_KC_COUNT] = {"linear", "attn_spatial", "attn_temporal", "layernorm", "embed", "head", "other"};
+  static const char* names[D3D_KC_COUNT] = {"linear", "attn_spatial", "attn_temporal", "layernorm", "embed", "head", "other",
+                                            "linear_qkv", "linear_proj", "linear_fc1", "linear_fc2"};
   return (cls >= 0 && cls < D3D_KC_COUNT) ? names[cls] : "?";
 }
 

@@ -393,6 +393,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
             o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
             __builtin_amdgcn_sched_barrier(0);
           }
+        } else if (VAR == 4) {   // experiment: no SLP packing of o[0] / o[1] (opaque after every update)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
+            o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+            asm volatile("" : "+v"(o[k]));
+          }
         } else {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -402,6 +409,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
         }
       }
     }
+    if (VAR == 5) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));   // experiment: idle before the reductions
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = wave_sum(o[k]);
     if (lane < 3) so[lr * 3 + lane] = (lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]));
@@ -441,17 +449,25 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
   if (a.rows <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
   const int grid = (a.rows + HEAD_ROWS - 1) / HEAD_ROWS;
-  static const int var = getenv("D3D_HEAD_VARIANT") ? atoi(getenv("D3D_HEAD_VARIANT")) : 0;   // (experiments/)
+  // D3D_HEAD_VARIANT (experiments/bisect_two_proc.py): the instruction streams compared on a GPU shared by two processes.
+  // Default 4 = one weight fragment loaded, waited for and consumed at a time, o[0] / o[1] never packed into one register pair
+  // (clean: 0 of 224 samplings, as variant 1, 0 of 416); 0 = the compiler's free schedule (three loads in flight behind
+  // counted waits, o[0] / o[1] in v_pk_* pairs: about 1 launch in 60 returned ONE wrong o[0]), 2 and 5 likewise.
+  static const int var = getenv("D3D_HEAD_VARIANT") ? atoi(getenv("D3D_HEAD_VARIANT")) : 4;
   if (a.D <= 256)
-    hipLaunchKernelGGL(k_head<1>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_head<1, 4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else if (a.D <= 512 && var == 1)
     hipLaunchKernelGGL((k_head<2, 1>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else if (a.D <= 512 && var == 2)
     hipLaunchKernelGGL((k_head<2, 2>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else if (a.D <= 512 && var == 0)
+    hipLaunchKernelGGL((k_head<2, 0>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+  else if (a.D <= 512 && var == 5)
+    hipLaunchKernelGGL((k_head<2, 5>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else if (a.D <= 512)
-    hipLaunchKernelGGL(k_head<2>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_head<2, 4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else
-    hipLaunchKernelGGL(k_head<4>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_head<4, 4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
@@ -480,7 +496,7 @@ hipError_t launch_q_sample(const float* x_start, const float* noise, const int32
 // perm[j] = index of the joint whose flipped prediction lands on j (identity when there is no TTA).
 __global__ __launch_bounds__(256) void k_tta_mpjpe(const float* __restrict__ pred, const float* __restrict__ pred_flip,
                                                    const float* __restrict__ gt, const uint8_t* __restrict__ mask,
-                                                   float scale, const int32_t* __restrict__ perm,
+                                                   float scale, JointPerm perm,
                                                    float* __restrict__ merged, double* __restrict__ sums, int BT, int J) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   float err = 0.f, cnt = 0.f;
@@ -489,7 +505,7 @@ __global__ __launch_bounds__(256) void k_tta_mpjpe(const float* __restrict__ pre
     float p[3];
     for (int k = 0; k < 3; ++k) p[k] = pred[(size_t)gid * 3 + k];
     if (pred_flip) {
-      const size_t src = ((size_t)bt * J + perm[j]) * 3;
+      const size_t src = ((size_t)bt * J + perm.p[j]) * 3;
       p[0] = __fdiv_rn(__fadd_rn(p[0], -pred_flip[src + 0]), 2.0f);
       p[1] = __fdiv_rn(__fadd_rn(p[1], pred_flip[src + 1]), 2.0f);
       p[2] = __fdiv_rn(__fadd_rn(p[2], pred_flip[src + 2]), 2.0f);
@@ -513,9 +529,10 @@ __global__ __launch_bounds__(256) void k_tta_mpjpe(const float* __restrict__ pre
 }
 
 hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, const uint8_t* mask, float scale,
-                            const int32_t* perm_dev, float* merged, double* sums, int B, int T, int J, hipStream_t s) {
+                            const JointPerm& perm, float* merged, double* sums, int B, int T, int J, hipStream_t s) {
+  if (J > JointPerm::MAXJ) return hipErrorInvalidValue;
   const int total = B * T * J;
-  hipLaunchKernelGGL(k_tta_mpjpe, dim3((total + 255) / 256), dim3(256), 0, s, pred, pred_flip, gt, mask, scale, perm_dev,
+  hipLaunchKernelGGL(k_tta_mpjpe, dim3((total + 255) / 256), dim3(256), 0, s, pred, pred_flip, gt, mask, scale, perm,
                      merged, sums, B * T, J);
   return hipGetLastError();
 }
@@ -525,7 +542,7 @@ hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const flo
 // one shifted back to end at the last frame, frames it shares with its predecessor masked out; sequences shorter than T
 // are edge-padded.  Optionally the horizontally flipped copy (x -> -x on channel 0, left/right joints swapped).
 __global__ __launch_bounds__(256) void k_window_gather(const float* __restrict__ seq, float* __restrict__ out,
-                                                       uint8_t* __restrict__ mask, const int32_t* __restrict__ perm, int n,
+                                                       uint8_t* __restrict__ mask, JointPerm perm, int n,
                                                        int T, int J, int C, int nc, int flip) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)nc * T * J;
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(256) void k_window_gather(const float* __restrict__
   const int c = (int)(gid / ((long long)J * T));
   int f = (c < nc - 1 ? c * T : n - T) + t;
   f = f < 0 ? 0 : (f > n - 1 ? n - 1 : f);
-  const int js = flip ? perm[j] : j;
+  const int js = flip ? perm.p[j] : j;
   const float* sp = seq + ((size_t)f * J + js) * C;
   float* op = out + (size_t)gid * C;
   for (int k = 0; k < C; ++k) op[k] = (flip && k == 0) ? -sp[k] : sp[k];
@@ -545,12 +562,12 @@ __global__ __launch_bounds__(256) void k_window_gather(const float* __restrict__
   }
 }
 
-hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const int32_t* perm_dev, int n, int T, int J, int C,
+hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const JointPerm& perm, int n, int T, int J, int C,
                                 int flip, hipStream_t s) {
-  if (n < 1 || T < 1 || J < 1 || C < 1) return hipErrorInvalidValue;
+  if (n < 1 || T < 1 || J < 1 || C < 1 || J > JointPerm::MAXJ) return hipErrorInvalidValue;
   const int nc = (n + T - 1) / T;
   const long long total = (long long)nc * T * J;
-  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, seq, out, mask, perm_dev, n, T, J, C,
+  hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, seq, out, mask, perm, n, T, J, C,
                      nc, flip);
   return hipGetLastError();
 }

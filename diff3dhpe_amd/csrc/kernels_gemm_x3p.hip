@@ -45,20 +45,22 @@ constexpr float P_A_SCALE = 8.0f;
 // range (the clamp below fired: |x| > 8188) ORs bit 0 into this sticky per-device word once, at the end of its epilogue.
 __device__ unsigned g_range_x3p;
 __device__ __forceinline__ void range_note(float amax) {
+#ifndef D3D_NO_RANGE_GUARD
   if (amax > X3_HALF_MAX) atomicOr(&g_range_x3p, 1u);
+#endif
 }
 
 // OUTSPLIT: 0 = fp32 C; 1 = hi/lo PLANES of C (two [M][N] fp16 matrices: the temporal attention kernel reads q/k/v
 // that way); 2 = PAIR layout (the consumer is another x3 GEMM).  Both carry 8*c (columns < qcols: 1*c, the q third
 // of a temporal qkv GEMM, which absorbs the dh^-0.5 = 2^-3 attention scale).
-template <int OUTSPLIT>
+template <int OUTSPLIT, bool GUARD = true>
 __device__ __forceinline__ void store_split4(const float (&v)[4], float osc, _Float16* Cht, _Float16* Clt, int off, int poff,
                                              float& amax) {
   h4 hh, ll;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float raw = v[e] * osc;
-    amax = __builtin_fmaxf(amax, __builtin_fabsf(raw));
+    if (GUARD) amax = __builtin_fmaxf(amax, __builtin_fabsf(raw));
     const float sc = __builtin_amdgcn_fmed3f(raw, -65504.0f, 65504.0f);
     hh[e] = (_Float16)sc;
     ll[e] = (_Float16)(sc - (float)hh[e]);
@@ -160,11 +162,12 @@ __device__ __forceinline__ f2 gelu_fast2(f2 x) {
   return fma2(-(splat2(0.5f) * ax * (p * t)), e, m);
 }
 // 8 values -> fp16 (hi, lo) of osc * v, clamped to the fp16 range
+template <bool GUARD = true>
 __device__ __forceinline__ void split8_x3(const f2 (&v)[4], float osc, h8& oh, h8& ol, float& amax) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     f2 sc = v[e] * osc;
-    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(sc.x)), __builtin_fabsf(sc.y));
+    if (GUARD) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(sc.x)), __builtin_fabsf(sc.y));
     sc.x = __builtin_amdgcn_fmed3f(sc.x, -65504.0f, 65504.0f);
     sc.y = __builtin_amdgcn_fmed3f(sc.y, -65504.0f, 65504.0f);
     oh[2 * e] = (_Float16)sc.x;
@@ -329,7 +332,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       }
       if (OUTSPLIT) {
         const int off = (16 * i + row) * N + 4 * rc4;
-        store_split4<OUTSPLIT>(v, osc, Cht, Clt, off, (16 * i + row) * 2 * N + pc, amax);
+        store_split4<OUTSPLIT, !(FX & FX_SO)>(v, osc, Cht, Clt, off, (16 * i + row) * 2 * N + pc, amax);   // (FX_SO: see x3q_epilogue8)
       } else {
         *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(4 * i + p) * rstep)) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -342,7 +345,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       __builtin_amdgcn_sched_barrier(0);   // two m-tiles (two patches) in flight at a time
     }
   }
-  if (OUTSPLIT) range_note(amax);
+  if constexpr (OUTSPLIT != 0 && !(FX & FX_SO)) range_note(amax);
 }
 
 // The same epilogue for the forms that touch fp16 planes (plane / pair outputs, plane residual): the read-back side gives a
@@ -374,7 +377,10 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   const int pc = (int)pair_col(8 * rc8);
   const float2* srow = reinterpret_cast<const float2*>(lds_x);
   const int npart = (N + 63) >> 6;
-  constexpr int PFMAX = (FX & FX_SO) ? 2 : 4;   // (row-statistics form: a window of 3 spills 26-82 accumulator registers around the last k-tile)
+#ifndef D3D_X3_PFMAX_SO
+#define D3D_X3_PFMAX_SO 3
+#endif
+  constexpr int PFMAX = (FX & FX_SO) ? D3D_X3_PFMAX_SO : 4;   // (the row-statistics form: 2 and 3 measure alike, 4 spills more)
   constexpr int PF = (EPI == EPI_RESIDUAL) ? (TM < PFMAX ? TM : PFMAX) : 0;   // residual window, see x3q_epilogue
   const unsigned ob = (unsigned)(rrow * N + 8 * rc8) * 4u;            // this lane's 8 floats in row rrow (fp32 buffer)
   const unsigned obh = (unsigned)(rrow * N + 8 * rc8) * 2u;           // ... in an [M][N] fp16 plane
@@ -452,7 +458,11 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       }
       if (OUTSPLIT) {
         h8 oh, ol;
-        split8_x3(v, osc, oh, ol, amax);
+        if constexpr ((FX & FX_SO) != 0) {   // range guard of this form: by the consumer of its row statistics (x3q_tile, FX_LNF) -- this
+          split8_x3<false>(v, osc, oh, ol, amax);   // epilogue sits at the 256-register limit: one more live register costs it 60 spilled
+        } else {                                  // accumulators (+17 % per launch)
+          split8_x3<true>(v, osc, oh, ol, amax);
+        }
         if (OUTSPLIT == 2) {
           *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep)) = oh;
           *reinterpret_cast<h8*>(Chb + (obp + (unsigned)(2 * i + p) * rstep) + 64u) = ol;
@@ -473,7 +483,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (OUTSPLIT) range_note(amax);
+  if constexpr (OUTSPLIT != 0 && !(FX & FX_SO)) range_note(amax);
 }
 
 // GELU + pair output straight from the accumulators (fc1 -> hidden activation).  The hidden activation is only ever the A
@@ -747,6 +757,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           const float2 t = *reinterpret_cast<const float2*>(fx.st_in + 2 * ((size_t)row * fx.st_np + p));
           sm += t.x; sq += t.y;
         }
+      // range guard for the producer of these rows (the proj / fc2 epilogues write the planes of x and these statistics of the
+      // unclamped values): a clamped element |x| > 8188 implies sum x^2 > 8188^2 -- never missed; rows of ~512 values above ~360
+      // would raise it falsely, a LayerNorm-ed stream is orders of magnitude below
+      if (sq >= (X3_HALF_MAX * 0.125f) * (X3_HALF_MAX * 0.125f)) range_note(2.0f * X3_HALF_MAX);
       const float mean = sm / (float)K;
       const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
       const float rstd = 1.0f / sqrtf(var + fx.eps);
@@ -927,8 +941,15 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
 
 // The SUB instantiation (tail slices, ragged edge tiles) as a real function: one copy per kernel, register-allocated on its
 // own, so that what it spills (it carries the checked epilogues) stays out of the whole-tile path of the persistent walk.
+// (measured as a real, non-inlined function -- one copy, register-allocated on its own --: the kernels then carry a scratch
+// segment and the post-norm fc2 launch took 6 % longer; inlined it stays)
+#ifdef D3D_X3_SUB_NOINLINE
+#define D3D_SUB_ATTR __attribute__((noinline))
+#else
+#define D3D_SUB_ATTR __forceinline__
+#endif
 template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
-__device__ __attribute__((noinline)) void x3q_tile_sub(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
+__device__ D3D_SUB_ATTR void x3q_tile_sub(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                                        const float* __restrict__ bias, const float* R, float* C, _Float16* Ch,
                                                        _Float16* Cl, int M, int N, int K, int m0, int n0, int nt, int ntiles,
                                                        int qcols, const X3Tail& fx, bool has_next, int m0n, int n0n, int tid_in,
@@ -1032,6 +1053,12 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
     const bool has_next = k + 1 < nitems;
     int mtn = 0, ntn = 0, swn = -1, gln = 0, ghn = TM;
     if (has_next) item_of(k + 1, mtn, ntn, swn, gln, ghn);
+#ifdef D3D_X3_NO_FULL   // (experiments: the round-1 walk -- one instantiation with run-time edge checks for every whole tile)
+    if (true)
+      x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true, false, false>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols,
+                                                                  nullptr, fx, has_next, mtn * BM, ntn * BN, tid_o);
+    else
+#endif
     if ((mt + 1) * BM <= M && (nt + 1) * BN <= N)   // (wave-uniform) whole tile inside the matrix: the unchecked instantiation
       x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, true, false, true>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols,
                                                                  nullptr, fx, has_next, mtn * BM, ntn * BN, tid_o);

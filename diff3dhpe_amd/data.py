@@ -1,0 +1,190 @@
+"""Evaluation-side dataset adaptor: from the reference's data files
+(data_3d_<dataset>.npz, data_2d_<dataset>_<keypoints>.npz) to the batches diff3dhpe_amd.evaluate.evaluate() consumes --
+what the reference's ``load_Dataset(..., 'test')`` + ``ChunkedGenerator(out_all=True)`` + DataLoader(shuffle=False) hand to
+its evaluate() (data/load_noisy_data.py:20-291, common/nosiy_generators.py:14-338, RUN:167-170, 562-575).
+
+Host-side data preparation only (numpy / torch-CPU index and coordinate math, once per data set); nothing here is on the
+DDIM hot path.  Camera tables and the skeleton are NOT shipped: they come from a dataset object the caller supplies --
+``load_h36m()`` imports ``common.h36m_dataset.Human36mDataset`` from the user's reference checkout at run time (integration
+depth 1 of INTEGRATION.md runs inside that checkout) -- or from any object with the same three accessors (tests use
+``diff3dhpe_amd.synth.synth_mocap``).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def world_to_camera(X: np.ndarray, R: np.ndarray, t: np.ndarray) -> np.ndarray:
+    """camera.py:33-35 with quaternion.py:13-38: rotate (X - t) by the inverse of the unit quaternion R.  Same fp32 torch
+    operations in the same order as the reference (its `wrap` helper runs them in torch), so results are bit-identical."""
+    q = torch.from_numpy(np.asarray(R))
+    q = torch.cat((q[..., :1], -q[..., 1:]), dim=-1)                       # qinverse
+    v = torch.from_numpy(X - t)
+    q = torch.from_numpy(np.tile(q.numpy(), (*X.shape[:-1], 1)))
+    qvec = q[..., 1:]
+    uv = torch.cross(qvec, v, dim=len(q.shape) - 1)
+    uuv = torch.cross(qvec, uv, dim=len(q.shape) - 1)
+    return (v + 2 * (q[..., :1] * uv + uuv)).numpy()
+
+
+def normalize_screen_coordinates(X: np.ndarray, w: int, h: int) -> np.ndarray:
+    """camera.py:17-21: [0, w] -> [-1, 1], aspect ratio preserved (the float64 intermediate of the reference included)."""
+    assert X.shape[-1] == 2
+    return X / w * 2 - [1, h / w]
+
+
+class MocapMeta:
+    """The three accessors of the reference's MocapDataset this adaptor uses (mocap_dataset.py:27-40), for callers that
+    have positions / cameras / skeleton sides at hand instead of a reference dataset object."""
+
+    def __init__(self, positions, cameras, joints_left, joints_right):
+        self._data = {s: {a: {"positions": p, "cameras": cameras[s]} for a, p in acts.items()} for s, acts in positions.items()}
+        self._cameras = cameras
+        self._jl, self._jr = list(joints_left), list(joints_right)
+
+    def __getitem__(self, key):
+        return self._data[key]
+
+    def cameras(self):
+        return self._cameras
+
+    def joints_left(self):
+        return self._jl
+
+    def joints_right(self):
+        return self._jr
+
+
+def _sides(dataset):
+    if hasattr(dataset, "skeleton"):
+        sk = dataset.skeleton()
+        return list(sk.joints_left()), list(sk.joints_right())
+    return list(dataset.joints_left()), list(dataset.joints_right())
+
+
+class EvalData:
+    """Test split of a mocap data set, windowed for sequence-to-sequence evaluation.
+
+    dataset      reference dataset object (Human36mDataset) or MocapMeta: dataset[subject][action]['positions'] world 3D,
+                 dataset.cameras()[subject][i] with 'orientation', 'translation', 'res_w', 'res_h'
+    keypoints    positions_2d dict of data_2d_*.npz: [subject][action] -> list over cameras of (n, J, 2+) pixel tracks
+    symmetry     (kps_left, kps_right) = metadata['keypoints_symmetry']
+    Mirrors load_Dataset.__init__/prepare_data/fetch for split='test', out_all=True (LOAD:20-231): camera-space,
+    root-relative 3D (LOAD:121-125), tracks truncated to the mocap length (LOAD:151-158), screen-normalised 2D
+    (LOAD:162-171), subject/action/camera iteration order, action filter by prefix (LOAD:185-193), downsampling (LOAD:228-
+    231) and scale = max |root-relative camera-space coordinate| over the WHOLE data set (h36m_dataset.py:260-275,
+    LOAD:45-52)."""
+
+    def __init__(self, dataset, keypoints: Dict, symmetry, subjects: Sequence[str], number_of_frames: int,
+                 actions: Optional[Sequence[str]] = None, downsample: int = 1, all_subjects: Optional[Sequence[str]] = None):
+        self.T = int(number_of_frames)
+        self.kps_left, self.kps_right = list(symmetry[0]), list(symmetry[1])
+        self.joints_left, self.joints_right = _sides(dataset)
+        cams = dataset.cameras()
+        # scale: over every subject / action / camera of the data set, as the dataset constructor computes it
+        lo, hi = np.inf, -np.inf
+        for subject in (all_subjects if all_subjects is not None else list(cams.keys())):
+            try:
+                acts = dataset[subject]
+            except KeyError:
+                continue
+            for action in acts.keys():
+                for cam in cams[subject]:
+                    p = world_to_camera(acts[action]["positions"], R=cam["orientation"], t=cam["translation"])
+                    c = p - p[:, :1]
+                    lo, hi = min(lo, float(c.min())), max(hi, float(c.max()))
+        pre = getattr(dataset, "_pos_3d_min", None)
+        if pre is not None:     # a reference dataset object has already done exactly this
+            lo, hi = float(dataset._pos_3d_min), float(dataset._pos_3d_max)
+        self.scale = float(abs(hi) if abs(hi) >= abs(lo) else abs(lo))
+        self.sequences: List = []       # (key, poses_2d (n, J, 2+), poses_3d (n, J, 3))
+        for subject in subjects:
+            for action in keypoints[subject].keys():
+                if actions is not None and not any(action.startswith(a) for a in actions):
+                    continue
+                pos = dataset[subject][action]["positions"]
+                for i, cam in enumerate(cams[subject]):
+                    p3 = world_to_camera(pos, R=cam["orientation"], t=cam["translation"])
+                    p3 -= p3[:, :1]
+                    kps = np.array(keypoints[subject][action][i])
+                    assert kps.shape[0] >= p3.shape[0], "2D track shorter than the mocap sequence"
+                    kps = kps[: p3.shape[0]].copy()
+                    kps[..., :2] = normalize_screen_coordinates(kps[..., :2], w=cam["res_w"], h=cam["res_h"])
+                    if downsample > 1:
+                        kps, p3 = kps[::downsample], p3[::downsample]
+                    self.sequences.append(((subject, action, i), kps, p3))
+
+    # ---- window table of one sequence (GEN:27-48; the same table d3d_window_gather builds on the device)
+    def _windows(self, n: int):
+        T = self.T
+        nc = (n + T - 1) // T
+        out = []
+        for c in range(nc):
+            start = c * T if c < nc - 1 else n - T
+            unused = (nc * T - n) if (c == nc - 1 and n >= T) else 0
+            out.append((start, unused))
+        return out
+
+    def _gather(self, seq: np.ndarray, start: int, flip: bool) -> np.ndarray:
+        n, T = seq.shape[0], self.T
+        idx = np.clip(np.arange(start, start + T), 0, n - 1)     # edge padding when the sequence is shorter than T (GEN:259-262)
+        w = seq[idx].copy()
+        if flip:                                                # GEN:272-276
+            w[:, :, 0] *= -1
+            w[:, self.kps_left + self.kps_right] = w[:, self.kps_right + self.kps_left]
+        return w
+
+    def __len__(self) -> int:
+        return sum(len(self._windows(s[1].shape[0])) for s in self.sequences)
+
+    def items(self) -> Iterator[Dict[str, np.ndarray]]:
+        """One evaluation window at a time, in the reference's `pairs` order (LOAD:243-291 __getitem__)."""
+        for key, p2, p3 in self.sequences:
+            for start, unused in self._windows(p2.shape[0]):
+                gt = self._gather(p3, start, False)
+                mask = np.full(self.T, True, dtype=bool)
+                if p2.shape[0] >= self.T:
+                    mask[:unused] = False
+                yield {"key": key, "inputs_3d": gt, "inputs_3d_norm": gt / self.scale, "inputs_2d": self._gather(p2, start, False),
+                       "inputs_2d_flip": self._gather(p2, start, True), "target_mask": mask}
+
+    def batches(self, batch_size: int) -> Iterator[Dict[str, torch.Tensor]]:
+        """DataLoader(shuffle=False) batches (RUN:169-170) as the dicts evaluate() takes."""
+        buf: List[Dict[str, np.ndarray]] = []
+
+        def flush():
+            return {k: torch.from_numpy(np.stack([b[k] for b in buf])) for k in ("inputs_2d", "inputs_2d_flip", "inputs_3d",
+                                                                                  "inputs_3d_norm", "target_mask")}
+        for it in self.items():
+            buf.append(it)
+            if len(buf) == batch_size:
+                yield flush()
+                buf = []
+        if buf:
+            yield flush()
+
+
+def load_eval_npz(dataset, root_path: str, dataset_name: str, keypoints_name: str, subjects: Sequence[str],
+                  number_of_frames: int, actions: Optional[Sequence[str]] = None, downsample: int = 1) -> EvalData:
+    """EvalData from `root_path/data_2d_<dataset>_<keypoints>.npz` (LOAD:128-137) and a dataset object."""
+    kp = np.load(f"{root_path}/data_2d_{dataset_name}_{keypoints_name}.npz", allow_pickle=True)
+    sym = kp["metadata"].item()["keypoints_symmetry"]
+    return EvalData(dataset, kp["positions_2d"].item(), sym, subjects, number_of_frames, actions, downsample)
+
+
+def load_h36m(root_path: str, keypoints_name: str = "cpn_ft_h36m_dbb", subjects_test: str = "S9,S11", number_of_frames: int = 243,
+              actions: str = "*", downsample: int = 1) -> EvalData:
+    """Human3.6M test split.  Needs the user's Diff3DHPE checkout on sys.path (run from inside it, as the unchanged runner
+    does): its `common.h36m_dataset.Human36mDataset` supplies the camera tables and the 32 -> 17 joint reduction
+    (h36m_dataset.py:18-292), neither of which this package ships."""
+    try:
+        from common.h36m_dataset import Human36mDataset      # the reference checkout's module (compat shim extends `common`)
+    except ImportError as e:
+        raise ImportError("load_h36m() needs the Diff3DHPE checkout on sys.path for common.h36m_dataset (camera tables, skeleton); "
+                          "use EvalData(...) with your own dataset object otherwise") from e
+    ds = Human36mDataset(f"{root_path}/data_3d_h36m.npz")
+    return load_eval_npz(ds, root_path, "h36m", keypoints_name, subjects_test.split(","), number_of_frames,
+                         None if actions == "*" else actions.split(","), downsample)

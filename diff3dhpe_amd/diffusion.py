@@ -9,6 +9,7 @@ The only host arithmetic left here is the init-time fp64 schedule tables (DIFF:1
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from typing import List, Optional
 
@@ -85,6 +86,9 @@ class GaussianDiffusion(nn.Module):
         for name, val in tables.items():  # registered as fp32 in this order (DIFF:149-183)
             self.register_buffer(name, val.to(torch.float32))
         self._sched_sig = {}
+        # debug mode (or D3D_CHECK_RANGE=1): after every sampling ask the engine's F16X3 range guard whether an operand left the
+        # fp16 range of its planes and raise D3DError if so (one stream synchronisation per call; include/d3d.h)
+        self.check_range = bool(os.environ.get("D3D_CHECK_RANGE"))
 
     # ------------------------------------------------------------------ engine plumbing
     def _engine(self, device: torch.device):
@@ -112,23 +116,38 @@ class GaussianDiffusion(nn.Module):
         return torch.clamp(x_start, min=-1., max=1.) if self.clip_denoised else x_start
 
     def _draw(self, x_in, target_shape, init_noise, step_noise):
+        """Noise for one sampling.  When the caller supplies none, the global generator is consumed exactly as the reference
+        consumes it -- one torch.randn(target_shape) (DIFF:275), then one randn_like per non-final step, S - 1 draws, whether
+        or not eta multiplies them by zero (DIFF:293) -- so that under the unchanged runner (torch.manual_seed, RUN) the
+        second sampling of a batch (flip-TTA), later batches and repeat_n start from the same generator state as there."""
         dev = self.model._compute_device(x_in, self.betas)
         shape = tuple(int(s) for s in target_shape)
-        if init_noise is None:
+        S = self.sampling_timesteps
+        drew_init = init_noise is None
+        if drew_init:
             init_noise = torch.randn(shape, device=dev)          # DIFF:275
-        if step_noise is None and self.ddim_sampling_eta != 0:
-            step_noise = torch.randn((self.sampling_timesteps,) + shape, device=dev)   # DIFF:293, one draw per step
+        if step_noise is None and (drew_init or self.ddim_sampling_eta != 0):
+            draws = [torch.randn(shape, device=dev) for _ in range(S - 1)]          # DIFF:293 (the last pair has time_next < 0)
+            if self.ddim_sampling_eta != 0:
+                step_noise = torch.stack(draws + [torch.zeros(shape, device=dev)], dim=0)   # entry S-1 is never read
         return dev, init_noise, step_noise
 
     @torch.no_grad()
     def ddim_sample_loop(self, x_in, target_shape, init_noise=None, step_noise=None):
         dev, init_noise, step_noise = self._draw(x_in, target_shape, init_noise, step_noise)
-        return self._engine(dev).ddim_sample(x_in, init_noise, step_noise).to(x_in.device)
+        eng = self._engine(dev)
+        y0 = eng.ddim_sample(x_in, init_noise, step_noise)
+        if self.check_range:
+            eng.check_range()
+        return y0.to(x_in.device)
 
     @torch.no_grad()
     def ddim_sample_loop_ouput_reverse_diffusion(self, x_in, target_shape, init_noise=None, step_noise=None):
         dev, init_noise, step_noise = self._draw(x_in, target_shape, init_noise, step_noise)
-        y0, rev, x0s = self._engine(dev).ddim_sample(x_in, init_noise, step_noise, trajectory=True)
+        eng = self._engine(dev)
+        y0, rev, x0s = eng.ddim_sample(x_in, init_noise, step_noise, trajectory=True)
+        if self.check_range:
+            eng.check_range()
         if self.seq2frame:  # DIFF-S2F:319 records the initial noise as trajectory entry 0
             rev = torch.cat([init_noise.to(rev.device).unsqueeze(-1), rev], dim=-1)
         return y0.to(x_in.device), rev.to(x_in.device), x0s.to(x_in.device)

@@ -73,3 +73,58 @@ def synth_inputs(B: int, T: int, J: int = 17, seed: int = 42, cpn_jitter: bool =
     gt = rng.uniform(-1.0, 1.0, (B, T, J, 3))
     gt = (gt - gt[:, :, :1, :]).astype(np.float32)
     return {"x2d": x2d, "noise": noise, "gt3d": gt}
+
+
+# ---------------------------------------------------------------------------------------------- synthetic mocap data set
+SYNTH_JOINTS_LEFT = [4, 5, 6, 11, 12, 13]      # 17-joint skeleton sides (what the reference's H36M skeleton has after remove_joints)
+SYNTH_JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]
+SYNTH_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]
+
+
+def synth_mocap(seed: int = 0):
+    """A tiny H36M-SHAPED data set with synthetic cameras (tests/golden/dataset_eval.npz; tests of diff3dhpe_amd.data).
+
+    Returns (positions, cameras, keypoints, metadata):
+      positions[subject][action] (n, 17, 3) float32 world coordinates in metres  -> the 'positions_3d' of data_3d_*.npz
+      cameras[subject] = list of dicts {orientation (4,) unit quaternion, translation (3,) metres, res_w, res_h, intrinsic (9,)}
+      keypoints[subject][action] = list over cameras of (n or n + extra, 17, 2) float32 pixel coordinates -> data_2d_*.npz
+      metadata = {'num_joints': 17, 'keypoints_symmetry': [left, right]}
+    Sequence lengths exercise a window shorter than T, an exact multiple and ragged tails; one camera track carries extra
+    frames (H36M videos do: the loader truncates them)."""
+    rng = np.random.RandomState(1000 + seed)
+    lengths = {"S9": {"Walk 1": 70, "Sit": 27}, "S11": {"Walk 1": 100, "Eat 2": 55, "Wait": 9}}
+    res = [(1000, 1002), (1000, 1000), (1000, 1000), (1000, 1002)]
+    positions, cameras, keypoints = {}, {}, {}
+    for subject, acts in lengths.items():
+        cams = []
+        for ci in range(2):
+            q = rng.standard_normal(4)
+            q = (q / np.linalg.norm(q)).astype(np.float32)
+            t = rng.uniform(-3.0, 3.0, 3).astype(np.float32)
+            cams.append({"orientation": q, "translation": t, "res_w": res[ci][0], "res_h": res[ci][1],
+                         "intrinsic": rng.uniform(-1.0, 1.0, 9).astype(np.float32)})
+        cameras[subject] = cams
+        positions[subject], keypoints[subject] = {}, {}
+        for action, n in acts.items():
+            root = np.cumsum(rng.normal(0.0, 0.02, (n, 1, 3)), axis=0) + rng.uniform(-1.0, 1.0, (1, 1, 3))
+            body = rng.uniform(-0.9, 0.9, (1, 17, 3)) + np.cumsum(rng.normal(0.0, 0.01, (n, 17, 3)), axis=0)
+            positions[subject][action] = (root + body).astype(np.float32)
+            tracks = []
+            for ci in range(2):
+                extra = 3 if (ci == 1 and action == "Walk 1") else 0
+                px = rng.uniform(100.0, 900.0, (1, 17, 2)) + np.cumsum(rng.normal(0.0, 3.0, (n + extra, 17, 2)), axis=0)
+                tracks.append(px.astype(np.float32))
+            keypoints[subject][action] = tracks
+    meta = {"num_joints": 17, "keypoints_symmetry": [list(SYNTH_JOINTS_LEFT), list(SYNTH_JOINTS_RIGHT)]}
+    return positions, cameras, keypoints, meta
+
+
+def write_synth_mocap(root: str, seed: int = 0, dataset: str = "h36m", keypoints_name: str = "synth"):
+    """Write data_3d_<dataset>.npz and data_2d_<dataset>_<keypoints>.npz in the layout the reference loaders read."""
+    import os
+    positions, cameras, keypoints, meta = synth_mocap(seed)
+    os.makedirs(root, exist_ok=True)
+    np.savez(os.path.join(root, f"data_3d_{dataset}.npz"), positions_3d=np.array(positions, dtype=object))
+    np.savez(os.path.join(root, f"data_2d_{dataset}_{keypoints_name}.npz"), positions_2d=np.array(keypoints, dtype=object),
+             metadata=np.array(meta, dtype=object))
+    return positions, cameras, keypoints, meta

@@ -73,11 +73,42 @@ def child(a):
                         k = int(d[i].nonzero()[0])
                         pr = (xn * W[k]).view(2, 64, 4).sum((0, 2))          # per-lane partial of o[k]
                         exact = float(pr.sum() + hb[k])
+                        P = (xn.view(1, 2, 64, 4) * W.view(3, 2, 64, 4))            # [k', i, lane, e] element products
+                        pl = P.sum(3)                                                # [k', i, lane] float4 partials
                         for nm2, val in (("first", float(u[i, k])), ("second", float(v[i, k]))):
                             err = val - max(-1.0, min(1.0, exact))
-                            near = (pr + err).abs().argmin()
-                            print(f"   row {i} k {k}: {nm2} {val:.7f} exact {exact:.7f} err {err:+.3e}; lane partial closest to -err: lane {int(near)} "
-                                  f"({float(pr[near]):+.4e}); x[0:4] {x[:4].tolist()}", flush=True)
+                            if abs(err) < 1e-5 or abs(val) >= 1.0:
+                                continue
+                            hyp = {}
+                            for ii in range(2):
+                                hyp[f"half {ii} dropped"] = -float(pl[k, ii].sum())
+                                for kk in range(3):
+                                    if kk != k:
+                                        hyp[f"half {ii} of row k'={kk} instead"] = float(pl[kk, ii].sum() - pl[k, ii].sum())
+                                hyp[f"half {ii}: other half's weights"] = float((xn.view(2, 64, 4)[ii] * W[k].view(2, 64, 4)[1 - ii]).sum() - pl[k, ii].sum())
+                            best = min(hyp, key=lambda h: abs(hyp[h] - err))
+                            cands = []
+                            for ii in range(2):
+                                for sign, nm3 in ((-1.0, "dropped"), (1.0, "doubled")):
+                                    dd = (sign * pl[k, ii] - err).abs()
+                                    cands.append((float(dd.min()), f"lane {int(dd.argmin())} float4 {ii} {nm3}"))
+                                    de = (sign * P[k, ii] - err).abs()
+                                    cands.append((float(de.min()), f"element lane {int(de.argmin()) // 4} i {ii} e {int(de.argmin()) % 4} {nm3}"))
+                                for kk in range(3):
+                                    if kk != k:
+                                        dd = ((pl[kk, ii] - pl[k, ii]) - err).abs()
+                                        cands.append((float(dd.min()), f"lane {int(dd.argmin())} float4 {ii} took row k'={kk}"))
+                            # a contiguous block of lanes (multiples of 4) whose half-ii partial is missing / doubled: what a DPP or
+                            # LDS read of the accumulator register would see if the last packed add had not yet landed in those lanes
+                            for ii in range(2):
+                                cs = torch.cat([torch.zeros(1, dtype=pl.dtype, device=pl.device), pl[k, ii].cumsum(0)])
+                                for a0 in range(0, 64, 4):
+                                    for b0 in range(a0 + 4, 65, 4):
+                                        blk = float(cs[b0] - cs[a0])
+                                        cands.append((abs(-blk - err), f"lanes [{a0},{b0}) half {ii} missing"))
+                            cands.sort()
+                            print(f"   row {i} k {k} err {err:+.6e} | wave-level best: {best} ({hyp[best]:+.6e}) | lane-level best: {cands[0][1]} (residual {cands[0][0]:.2e}), "
+                                  f"next {cands[1][1]} ({cands[1][0]:.2e})", flush=True)
     np.savez(a.out, sums=np.array(sums, dtype=np.uint64), tags=np.array(tags or [], dtype=np.uint32),
              outs=np.array(outs, dtype=np.uint64))
 

@@ -149,7 +149,12 @@ int d3d_window_gather(const float* seq_dev, int32_t n_frames, int32_t T, int32_t
 #define D3D_KC_EMBED 4
 #define D3D_KC_HEAD 5
 #define D3D_KC_OTHER 6
-#define D3D_KC_COUNT 7
+/* the GEMM launches of the F16X3 block flow once more, by kind (each is ALSO counted under D3D_KC_LINEAR: do not add these to it) */
+#define D3D_KC_LINEAR_QKV 7
+#define D3D_KC_LINEAR_PROJ 8
+#define D3D_KC_LINEAR_FC1 9
+#define D3D_KC_LINEAR_FC2 10
+#define D3D_KC_COUNT 11
 int d3d_engine_set_profiling(d3d_engine* e, int32_t on);
 int d3d_engine_profile_reset(d3d_engine* e);
 int d3d_engine_profile_read(d3d_engine* e, int32_t kernel_class, double* total_ms, int64_t* launches, double* flops,

@@ -383,9 +383,66 @@ def gen_chunks():
     save("chunks", **out)
 
 
+def gen_dataset():
+    """Reference load_Dataset(..., 'test') + ChunkedGenerator on the synthetic H36M-shaped data set of diff3dhpe_amd.synth
+    (synthetic cameras: the reference's H36M camera literals are not involved): every evaluation window in `pairs` order."""
+    import tempfile
+    from types import SimpleNamespace
+    from common.mocap_dataset import MocapDataset
+    from common.skeleton import Skeleton
+    from common.camera import world_to_camera
+    from data.load_noisy_data import load_Dataset
+    from diff3dhpe_amd.synth import write_synth_mocap, SYNTH_PARENTS, SYNTH_JOINTS_LEFT, SYNTH_JOINTS_RIGHT
+    from diff3dhpe_amd.data import EvalData, MocapMeta
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        positions, cameras, keypoints, meta = write_synth_mocap(root, seed=0)
+        for T in (27, 9):
+            ds = MocapDataset(fps=50, skeleton=Skeleton(parents=list(SYNTH_PARENTS), joints_left=list(SYNTH_JOINTS_LEFT),
+                                                        joints_right=list(SYNTH_JOINTS_RIGHT)))
+            ds._cameras = cameras
+            ds._data = {s: {a: {"positions": p, "cameras": cameras[s]} for a, p in acts.items()} for s, acts in positions.items()}
+            allp = []
+            for s, acts in positions.items():          # h36m_dataset.py:260-275
+                for a, p in acts.items():
+                    for cam in cameras[s]:
+                        allp.append(world_to_camera(p, R=cam["orientation"], t=cam["translation"]))
+            allp = np.concatenate(allp, axis=0)
+            cen = allp - allp[:, :1]
+            ds._pos_3d_min, ds._pos_3d_max = cen.min(), cen.max()
+            ds._w_mpjpe = torch.ones(17)
+            opt = SimpleNamespace(dataset="h36m", keypoints="synth", subjects_train="S9", subjects_test="S9,S11", actions="*",
+                                  downsample=1, subset=1, stride=T, test_time_augmentation=True, number_of_frames=T, out_all=True,
+                                  batch_size=4, data_augmentation=False)
+            ref = load_Dataset(opt, ds, root, "test")
+            items = [ref[i] for i in range(len(ref))]
+            g3 = np.stack([it[1] for it in items]); g3n = np.stack([it[2] for it in items]); x2 = np.stack([it[3] for it in items])
+            x2f = np.stack([it[4] for it in items]); tm = np.stack([it[5] for it in items])
+            # the product's adaptor on the same files must hand out the same windows
+            ed = EvalData(MocapMeta(positions, cameras, SYNTH_JOINTS_LEFT, SYNTH_JOINTS_RIGHT), keypoints, meta["keypoints_symmetry"],
+                          ["S9", "S11"], T)
+            mine = list(ed.items())
+            assert len(mine) == len(items), (len(mine), len(items))
+            for nm, refa, key in (("3d", g3, "inputs_3d"), ("3dn", g3n, "inputs_3d_norm"), ("2d", x2, "inputs_2d"), ("2df", x2f, "inputs_2d_flip"),
+                                  ("mask", tm, "target_mask")):
+                m = np.stack([it[key] for it in mine])
+                assert m.dtype == refa.dtype and np.array_equal(m, refa), (T, nm, m.dtype, refa.dtype, np.abs(m.astype(np.float64) - refa).max())
+            assert np.float32(ed.scale) == np.float32(ref.scale), (ed.scale, ref.scale)
+            if T == 27:      # whole arrays for one window length, position-weighted checksums for the other
+                out[f"T{T}/inputs_3d"] = g3; out[f"T{T}/inputs_3d_norm"] = g3n; out[f"T{T}/inputs_2d"] = x2
+                out[f"T{T}/inputs_2d_flip"] = x2f
+            for nm, arr in (("inputs_3d", g3), ("inputs_3d_norm", g3n), ("inputs_2d", x2), ("inputs_2d_flip", x2f)):
+                wts = np.arange(1, arr.size + 1, dtype=np.float64).reshape(arr.shape) % 9973.0
+                out[f"T{T}/{nm}_checksum"] = np.float64((arr.astype(np.float64) * wts).sum())
+            out[f"T{T}/target_mask"] = tm; out[f"T{T}/scale"] = np.float32(ref.scale)
+            print(f"  dataset T={T}: {len(items)} windows, scale {float(ref.scale):.6f}: diff3dhpe_amd.data == reference (bit-equal)")
+    save("dataset_eval", **out)
+
+
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
+    "dataset": gen_dataset,
 }
 
 if __name__ == "__main__":

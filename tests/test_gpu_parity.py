@@ -7,6 +7,8 @@ import torch
 
 from conftest import gold
 from helpers import cfg_small, cfg_full, inputs, hashed, build_product, maxabs, torch_sd
+import diff3dhpe_amd as d3d
+from diff3dhpe_amd.spec import DenoiserConfig
 
 pytestmark = pytest.mark.gpu
 GATE = 1e-4
@@ -388,6 +390,118 @@ def test_c_abi_error_behaviour_on_device():
     eng.set_schedule(tabs.alphas_cumprod, tabs.sqrt_one_minus_alphas_cumprod, 3, 0.0, True)
     res = eng.ddim_sample(x2d, y)
     assert torch.isfinite(res).all()
+
+
+def test_dataset_adaptor_feeds_evaluate():
+    """Section 8f row 4 end to end: windows from diff3dhpe_amd.data (bit-equal to the reference loader, tests/test_data_adaptor.py)
+    through evaluate() -- two samplings per window, merge, de-normalise by the data set's scale, masked MPJPE (RUN:562-606) --
+    against the oracle doing the same on the same windows."""
+    from diff3dhpe_amd.data import EvalData, MocapMeta
+    from diff3dhpe_amd.evaluate import evaluate
+    from diff3dhpe_amd.synth import synth_mocap, SYNTH_JOINTS_LEFT as JL, SYNTH_JOINTS_RIGHT as JR
+    from oracle import d3d_oracle as orc
+    pos, cams, kp, meta = synth_mocap(0)
+    ed = EvalData(MocapMeta(pos, cams, JL, JR), kp, meta["keypoints_symmetry"], ["S9"], 27)      # 8 windows
+    cfg = cfg_small(27)
+    _, diff = build_product(cfg, 31, sampling=3)
+    batches = []
+    for i, b in enumerate(ed.batches(5)):
+        n = b["inputs_2d"].shape[0]
+        b["init_noise"] = hashed(f"dsn{i}", (n, 27, 17, 3), 4)
+        b["init_noise_flip"] = hashed(f"dsf{i}", (n, 27, 17, 3), 5)
+        batches.append(b)
+    res = evaluate(diff, batches, scale=ed.scale, joints_left=ed.joints_left, joints_right=ed.joints_right, verbose=False)
+    sd, tabs = torch_sd(cfg, 31), orc.diffusion_tables("cosine", 1000)
+    kw = dict(num_timesteps=1000, sampling_timesteps=3, depth=cfg.depth)
+    err, cnt = 0.0, 0
+    for b in batches:
+        p = orc.ddim_sample_loop(sd, tabs, b["inputs_2d"], b["init_noise"], **kw)
+        pf = orc.ddim_sample_loop(sd, tabs, b["inputs_2d_flip"], b["init_noise_flip"], **kw)
+        merged = orc.merge_flip_tta(p, pf, ed.scale, b["target_mask"])
+        gtm = b["inputs_3d"].view(-1, 17, 3)[b["target_mask"].view(-1)].unsqueeze(1)
+        err += orc.mpjpe(merged, gtm).item() * gtm.shape[0]
+        cnt += gtm.shape[0]
+    assert res["frames"] == cnt == int(sum(int(b["target_mask"].sum()) for b in batches))
+    assert abs(res["mpjpe_mm"] - err / cnt * 1000) < 0.05
+
+
+def test_rng_is_consumed_as_the_reference_consumes_it():
+    """Without supplied noise a sampling draws randn(target_shape) once and then S - 1 more tensors of that shape from the global
+    generator, eta or not (DIFF:275, 293): the next sampling of an unchanged runner starts from the same generator state."""
+    cfg = cfg_small(27)
+    _, diff = build_product(cfg, 12, sampling=4)
+    x2d = inputs(2, 27, 7)["x2d"].cuda()
+    shape = (2, 27, 17, 3)
+    torch.manual_seed(1234)
+    first = torch.randn(shape, device="cuda")
+    for _ in range(3):
+        torch.randn(shape, device="cuda")
+    expect_next = torch.randn(shape, device="cuda")
+    torch.manual_seed(1234)
+    _, y_auto = diff(clean_3d_pose=torch.zeros(shape, device="cuda"), noisy_2d_pose=x2d, output_loss=False)
+    got_next = torch.randn(shape, device="cuda")
+    assert torch.equal(got_next, expect_next)
+    _, y_given = diff(clean_3d_pose=torch.zeros(shape, device="cuda"), noisy_2d_pose=x2d, output_loss=False, init_noise=first)
+    assert torch.equal(y_auto, y_given)
+
+
+def test_f16x3_range_guard():
+    """Operands beyond the fp16 range of the F16X3 planes (|x| > 8188, |w| > 15.99) must raise the sticky flags -- and only they."""
+    from diff3dhpe_amd import _lib
+    cfg = DenoiserConfig(num_frame=27, embed_dim=512, depth=1)
+    inp = inputs(2, 27, 3)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def run(mutate):
+        sd = torch_sd(cfg, 8)
+        mutate(sd)
+        net = d3d.HPE_model(d3d.S2S_NAME)(num_frame=27, embed_dim=512, depth=1)
+        net.load_state_dict(sd)
+        net.precision = "f16x3"
+        diff = d3d.GaussianDiffusion(model=net, timesteps=1000, sampling_timesteps=2, clip_denoised=True).eval().to(dev)
+        eng = diff._engine(dev)
+        eng.range_flags(clear=True)
+        diff(clean_3d_pose=torch.zeros_like(nz), noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+        return eng
+    eng = run(lambda sd: None)
+    assert eng.range_flags() == 0
+    eng.check_range()                                                            # healthy model: no exception
+
+    def big_w(sd):
+        sd["STEblocks.0.mlp.fc1.weight"][3, 5] = 20.0                            # |4096 w| > 65504
+    eng = run(big_w)
+    assert eng.range_flags(clear=False) & _lib.RANGE_WEIGHT
+    with pytest.raises(_lib.D3DError, match="range"):
+        eng.check_range()
+
+    def big_x(sd):
+        sd["fusion_layer.bias"] += 1.0e4                                         # residual stream ~1e4: |8 x| > 65504
+    eng = run(big_x)
+    f = eng.range_flags()
+    assert f & _lib.RANGE_ACT and not (f & _lib.RANGE_WEIGHT)
+    assert eng.range_flags() == 0                                                # cleared by the read
+
+
+def test_hipgraph_replay_long_chain_T243():
+    """BASELINE configs[3] at its own size: T=243, 50 DDIM steps, B=4 -- one captured graph of 50 x 82 launches replayed twice,
+    bit-identical to the eager launch sequence."""
+    cfg = cfg_full(243)
+    _, diff = build_product(cfg, 5, sampling=50, precision="f16x3")
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(4, 243, 77)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    z = torch.zeros(4, 243, 17, 3, device="cuda")
+    eng.set_graph_mode(False)
+    _, eager = diff(clean_3d_pose=z, noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+    eng.set_graph_mode(True)
+    try:
+        for rep in range(2):
+            _, g = diff(clean_3d_pose=z, noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+            assert torch.equal(g, eager), rep
+    finally:
+        eng.set_graph_mode(False)
+    assert torch.isfinite(eager).all() and float(eager.abs().max()) <= 1.0
 
 
 def test_bench_two_ranks_on_one_device():
