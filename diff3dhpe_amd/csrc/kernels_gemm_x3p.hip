@@ -867,9 +867,135 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     }                                                                                                                    \
   } while (0)
 
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true);
-  D3D_QKTILE(kt, false);
+#ifndef D3D_X3_PIPE2
+#define D3D_X3_PIPE2 1
+#endif
+  // Measured (same box, experiments/ab_libs.sh, two alternations): qkv 1.122 -> 1.095 ms per launch, fc1 0.829 -> 0.830, proj 0.491 ->
+  // 0.502 (its epilogue's residual loads then queue behind more staging in flight), whole-row fc2 0.841 -> 0.885: on for the two
+  // forms without a residual read (D3D_X3_PIPE2=2 forces it everywhere, =0 nowhere -- experiments/build_variant.sh).
+  if constexpr (PERSIST && TM % 2 == 0 && (D3D_X3_PIPE2 > 1 || (D3D_X3_PIPE2 == 1 && WM == 2 && EPI != EPI_RESIDUAL))) {
+    // ---- Two phases per k-tile, staging two phases ahead (persistent walk).  A k-tile is split where its buffers die: the W
+    // fragments go to registers at the top of the first phase, the A rows of m-tiles 0..TM/2-1 are read in the first phase, those
+    // of TM/2..TM-1 in the second.  So the pieces of a LATER k-tile can be issued into a stage while its other half is still read:
+    //   phase 2t   (m-tiles 0..TM/2-1 of k-tile t) issues A(t+1)  [its stage last held A(t-1), read through phase 2t-1]
+    //   phase 2t+1 (m-tiles TM/2..TM-1)           issues W(t+2)  [its stage half held W(t), in registers since phase 2t]
+    // and every piece has at least one whole phase to land: the wait before the barrier of a phase is a COUNTED vmcnt that leaves
+    // the pieces of the phase just finished in flight (the one-barrier form waited vmcnt(0) for pieces issued a sixth of a k-tile
+    // earlier).  The stream runs on across tiles: W(0) / A(0) of the next tile are issued by phases 2nk-3 / 2nk-2 of this one, its
+    // W(1) -- whose stage holds the epilogue's patches -- with A(1) in its own phase 0.  Same MFMAs in the same order per element
+    // as the one-barrier form (values unchanged).
+    auto wait_vm = [](int n) {   // s_waitcnt vmcnt(n), n wave-uniform (counts differ per wave only in tail slices)
+      switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      }
+    };
+    const int nA = SUB ? __builtin_popcount(amask & ((1u << A_IT) - 1u)) : A_IT;   // A pieces this wave issues per k-tile
+    int issued_prev = 0;                                                            // pieces this wave issued in the previous phase
+    // piece `it` (A: 0..A_IT-1, W: A_IT..N_IT-1) of k-tile KTT of this tile (KTT < nk) or of k-tile 0 of the next one (KTT == nk)
+#define D3D_PIECE(KTT, IT)                                                                                               \
+    do {                                                                                                                 \
+      const bool nxt_ = (KTT) >= nk;                                                                                     \
+      const int st_ = ((KTT) & 1) * STAGE;                                                                               \
+      if ((IT) < A_IT) {                                                                                                 \
+        if ((amask >> (IT)) & 1u) {                                                                                      \
+          const char* b_ = nxt_ ? ubAn + (IT) * it_stride : ubA + ((size_t)(KTT) * 128 + (IT) * it_stride);              \
+          D3D_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstA + (IT) * NW * 1024);                                                 \
+        }                                                                                                                \
+      } else {                                                                                                           \
+        const char* b_ = nxt_ ? ubBn + ((IT) - A_IT) * it_stride : ubB + ((size_t)(KTT) * 128 + ((IT) - A_IT) * it_stride); \
+        D3D_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstB + ((IT) - A_IT) * NW * 1024);                                          \
+      }                                                                                                                  \
+    } while (0)
+    // one phase: H = 0 / 1.  Even phase (H = 0) of k-tile KT: A(KT+1) and the W pieces W_ODD..B_IT-1 of W(KT+1) if DO_A (all of
+    // W(1) in a tile's first phase, W_FULL1); odd phase: the W pieces 0..W_ODD-1 of W(KT+2) if DO_W.  W_ODD = B_IT where A and W
+    // are the same size (256 x 256 tiles: 4 + 4 pieces per wave and k-tile), B_IT / 2 for the whole-row tiles (2 + 8).
+    constexpr int W_ODD = (WM == 2) ? B_IT : B_IT / 2;
+#define D3D_PHASE(KT, H, DO_A, W_FULL1, DO_W)                                                                             \
+    do {                                                                                                                  \
+      wait_vm(issued_prev);                                                                                               \
+      __builtin_amdgcn_s_barrier();                                                                                       \
+      asm volatile("" : "+v"(lofs_) : : "memory");                                                                        \
+      const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                 \
+      constexpr int G0 = (H) * (TM / 2), G1 = G0 + TM / 2;                                                                \
+      if ((H) == 0) {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+          bh[j] = *reinterpret_cast<const h8*>(sb + boff + j * 2048);                                                     \
+          bl[j] = *reinterpret_cast<const h8*>(sb + ((boff + j * 2048) ^ 64));                                            \
+        }                                                                                                                 \
+      }                                                                                                                   \
+      const int gf = gl > G0 ? gl : G0;                     /* first active m-tile of this phase */                       \
+      if (gf < gh && gf < G1) {                                                                                           \
+        ah[gf & 1] = *reinterpret_cast<const h8*>(sb + aoff + gf * 2048);                                                 \
+        al[gf & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + gf * 2048) ^ 64));                                        \
+      }                                                                                                                   \
+      _Pragma("unroll") for (int g = G0; g < G1; ++g) {                                                                   \
+        const bool g_act = g >= gl && g < gh;                                                                             \
+        if (g_act && g + 1 < gh && g + 1 < G1) {                                                                          \
+          ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                     \
+          al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                            \
+        }                                                                                                                 \
+        constexpr int NP_ = ((H) == 0) ? A_IT + B_IT : W_ODD;      /* piece slots of this phase kind, spread over TM/2 groups */ \
+        constexpr int PPG_ = (NP_ + TM / 2 - 1) / (TM / 2);                                                               \
+        _Pragma("unroll") for (int pp = 0; pp < PPG_; ++pp) {                                                             \
+          const int sl = (g - G0) * PPG_ + pp;                                                                            \
+          if ((H) == 0) {                                                                                                 \
+            if (sl < A_IT) { if (DO_A) D3D_PIECE((KT) + 1, sl); }                                                         \
+            else if (sl < A_IT + B_IT) {                                                                                  \
+              if ((W_FULL1) || ((DO_A) && sl - A_IT >= W_ODD)) D3D_PIECE((KT) + 1, sl);                                   \
+            }                                                                                                             \
+          } else if (sl < W_ODD) {                                                                                        \
+            if (DO_W) D3D_PIECE((KT) + 2, A_IT + sl);                                                                     \
+          }                                                                                                               \
+        }                                                                                                                 \
+        if (g_act) {                                                                                                      \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
+            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                     \
+            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
+            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
+          }                                                                                                               \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+      }                                                                                                                   \
+      if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : ((DO_A) ? B_IT - W_ODD : 0));                   \
+      else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
+    } while (0)
+    h8 bh[4], bl[4], ah[2], al[2];
+    // first k-tile: everything issued before this tile (stores of the previous epilogue included) has landed: vmcnt(0)
+    issued_prev = 0;
+    D3D_PHASE(0, 0, true, true, false);
+    D3D_PHASE(0, 1, false, false, nk > 2 || has_next);
+    int kt = 1;
+    for (; kt + 2 < nk; ++kt) {
+      D3D_PHASE(kt, 0, true, false, false);
+      D3D_PHASE(kt, 1, false, false, true);
+    }
+    if (nk > 2) {   // k-tile nk-2: A(nk-1) of this tile, then W(0) of the next tile
+      D3D_PHASE(kt, 0, true, false, false);
+      D3D_PHASE(kt, 1, false, false, has_next);
+      ++kt;
+    }
+    // k-tile nk-1: A(0) of the next tile; W(1) of the next tile waits for its own phase 0 (the epilogue's patches live there)
+    D3D_PHASE(kt, 0, has_next, false, false);
+    D3D_PHASE(kt, 1, false, false, false);
+#undef D3D_PHASE
+#undef D3D_PIECE
+  } else {
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true);
+    D3D_QKTILE(kt, false);
+  }
 #undef D3D_QKTILE
 #undef D3D_QSTAGE_ONE
 #undef D3D_QSTAGE_NEXT

@@ -5,7 +5,7 @@
 #   profiles/collect.sh r01_f16x3 [bench.py args...]
 set -eo pipefail
 tag=${1:-r01_f16x3}; shift || true
-args="--steps 1 --warmup 1 --no-cpu-baseline --no-selfcheck $*"
+args="--steps 1 --warmup 1 --no-cpu-baseline --no-selfcheck --no-extras $*"
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 export TMPDIR=/tmp
@@ -23,5 +23,12 @@ python3 profiles/summarize.py stats $out/stats $out/stats_table.md > /dev/null
 python3 profiles/summarize.py pmc $out/fetch $out/write profiles/${tag}_pmc.json "bench.py $args" > /dev/null
 python3 profiles/summarize.py sq $out/sq profiles/${tag}_sq_counters.json > /dev/null
 grep '^{' $out/stats.log | tail -1 > profiles/${tag}_bench_under_rocprof.json || true
-cp profiles/${tag}_* gpurun_out/ 2>/dev/null || true
+# per-class HBM bytes for bench.py's roofline.traffic (tagged there as coming from these passes, not from the bench run itself)
+prec=f16x3; case "$*" in *fp32*) prec=fp32;; esac
+python3 profiles/summarize.py traffic profiles/${tag}_pmc.json profiles/hbm_traffic.json 243 64 $prec > /dev/null || true
+python3 - <<PY
+import json, time
+p = "profiles/hbm_traffic.json"; d = json.load(open(p)); d["_collected"] = "${tag}, " + time.strftime("%Y-%m-%d"); json.dump(d, open(p, "w"), indent=1)
+PY
+cp profiles/${tag}_* profiles/hbm_traffic.json gpurun_out/ 2>/dev/null || true
 cat profiles/${tag}_kernel_stats.md
