@@ -972,6 +972,80 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
     } while (0)
     h8 bh[4], bl[4], ah[2], al[2];
+#ifndef D3D_X3_STAGGER
+#define D3D_X3_STAGGER 0
+#endif
+    if constexpr (D3D_X3_STAGGER != 0 && !SUB && WM == 2 && TM == 8) {
+      // ---- Staggered form (experiment, MI355X_MICROARCH "Two waves per SIMD" item 9): the waves of wave-row 1 (waves 4..7, the
+      // SIMD partners of 0..3) run ONE PHASE behind those of wave-row 0, so that partners are never in the same kind of phase
+      // start (fragment burst, staging issue) together.  Wave-row 1 takes its m-tiles in the order 4..7, 0..3: then in an even
+      // global phase every wave runs the m-tile group 0..3 (row 0 on k-tile t, row 1 on k-tile t-1) and in an odd phase the
+      // group 4..7 of k-tile t -- one instruction stream, the stage differs.  A tile takes 2 nk + 1 phases (row 1 idles in the
+      // first, row 0 in the last).  Staging by global phase: even 2t: W(t+1) and the A rows of row 0's first half of k-tile t+1;
+      // odd 2t+1: the other three A row bands of k-tile t+1.
+      const int lag = wm;                                            // wave-uniform: 0 / 1
+      const int nA0 = 1, nA1 = A_IT - 1;
+      static_assert(A_IT == 4, "row bands of 64 rows");
+#define D3D_SGROUPS(G0_, SB_)                                                                                             \
+      do {                                                                                                                \
+        ah[(G0_) & 1] = *reinterpret_cast<const h8*>((SB_) + aoff + (G0_) * 2048);                                        \
+        al[(G0_) & 1] = *reinterpret_cast<const h8*>((SB_) + ((aoff + (G0_) * 2048) ^ 64));                               \
+        _Pragma("unroll") for (int g = (G0_); g < (G0_) + 4; ++g) {                                                       \
+          if (g + 1 < (G0_) + 4) {                                                                                        \
+            ah[(g + 1) & 1] = *reinterpret_cast<const h8*>((SB_) + aoff + (g + 1) * 2048);                                \
+            al[(g + 1) & 1] = *reinterpret_cast<const h8*>((SB_) + ((aoff + (g + 1) * 2048) ^ 64));                       \
+          }                                                                                                               \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
+            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                     \
+            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
+            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
+          }                                                                                                               \
+          __builtin_amdgcn_sched_barrier(0);                                                                              \
+        }                                                                                                                 \
+      } while (0)
+#define D3D_SWFRAGS(SB_)                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                     \
+        bh[j] = *reinterpret_cast<const h8*>((SB_) + boff + j * 2048);                                                    \
+        bl[j] = *reinterpret_cast<const h8*>((SB_) + ((boff + j * 2048) ^ 64));                                           \
+      }
+      issued_prev = 0;
+      for (int t = 0; t <= nk; ++t) {
+        {   // ---- even global phase 2t: m-tiles 0..3; wave-row 0 on k-tile t, wave-row 1 on k-tile t-1
+          wait_vm(issued_prev);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" : "+v"(lofs_) : : "memory");
+          const int my_t = t - lag;
+          const bool issue = t < nk && (t + 1 < nk || has_next);
+          if (issue) {   // W(t+1) and row band 0 of A(t+1)
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) D3D_PIECE(t + 1, A_IT + it);
+            D3D_PIECE(t + 1, 0);
+          }
+          if (my_t >= 0 && my_t < nk) {
+            const unsigned char* sb = lds + (my_t & 1) * STAGE;
+            if (lag == 0) { D3D_SWFRAGS(sb); }
+            D3D_SGROUPS(0, sb);
+          }
+          issued_prev = issue ? B_IT + nA0 : 0;
+        }
+        if (t < nk) {   // ---- odd global phase 2t+1: m-tiles 4..7 of k-tile t, every wave
+          wait_vm(issued_prev);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" : "+v"(lofs_) : : "memory");
+          const bool issue = t + 1 < nk || has_next;
+          if (issue) {
+#pragma unroll
+            for (int it = 1; it < A_IT; ++it) D3D_PIECE(t + 1, it);
+          }
+          const unsigned char* sb = lds + (t & 1) * STAGE;
+          if (lag == 1) { D3D_SWFRAGS(sb); }
+          D3D_SGROUPS(4, sb);
+          issued_prev = issue ? nA1 : 0;
+        }
+      }
+#undef D3D_SGROUPS
+#undef D3D_SWFRAGS
+    } else {
     // first k-tile: everything issued before this tile (stores of the previous epilogue included) has landed: vmcnt(0)
     issued_prev = 0;
     D3D_PHASE(0, 0, true, true, false);
@@ -989,6 +1063,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     // k-tile nk-1: A(0) of the next tile; W(1) of the next tile waits for its own phase 0 (the epilogue's patches live there)
     D3D_PHASE(kt, 0, has_next, false, false);
     D3D_PHASE(kt, 1, false, false, false);
+    }
 #undef D3D_PHASE
 #undef D3D_PIECE
   } else {

@@ -69,6 +69,11 @@ def timeit(fn, *a):
 
 t1, ref = timeit(one_stream)
 print(f"one stream   B={B}: {t1 * 1e3:8.1f} ms  {B / t1:7.2f} seq/s", flush=True)
-for split in (B // 2, B // 2 + B // 8):
+# round quantisation of the persistent GEMM walks: B=63 at T=243 is 7.95 / 15.9 / 23.8 rounds of 256 tiles, B=64 8.07 / 16.1 / 24.2
+for b in (B - 1, B - 2, B - 9):
+    tb, _ = timeit(lambda: engs[0].ddim_sample(x2d[:b].contiguous(), noise[:b].contiguous()))
+    print(f"one stream   B={b}: {tb * 1e3:8.1f} ms  {b / tb:7.2f} seq/s", flush=True)
+splits = [int(v) for v in os.environ.get("SPLITS", f"{B // 2},{B - 1},{B - 2},{B - 9}").split(",")]
+for split in splits:
     t2, out = timeit(two_streams, split)
     print(f"two streams {split}+{B - split}: {t2 * 1e3:8.1f} ms  {B / t2:7.2f} seq/s  bit-identical={bool((out == ref).all())}", flush=True)
