@@ -260,7 +260,9 @@ def main():
         tot_ms = sum(v["ms"] for v in prof.values()) or 1.0
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
-        if dom == "linear" or dom == "attn_temporal":
+        if not d["ms"]:                         # --graph: no per-kernel events; the whole-path figures are filled in below
+            roof = {"bound": "mfma", "achieved": None, "peak": round(PEAK_TFLOPS[a.precision], 1), "unit": "TFLOP/s", "frac": None}
+        elif dom == "linear" or dom == "attn_temporal":
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             peak = PEAK_TFLOPS[a.precision]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}

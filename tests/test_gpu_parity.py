@@ -261,6 +261,35 @@ def test_engine_matches_oracle_on_other_widths(prec):
         assert maxabs(y0, ref) <= GATE, (cfg.embed_dim, cfg.num_heads, cfg.mlp_ratio)
 
 
+@pytest.mark.parametrize("off", [2.0, 8.0])
+def test_folded_layernorm_statistics_with_offset_rows(off):
+    """The LayerNorm folded into the qkv / fc1 GEMMs takes its row variance as sum(x^2)/D - mean^2 from the producer's (sum,
+    sum of squares) partials -- a one-pass form whose relative error grows like eps * (1 + mean^2/var).  Rows of the stream are
+    LayerNorm outputs (|mean| well below the standard deviation for any sane checkpoint); this test pushes the post-norm biases
+    and the position embeddings so that |mean| = 2 and 8 standard deviations and checks the gate against the oracle (two-pass
+    statistics) still holds with a wide margin.  DESIGN.md section 4.1 states the bound."""
+    from oracle import d3d_oracle as orc
+    cfg = cfg_full(9)
+    sd = torch_sd(cfg, 77)
+    for k in ("Spatial_norm.bias", "Temporal_norm.bias"):
+        sd[k] = sd[k] + off * sd[k.replace("bias", "weight")].abs().mean()
+    import diff3dhpe_amd as d3d
+    net = d3d.HPE_model(d3d.S2S_NAME)(num_frame=9, num_joints=17, in_chans=2, embed_dim=512, depth=8, num_heads=8, mlp_ratio=2.0,
+                                      qkv_bias=True, qk_scale=None, drop_path_rate=0.1)
+    net.load_state_dict(sd, strict=True)
+    net.precision = "f16x3"
+    net = net.cuda()
+    inp = inputs(3, 9, 557)
+    xcat = torch.cat([inp["x2d"], inp["noise"]], dim=-1)
+    t = torch.tensor([999, 400, 3])
+    out = net.forward_denoise(xcat.cuda(), t.cuda())
+    ref = orc.forward_denoise(sd, xcat, t, depth=8)
+    net.precision = "fp32"                         # the plain dataflow: two-pass row kernels, no folded statistics
+    e, e32 = maxabs(out, ref), maxabs(net.forward_denoise(xcat.cuda(), t.cuda()), ref)
+    print(f"row mean = {off} std: folded F16X3 flow vs oracle {e:.3e}; FP32 flow vs oracle {e32:.3e}")
+    assert e <= GATE / 4
+
+
 def test_evaluate_harness_flip_tta():
     from diff3dhpe_amd.evaluate import evaluate, flip_2d, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
     from oracle import d3d_oracle as orc
@@ -555,3 +584,24 @@ def test_bench_rccl_collectives_on_a_one_rank_group():
     ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     assert "dist" not in ref
     assert line["mpjpe_vs_synthetic_gt"] == ref["mpjpe_vs_synthetic_gt"]        # the gathered prediction is the local one
+
+
+def test_bench_graph_flag_times_the_main_leg_under_replay():
+    """`bench.py --graph` (BASELINE configs[3] protocol): the main leg runs as hipGraph replays, prints a complete line whose
+    prediction error equals the eager run's (same values), and says that per-kernel timing was off."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    common = ["--gpus", "1", "--batch", "4", "--steps", "2", "--warmup", "1", "--frames", "27", "--sampling", "5",
+              "--no-cpu-baseline", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k != "D3D_FORCE_DIST"}
+    lines = []
+    for extra in ([], ["--graph"]):
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, capture_output=True, text=True,
+                             cwd=ROOT, timeout=600, env=env)
+        assert run.returncode == 0, run.stderr[-2000:]
+        lines.append(json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1]))
+    eager, graph = lines
+    assert graph["graph_replay"] and "graph_replay" not in eager
+    assert graph["mpjpe_vs_synthetic_gt"] == eager["mpjpe_vs_synthetic_gt"]
+    assert graph["selfcheck_batch_vs_pair_bit_identical"] and graph["roofline"]["frac"] > 0
+    assert graph["roofline"]["kernel"].startswith("whole path")
