@@ -1301,6 +1301,7 @@ int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t
     (void)hipFree(tmp);
     HIP_TRY(e3);
     HIP_TRY(e4);
+    if (getenv("D3D_ATTN_DIAG")) attn_x3_diag_report();
     return D3D_OK;
   }
   if (!force_generic && !temporal && attn_spatial_fast_ok(J, D, H)) {

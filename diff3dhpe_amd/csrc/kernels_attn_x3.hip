@@ -17,6 +17,8 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <utility>
 
 namespace d3d {
 
@@ -34,6 +36,7 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((c
 __device__ __forceinline__ int vkey(int row) { return (((row >> 1) & 1) << 2) ^ ((row >> 2) & 3); }
 __device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ vkey(row)) << 4); }
 typedef short s4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = an output clamp fired
 __device__ unsigned g_range_attn;
@@ -520,6 +523,371 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   }
 }
 
+// ---- persistent form with the two wave halves of the workgroup ONE PHASE APART (temporal blocks, 8 key tiles) ---------
+// k_attn_temporal_x3p keeps all eight waves of the CU in the same phase: score MFMAs, then softmax VALU, then PV MFMAs --
+// the matrix pipe idles during the softmax and the VALU during the products.  Waves w and w + 4 share a SIMD; here waves
+// 0-3 (half 0) run one phase AHEAD of waves 4-7 (half 1), so that on every SIMD one wave's MFMA phase meets the other's VALU
+// phase two steps out of three.  A unit takes three steps, every step starts with vmcnt(0) + workgroup barrier:
+//
+//   step 3i     half 0: S(i)        [K_i]      half 1: PV(i-1)   [V_{i-1}]
+//   step 3i+1   half 0: softmax(i)             half 1: S(i)      [K_i]        all waves first issue the V_i DMA (V_{i-1} is dead)
+//   step 3i+2   half 0: PV(i)       [V_i]      half 1: softmax(i)             all waves first issue the K_{i+1} DMA (K_i is dead)
+//
+// One K and one V buffer as before (128 KiB); every DMA has one whole step to land.  The two halves run two INSTANCES of the
+// same statically scheduled loop (HALF is a template parameter: the phase of a wave is never a run-time value, so register
+// allocation is that of k_attn_temporal_x3p), half 1 behind one extra barrier; both execute 3n + 1 barriers.  Each wave
+// computes exactly what it computes in k_attn_temporal_x3p (same MFMAs, same order, same softmax): results are bit-identical,
+// only WHEN differs.
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>) -- the body sees its index as a constant expression (asm
+// immediates)
+template <int... Js, class F>
+__device__ __forceinline__ void static_for_(std::integer_sequence<int, Js...>, F&& f) { (f(std::integral_constant<int, Js>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_(std::make_integer_sequence<int, N>{}, f); }
+// LDS fragment reads as inline asm: the compiler does not know them as LDS operations, so it inserts no s_waitcnt for them --
+// the caller places counted lgkmcnt waits itself (LDS operations of one wave return in order).  Needed because the compiler's
+// own waits for a ring of fragment registers came out as lgkmcnt(0) right behind the newest read in several instantiations.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(h8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16_b64(s4v& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// (e0, e1) -> packed fp16 pairs hi = fp16(k e), lo = fp16(k e - hi), k a power of two: v_fma_mixlo/mixhi_f16 do scale,
+// subtract (reading the fp16 hi half directly) and convert in one instruction each -- 2 VALU instructions per value where the
+// generic lowering (multiply, convert, convert back, subtract, convert, pack) takes 5.  Same values: k e and k e - hi are exact
+// in fp32, so every form rounds the same quantity once.  volatile: pins the split to the step it is written in.
+__device__ __forceinline__ void split_pair_f16(float e0, float e1, float k, unsigned& hi, unsigned& lo) {
+  asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(e0), "s"(k));
+  asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(e1), "s"(k));
+  asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(e0), "s"(k), "v"(hi));
+  asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(e1), "s"(k), "v"(hi));
+}
+
+#ifndef D3D_ATTN_ABL
+#define D3D_ATTN_ABL 0   // timing experiments only (wrong results), bit mask: 1 = stage K / V of the first unit only, 2 = no score phase,
+                         // 4 = no softmax, 8 = no PV phase, 16 = PV without the E conversions, 32 = PV without the V reads, 64 = no output arithmetic
+#endif
+// wave priority per phase (s_setprio): the two waves of a SIMD are in different phases; without it the OLDER wave's VALU stream
+// (softmax) wins every issue arbitration and the younger wave's MFMAs starve
+#ifndef D3D_ATTN_PRIO_S
+#define D3D_ATTN_PRIO_S 2
+#define D3D_ATTN_PRIO_PV 1
+#define D3D_ATTN_PRIO_SOFT 0
+#endif
+#define D3D_ATTN_PRIO(p) do { if ((p) >= 0) __builtin_amdgcn_s_setprio(p); } while (0)
+template <int NKT, int HALF>
+__device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl, _Float16* __restrict__ out_x3,
+                                              int T, int J, int H, int D, int units, unsigned char* const lds, const int wave,
+                                              unsigned long long* diag) {
+  constexpr int TP = 32 * NKT;
+  constexpr int PLANE = TP * 128;
+  unsigned char* const sKh = lds;
+  unsigned char* const sKl = lds + PLANE;
+  unsigned char* const sVh = lds + 2 * PLANE;
+  unsigned char* const sVl = lds + 3 * PLANE;
+  int lane = (int)threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));
+  int r = lane & 31, h = lane >> 5;
+  const int D3 = 3 * D;
+  const int u0 = (int)blockIdx.x, ustep = (int)gridDim.x;
+  const int n = (units - u0 + ustep - 1) / ustep;              // units of this workgroup (>= 1)
+#ifdef D3D_ATTN_DIAG_BUILD   // timing experiments: shader-clock stamps at the arrival at and the release from every step barrier
+  unsigned long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool rec = diag && blockIdx.x < 8 && (wave & 3) == 0;
+#define D3D_STAMP(k) do { if (rec) stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define D3D_STAMP(k) do { } while (0)
+#endif
+#define D3D_STEP_SYNC(k)                                                                                       \
+  do {                                                                                                         \
+    D3D_STAMP(2 * (k));                                                                                        \
+    __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): last step's DMA has landed, stores are acknowledged */    \
+    __syncthreads();                                                                                           \
+    D3D_STAMP(2 * (k) + 1);                                                                                    \
+    asm volatile("" : "+v"(lane));                                                                             \
+    r = lane & 31; h = lane >> 5; tq = 32 * wave + r;                                                          \
+  } while (0)
+  auto dma = [&](int which, size_t tok0, int hd) {   // which: 1 = K, 2 = V; wave w moves pieces w, w+8, w+16, w+24 of each plane
+    const int drow = lane >> 3, dslot = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int piece = wave + NKT * it;
+      const int row = 8 * piece + drow;
+      const int chunk = (which == 1) ? (dslot ^ ((row >> 1) & 7)) : (dslot ^ vkey(row));
+      const size_t o = (tok0 + (size_t)row * J) * D3 + (size_t)which * D + hd * XDH + chunk * 8;
+      unsigned char* dh = (which == 1 ? sKh : sVh) + piece * 1024;
+      unsigned char* dl = (which == 1 ? sKl : sVl) + piece * 1024;
+      if (row < T) {
+        __builtin_amdgcn_global_load_lds(Ph + o, (__attribute__((address_space(3))) void*)(uintptr_t)dh, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(Pl + o, (__attribute__((address_space(3))) void*)(uintptr_t)dl, 16, 0, 0);
+      }
+    }
+  };
+  auto unit_of = [&](int i, int& hd, size_t& tok0) {
+    const int uu = u0 + i * ustep;
+    hd = uu % H;
+    const int bj = uu / H;
+    tok0 = (size_t)(bj / J) * T * J + (bj % J);
+  };
+  h8 qh[4], ql[4];
+  auto load_q = [&](size_t tok0, int hd) {
+    const int tq_ = 32 * wave + r;
+    const size_t o = (tok0 + (size_t)(tq_ < T ? tq_ : 0) * J) * D3 + hd * XDH + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = *reinterpret_cast<const h8*>(Ph + o + 16 * ks);
+      ql[ks] = *reinterpret_cast<const h8*>(Pl + o + 16 * ks);
+    }
+  };
+
+  int hd;
+  size_t tok0;
+  unit_of(0, hd, tok0);
+  dma(1, tok0, hd);             // K_0: every wave its pieces (both halves)
+  load_q(tok0, hd);
+  // Outputs of a unit: hi/lo halves are transposed through a wave-private 4 KiB LDS patch (32 rows x one 128-byte line, 16-byte
+  // chunks XOR-swizzled by row) so that every global store covers whole lines at 16 B per lane -- 8 lanes per row -- instead
+  // of 16-byte pieces of 32 different lines per instruction; kept in registers over the step barrier, stored one step later.
+  unsigned char* const patch = lds + 4 * PLANE + wave * 4096;
+  u32x4 po[8];                  // [dt * 4 + it]: row 32 wave + 8 it + (lane >> 3), chunk lane & 7 of line dt
+  _Float16* po_ptr = out_x3;    // that row's line 0, this lane's chunk (row 8 it: + it * po_stride)
+  const size_t po_stride = (size_t)8 * J * 2 * D;
+  bool po_valid = false;
+  int tq = 32 * wave + r;
+  if (HALF == 1) D3D_STEP_SYNC(3);      // global step 0: half 0 alone (no DMA duty in that step)
+
+  for (int i = 0; i < n; ++i) {
+    const bool has_next = i + 1 < n;    // workgroup-uniform
+    int hd_n = 0;
+    size_t tok0_n = 0;
+    if (has_next) unit_of(i + 1, hd_n, tok0_n);
+    // ================= this wave's S step (global step 3i + HALF)
+    D3D_STEP_SYNC(0);
+    if (HALF == 1 && (!(D3D_ATTN_ABL & 1) || i == 0)) dma(2, tok0, hd);    // global step 3i+1: V_i
+    if (po_valid) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (32 * wave + 8 * it + (lane >> 3) < T) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(po_ptr + it * po_stride + dt * 64) = po[dt * 4 + it];
+        }
+    }
+    D3D_ATTN_PRIO(D3D_ATTN_PRIO_S);
+    // ---- S^T tiles (rows = keys, column = query tq); acc = 64 * s.  A step = one 16-deep d-slice of one key tile: two
+    // ds_read_b128, three MFMAs; the fragments of step j + 2 are requested before the MFMAs of step j issue, which wait for
+    // their own fragments only (lgkmcnt(4): the four younger reads stay in flight).
+    f32x16 sacc[NKT];
+    {
+      h8 kfh[3], kfl[3];
+      unsigned kaddr[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kaddr[ks] = (unsigned)(uintptr_t)(sKh + kswz(r, 2 * ks + h));   // + 4096 kt; lo plane + PLANE
+      static_assert(PLANE + (NKT - 1) * 4096 < 65536, "ds offset field");
+      lds_read_b128<0>(kfh[0], kaddr[0]); lds_read_b128<PLANE>(kfl[0], kaddr[0]);
+      lds_read_b128<0>(kfh[1], kaddr[1]); lds_read_b128<PLANE>(kfl[1], kaddr[1]);
+      static_for<4 * NKT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, kt = j >> 2, ks = j & 3, jn = j + 2;
+        if constexpr (jn < 4 * NKT) {
+          lds_read_b128<(jn >> 2) * 4096>(kfh[jn % 3], kaddr[jn & 3]);
+          lds_read_b128<(jn >> 2) * 4096 + PLANE>(kfl[jn % 3], kaddr[jn & 3]);
+        }
+        lgkm_wait<(jn < 4 * NKT) ? 4 : (j + 1 < 4 * NKT ? 2 : 0)>();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks == 0) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sacc[kt][q] = 0.f;
+        }
+        if (!(D3D_ATTN_ABL & 2)) {
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[j % 3], qh[ks], sacc[kt], 0, 0, 0);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[j % 3], ql[ks], sacc[kt], 0, 0, 0);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[j % 3], qh[ks], sacc[kt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    // ================= softmax step (global step 3i + 1 + HALF)
+    D3D_STEP_SYNC(1);
+    if (HALF == 0 && (!(D3D_ATTN_ABL & 1) || i == 0)) dma(2, tok0, hd);                         // global step 3i+1: V_i
+    if (HALF == 1 && has_next && !(D3D_ATTN_ABL & 1)) dma(1, tok0_n, hd_n);         // global step 3i+2: K_{i+1}
+    D3D_ATTN_PRIO(D3D_ATTN_PRIO_SOFT);
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = ((D3D_ATTN_ABL & 4) ? NKT - 1 : 0); kt < NKT; ++kt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (kt == NKT - 1) {
+          const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (key >= T) sacc[kt][q] = -INFINITY;
+        }
+        m = fmaxf(m, sacc[kt][q]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    constexpr float C_EXP = 1.4426950408889634f / 64.0f;
+    const float mb = m * C_EXP;
+    float l = 0.f;
+    // numerators e = 2^(...) and, in the same step, their split into fp16 hi / lo of 1024 e (the B operand of the PV product:
+    // the accumulator tile IS that operand after the pairwise conversion) -- the PV step then holds MFMAs, V reads and the
+    // output arithmetic only.  lo = fp16(1024 e - hi) as ONE fused multiply-add (1024 e is exact, so the value is that of the
+    // two-instruction form); the compiler selects v_fma_mix*_f16 for it.
+    u32x4 ehv[NKT][2], elv[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < ((D3D_ATTN_ABL & 4) ? 1 : NKT); ++kt)
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][q], C_EXP, -mb));
+        const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][q + 1], C_EXP, -mb));
+        l += e0;
+        l += e1;
+        unsigned hp, lp;
+        split_pair_f16(e0, e1, 1024.0f, hp, lp);
+        ehv[kt][q >> 3][(q & 7) >> 1] = hp;
+        elv[kt][q >> 3][(q & 7) >> 1] = lp;
+      }
+    l += __shfl_xor(l, 32, 64);
+    // ================= PV step (global step 3i + 2 + HALF)
+    D3D_STEP_SYNC(2);
+    if (HALF == 0 && has_next && !(D3D_ATTN_ABL & 1)) dma(1, tok0_n, hd_n);         // global step 3i+2: K_{i+1}
+    D3D_ATTN_PRIO(D3D_ATTN_PRIO_PV);
+    D3D_STAMP(6);
+    // ---- O^T[d][query] = sum_key V^T[d][key] E^T[key][query]
+    f32x16 oacc[2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { oacc[0][q] = 0.f; oacc[1][q] = 0.f; }
+    {
+      // a step = 16 keys (kt, s2): eight transposing reads (V^T fragments of both d-halves, hi and lo) and six MFMAs; the reads
+      // of step j + 1 are requested before the MFMAs of step j, which wait lgkmcnt(8)
+      const int gi = lane & 15, tq_ = gi >> 2, tp_ = gi & 3;
+      unsigned vaddr[4];     // [dt][row half]: + 2048 per step; lo plane + PLANE
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int d0 = dt * 32 + 16 * ((lane >> 4) & 1);
+        const int ch = (d0 >> 3) + (tp_ >> 1), sub = (tp_ & 1) * 8;
+        vaddr[2 * dt] = (unsigned)(uintptr_t)(sVh + vswz(4 * h + tq_, ch) + sub);
+        vaddr[2 * dt + 1] = (unsigned)(uintptr_t)(sVh + vswz(4 * h + 8 + tq_, ch) + sub);
+      }
+      s4v vf[2][8];          // [buffer][dt * 4 + {hi rows 0-3, hi rows 8-11, lo rows 0-3, lo rows 8-11}]
+      auto vread = [&](auto jc, s4v(&f)[8]) {
+        constexpr int off = decltype(jc)::value * 2048;
+        static_assert(off + PLANE < 65536, "ds offset field");
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          lds_read_tr16_b64<off>(f[4 * dt], vaddr[2 * dt]);
+          lds_read_tr16_b64<off>(f[4 * dt + 1], vaddr[2 * dt + 1]);
+          lds_read_tr16_b64<off + PLANE>(f[4 * dt + 2], vaddr[2 * dt]);
+          lds_read_tr16_b64<off + PLANE>(f[4 * dt + 3], vaddr[2 * dt + 1]);
+        }
+      };
+      if (!(D3D_ATTN_ABL & 8)) vread(std::integral_constant<int, 0>{}, vf[0]);
+      static_for<2 * NKT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, kt = j >> 1, s2 = j & 1;
+        if (!(D3D_ATTN_ABL & 8)) {
+          if constexpr (j + 1 < 2 * NKT) vread(std::integral_constant<int, j + 1>{}, vf[(j + 1) & 1]);
+          const h8 eh = __builtin_bit_cast(h8, ehv[kt][s2]), el = __builtin_bit_cast(h8, elv[kt][s2]);
+          lgkm_wait<(j + 1 < 2 * NKT) ? 8 : 0>();
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            h8 vh, vl;
+            const h4 a0h = __builtin_bit_cast(h4, vf[j & 1][4 * dt]), a1h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 1]);
+            const h4 c0h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 2]), c1h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vh[e] = a0h[e]; vh[4 + e] = a1h[e]; vl[e] = c0h[e]; vl[4 + e] = c1h[e]; }
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, eh, oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, el, oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, eh, oacc[dt], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (j == 9) { if (has_next) load_q(tok0_n, hd_n); }   // into the dead Q registers once two score tiles have been consumed
+      });
+    }
+    D3D_STAMP(7);
+    // ---- O = O^T / (2^13 l) - v_query (v_query from the V planes in LDS), packed as hi/lo of 8*o; stored in the next S step
+    {
+      const float inv = 1.0f / (8192.0f * l);
+      const int tqc = tq < T ? tq : 0;
+      float amax = 0.0f;   // range guard (rows tq >= T are never stored)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int vo = vswz(tqc, dt * 4 + g4) + 8 * h;
+          const h4 vqh = *reinterpret_cast<const h4*>(sVh + vo);
+          const h4 vql = *reinterpret_cast<const h4*>(sVl + vo);
+          h4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
+            const float o = oacc[dt][4 * g4 + e] * inv - vq;
+            amax = fmaxf(amax, fabsf(o));
+            const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
+            oh[e] = (_Float16)sc;
+            ol[e] = (_Float16)(sc - (float)oh[e]);
+            if (D3D_ATTN_ABL & 64) { oh[e] = (_Float16)oacc[dt][4 * g4 + e]; ol[e] = oh[e]; }
+          }
+          // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout), 8 h bytes in
+          const int sw = (r >> 1) & 7;
+          *reinterpret_cast<h4*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
+          *reinterpret_cast<h4*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = 8 * it + (lane >> 3);
+          po[dt * 4 + it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+        }
+      }
+      if (tq < T && amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
+      po_ptr = out_x3 + (tok0 + (size_t)(32 * wave + (lane >> 3)) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
+      po_valid = true;
+    }
+    D3D_STAMP(8);
+    hd = hd_n; tok0 = tok0_n;
+#ifdef D3D_ATTN_DIAG_BUILD
+    if (rec && i < 8 && (threadIdx.x & 63) == 0) {
+      stamp[10] = __builtin_amdgcn_s_memrealtime();
+      stamp[11] = __builtin_amdgcn_s_memtime();
+      unsigned long long* d = diag + (((size_t)blockIdx.x * 2 + HALF) * 8 + i) * 12;
+      for (int k = 0; k < 12; ++k) d[k] = stamp[k];
+    }
+#endif
+  }
+  if (HALF == 0) D3D_STEP_SYNC(3);      // global step 3n: half 1's last PV step
+#undef D3D_STEP_SYNC
+#undef D3D_STAMP
+  {   // outputs of the last unit
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (32 * wave + 8 * it + (lane >> 3) < T) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(po_ptr + it * po_stride + dt * 64) = po[dt * 4 + it];
+      }
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3s(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
+                                                                _Float16* __restrict__ out_x3, int T, int J, int H, int D, int units,
+                                                                unsigned long long* diag) {
+  static_assert(NKT == 8, "two halves of four waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_s[];
+  constexpr int TP = 32 * NKT;
+  constexpr int PLANE = TP * 128;
+  if ((int)blockIdx.x >= units) return;                        // workgroup-uniform
+  for (int idx = (int)threadIdx.x; idx < (TP - T) * 8 * 4; idx += 64 * NKT) {   // pad rows [T, TP) of the four planes: zero once
+    const int pl = idx / ((TP - T) * 8), rem = idx % ((TP - T) * 8);
+    *reinterpret_cast<uint4*>(lds_s + pl * PLANE + (T + (rem >> 3)) * 128 + ((rem & 7) << 4)) = make_uint4(0, 0, 0, 0);
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // 32-query tile of the unit
+  if (wave < 4) attn_x3s_half<NKT, 0>(Ph, Pl, out_x3, T, J, H, D, units, lds_s, wave, diag);
+  else attn_x3s_half<NKT, 1>(Ph, Pl, out_x3, T, J, H, D, units, lds_s, wave, diag);
+}
+
 hipError_t range_flags_attn(unsigned* flags, bool clear) {
   hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_attn), sizeof(unsigned));
   const unsigned zero = 0;
@@ -563,6 +931,55 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
   return hipGetLastError();
 }
 
+#ifdef D3D_ATTN_DIAG_BUILD
+static unsigned long long* g_attn_diag = nullptr;
+constexpr size_t ATTN_DIAG_WORDS = 8 * 2 * 8 * 12;   // [workgroup < 8][half][unit < 8][6 stamps, 100 MHz stamp, clock stamp]
+#endif
+void attn_x3_diag_report() {
+#ifdef D3D_ATTN_DIAG_BUILD
+  if (!g_attn_diag) return;
+  static unsigned long long h[ATTN_DIAG_WORDS];
+  if (hipMemcpy(h, g_attn_diag, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+  for (int wg = 0; wg < 8; wg += 3)
+    for (int half = 0; half < 2; ++half) {
+      double ghz = 0;
+      {
+        const unsigned long long* a = &h[((wg * 2 + half) * 8 + 2) * 12];
+        const unsigned long long* b = &h[((wg * 2 + half) * 8 + 7) * 12];
+        if (b[10] > a[10]) ghz = (double)(b[11] - a[11]) / (double)(b[10] - a[10]) * 0.1;
+      }
+      fprintf(stderr, "[attn diag] wg %d half %d clock %.3f GHz; per unit, cycles: S wait|work  softmax wait|work  PV wait|work\n", wg, half, ghz);
+      for (int i = 2; i < 7; ++i) {
+        const unsigned long long* d = &h[((wg * 2 + half) * 8 + i) * 12];
+        const unsigned long long* n = &h[((wg * 2 + half) * 8 + i + 1) * 12];
+        fprintf(stderr, "   unit %d: %6llu|%6llu  %6llu|%6llu  %6llu|%6llu   (unit %llu cycles)  PV: issue %llu  products %llu  outputs %llu  rest %llu\n",
+                i, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], n[0] - d[5], n[0] - d[0], d[6] - d[5], d[7] - d[6],
+                d[8] - d[7], n[0] - d[8]);
+      }
+    }
+#endif
+}
+
+static hipError_t launch_x3s(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H, hipStream_t s) {
+  constexpr int NKT = 8;
+  const size_t lds_bytes = (size_t)4 * 32 * NKT * 128 + NKT * 4096;   // K / V planes + one 4 KiB output patch per wave = 160 KiB
+  static std::atomic<unsigned long long> attr_set{0};   // one bit per device
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3s<NKT>), lds_bytes, attr_set)) return e;
+  const int n_cu = device_cu_count();
+  if (n_cu <= 0) return hipErrorUnknown;
+  const long long units = (long long)B * J * H;
+  if (units > 0x7fffffffLL / 4) return hipErrorInvalidValue;
+  const long long grid = units < n_cu ? units : n_cu;
+  unsigned long long* diag = nullptr;
+#ifdef D3D_ATTN_DIAG_BUILD
+  if (!g_attn_diag) { if (hipMalloc(&g_attn_diag, ATTN_DIAG_WORDS * 8) != hipSuccess) return hipErrorOutOfMemory; }
+  (void)hipMemsetAsync(g_attn_diag, 0, ATTN_DIAG_WORDS * 8, s);
+  diag = g_attn_diag;
+#endif
+  hipLaunchKernelGGL((k_attn_temporal_x3s<NKT>), dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, ox, T, J, H, D, (int)units, diag);
+  return hipGetLastError();
+}
+
 hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void* out_x3, int B, int T, int J,
                                    int D, int H, hipStream_t s) {
   if (!attn_temporal_x3_ok(T, D, H) || !qkv_hi || !qkv_lo || !out_x3) return hipErrorInvalidValue;
@@ -589,7 +1006,11 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
     case 5: return launch_x3_nkt<5>(ph, pl, ox, B, T, J, D, H, s);
     case 6: return launch_x3_nkt<6>(ph, pl, ox, B, T, J, D, H, s);
     case 7: return launch_x3_nkt<7>(ph, pl, ox, B, T, J, D, H, s);
-    default: return (persist ? launch_x3p_nkt<8> : launch_x3_nkt<8, 1>)(ph, pl, ox, B, T, J, D, H, s);
+    default: {
+      static const bool lockstep = getenv("D3D_ATTN_LOCKSTEP") != nullptr;   // experiments only: all eight waves in one phase
+      if (persist && !lockstep) return launch_x3s(ph, pl, ox, B, T, J, D, H, s);
+      return (persist ? launch_x3p_nkt<8> : launch_x3_nkt<8, 1>)(ph, pl, ox, B, T, J, D, H, s);
+    }
   }
 }
 
