@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
-          const float o = oacc[dt][4 * g4 + e] * inv - vq;
+          const float o = __builtin_fmaf(oacc[dt][4 * g4 + e], inv, -vq);   // stated: every form of this kernel must round the same way
           amax = fmaxf(amax, fabsf(o));
           const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
           oh[e] = (_Float16)sc;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
-            const float o = oacc[dt][4 * g4 + e] * inv - vq;
+            const float o = __builtin_fmaf(oacc[dt][4 * g4 + e], inv, -vq);   // stated: every form of this kernel must round the same way
             amax = fmaxf(amax, fabsf(o));
             const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
             oh[e] = (_Float16)sc;
@@ -523,23 +523,24 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   }
 }
 
-// ---- persistent form with the two wave halves of the workgroup ONE PHASE APART (temporal blocks, 8 key tiles) ---------
-// k_attn_temporal_x3p keeps all eight waves of the CU in the same phase: score MFMAs, then softmax VALU, then PV MFMAs --
-// the matrix pipe idles during the softmax and the VALU during the products.  Waves w and w + 4 share a SIMD; here waves
-// 0-3 (half 0) run one phase AHEAD of waves 4-7 (half 1), so that on every SIMD one wave's MFMA phase meets the other's VALU
-// phase two steps out of three.  A unit takes three steps, every step starts with vmcnt(0) + workgroup barrier:
+// ---- persistent form with the two wave halves of the workgroup ONE STEP APART (temporal blocks, 8 key tiles) ----------
+// k_attn_temporal_x3p keeps all eight waves of the CU in the same phase: score MFMAs, then softmax VALU, then PV MFMAs, then the
+// output arithmetic -- the matrix pipe idles during the VALU phases and the VALU during the products.  Waves w and w + 4 share a
+// SIMD; here a unit takes FOUR steps (every step starts with vmcnt(0) + workgroup barrier) and waves 4-7 (half 1) run one step
+// behind waves 0-3 (half 0), so that on every SIMD, in every step, one wave is in an MFMA phase and the other in a VALU /
+// memory phase:
 //
-//   step 3i     half 0: S(i)        [K_i]      half 1: PV(i-1)   [V_{i-1}]
-//   step 3i+1   half 0: softmax(i)             half 1: S(i)      [K_i]        all waves first issue the V_i DMA (V_{i-1} is dead)
-//   step 3i+2   half 0: PV(i)       [V_i]      half 1: softmax(i)             all waves first issue the K_{i+1} DMA (K_i is dead)
+//   step 4i     half 0: scores(i)    [K_i]            half 1: outputs(i-1), stages V_i
+//   step 4i+1   half 0: softmax(i), stages V_i        half 1: scores(i)    [K_i]
+//   step 4i+2   half 0: products(i)  [V_i]            half 1: softmax(i), stages K_{i+1}
+//   step 4i+3   half 0: outputs(i), stages K_{i+1}    half 1: products(i)  [V_i]
 //
-// One K and one V buffer as before (128 KiB); every DMA has one whole step to land.  The two halves run two INSTANCES of the
-// same statically scheduled loop (HALF is a template parameter: the phase of a wave is never a run-time value, so register
-// allocation is that of k_attn_temporal_x3p), half 1 behind one extra barrier; both execute 3n + 1 barriers.  Each wave
-// computes exactly what it computes in k_attn_temporal_x3p (same MFMAs, same order, same softmax): results are bit-identical,
-// only WHEN differs.
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>) -- the body sees its index as a constant expression (asm
-// immediates)
+// One K and one V buffer (128 KiB) + a 4 KiB output patch per wave.  K_i is read in steps 4i, 4i+1 and re-staged in 4i+2, 4i+3;
+// V_i is read in steps 4i+2, 4i+3 (v_query goes to registers at the end of the product step) and re-staged in 4i+4, 4i+5.  A
+// wave issues the LDS-DMA of its pieces at the start of its own VALU steps (see dma below).  The two halves run two INSTANCES of the
+// same statically scheduled loop (HALF is a template parameter: the phase of a wave is never a run-time value), half 1 behind
+// one extra barrier; both execute 4n + 1 barriers.  Per wave the arithmetic is that of k_attn_temporal_x3p (same MFMAs in the
+// same order, same softmax, same conversions): results are bit-identical, only WHEN and by WHICH instructions differs.
 template <int... Js, class F>
 __device__ __forceinline__ void static_for_(std::integer_sequence<int, Js...>, F&& f) { (f(std::integral_constant<int, Js>{}), ...); }
 template <int N, class F>
@@ -581,6 +582,13 @@ __device__ __forceinline__ void split_pair_f16(float e0, float e1, float k, unsi
 #define D3D_ATTN_PRIO_SOFT 0
 #endif
 #define D3D_ATTN_PRIO(p) do { if ((p) >= 0) __builtin_amdgcn_s_setprio(p); } while (0)
+// wave-uniform pointer pinned into an SGPR pair (the DMA then takes the saddr + 32-bit voffset form)
+__device__ __forceinline__ const char* sgpr_ptr_(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
 template <int NKT, int HALF>
 __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl, _Float16* __restrict__ out_x3,
                                               int T, int J, int H, int D, int units, unsigned char* const lds, const int wave,
@@ -598,7 +606,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
   const int u0 = (int)blockIdx.x, ustep = (int)gridDim.x;
   const int n = (units - u0 + ustep - 1) / ustep;              // units of this workgroup (>= 1)
 #ifdef D3D_ATTN_DIAG_BUILD   // timing experiments: shader-clock stamps at the arrival at and the release from every step barrier
-  unsigned long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const bool rec = diag && blockIdx.x < 8 && (wave & 3) == 0;
 #define D3D_STAMP(k) do { if (rec) stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -613,20 +621,31 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     asm volatile("" : "+v"(lane));                                                                             \
     r = lane & 31; h = lane >> 5; tq = 32 * wave + r;                                                          \
   } while (0)
-  auto dma = [&](int which, size_t tok0, int hd) {   // which: 1 = K, 2 = V; wave w moves pieces w, w+8, w+16, w+24 of each plane
-    const int drow = lane >> 3, dslot = lane & 7;
+  // Staging of K / V by LDS-DMA: every wave moves pieces wave + 8 it, it = 0..3 (8 rows x 128 B each), of the hi and of the lo
+  // plane, at the START of one of its VALU steps (the partner wave of the SIMD runs MFMAs meanwhile):
+  //   V_i      half 0: in softmax(i)   (step 4i+1)     half 1: in outputs(i-1) (step 4i)       read from step 4i+2 on
+  //   K_{i+1}  half 0: in outputs(i)   (step 4i+3)     half 1: in softmax(i)   (step 4i+2)     read from step 4i+4 on
+  // The kernel moves 249 KB per unit and runs within 1.4x of the time HBM needs for that, so every vector-memory instruction
+  // queues (a wave gets one through per ~250 cycles, LDS-DMA or plain load alike): measured alternatives -- one half issuing a
+  // whole K or V, the pieces spread between the MFMAs / the softmax of a step, staging through registers with the LDS writes
+  // at the end of the step -- were 0 to 15 % slower.  Source address = (wave-uniform base: SGPR pair) + (one 32-bit per-lane
+  // byte offset, advanced by a uniform step per piece); the bank swizzles are applied to the per-lane SOURCE chunk.
+  auto dma = [&](int which, size_t tok0, int hd) {   // which: 1 = K, 2 = V
+    if (D3D_ATTN_ABL & 1) return;
+    const int row0 = 8 * wave + (lane >> 3), dslot = lane & 7;
+    const int chunk = (which == 1) ? (dslot ^ ((row0 >> 1) & 7)) : (dslot ^ vkey(row0));   // (both swizzles have period 32 in the row)
+    const size_t ub = tok0 * D3 + (size_t)which * D + hd * XDH;
+    const char* const bh = sgpr_ptr_(reinterpret_cast<const char*>(Ph + ub));
+    const char* const bl = sgpr_ptr_(reinterpret_cast<const char*>(Pl + ub));
+    unsigned voff = (unsigned)((row0 * J * D3 + chunk * 8) * 2);
+    const unsigned dst = (unsigned)(uintptr_t)((which == 1 ? sKh : sVh) + wave * 1024);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int piece = wave + NKT * it;
-      const int row = 8 * piece + drow;
-      const int chunk = (which == 1) ? (dslot ^ ((row >> 1) & 7)) : (dslot ^ vkey(row));
-      const size_t o = (tok0 + (size_t)row * J) * D3 + (size_t)which * D + hd * XDH + chunk * 8;
-      unsigned char* dh = (which == 1 ? sKh : sVh) + piece * 1024;
-      unsigned char* dl = (which == 1 ? sKl : sVl) + piece * 1024;
-      if (row < T) {
-        __builtin_amdgcn_global_load_lds(Ph + o, (__attribute__((address_space(3))) void*)(uintptr_t)dh, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(Pl + o, (__attribute__((address_space(3))) void*)(uintptr_t)dl, 16, 0, 0);
+    for (int it = 0; it < 4; ++it) {      // rows row0 + 64 it: only the last piece can reach beyond T (T > 224 with 8 key tiles)
+      if (it < 3 || row0 + 192 < T) {
+        __builtin_amdgcn_global_load_lds(bh + voff, (__attribute__((address_space(3))) void*)(uintptr_t)(dst + it * 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(bl + voff, (__attribute__((address_space(3))) void*)(uintptr_t)(dst + it * 8192 + PLANE), 16, 0, 0);
       }
+      voff += (unsigned)(64 * J * D3 * 2);
     }
   };
   auto unit_of = [&](int i, int& hd, size_t& tok0) {
@@ -641,7 +660,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     const size_t o = (tok0 + (size_t)(tq_ < T ? tq_ : 0) * J) * D3 + hd * XDH + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qh[ks] = *reinterpret_cast<const h8*>(Ph + o + 16 * ks);
+      qh[ks] = *reinterpret_cast<const h8*>(Ph + o + 16 * ks);     // rows >= T reuse row 0: their columns are never stored
       ql[ks] = *reinterpret_cast<const h8*>(Pl + o + 16 * ks);
     }
   };
@@ -649,7 +668,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
   int hd;
   size_t tok0;
   unit_of(0, hd, tok0);
-  dma(1, tok0, hd);             // K_0: every wave its pieces (both halves)
+  dma(1, tok0, hd);                     // K_0
   load_q(tok0, hd);
   // Outputs of a unit: hi/lo halves are transposed through a wave-private 4 KiB LDS patch (32 rows x one 128-byte line, 16-byte
   // chunks XOR-swizzled by row) so that every global store covers whole lines at 16 B per lane -- 8 lanes per row -- instead
@@ -660,16 +679,18 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
   const size_t po_stride = (size_t)8 * J * 2 * D;
   bool po_valid = false;
   int tq = 32 * wave + r;
-  if (HALF == 1) D3D_STEP_SYNC(3);      // global step 0: half 0 alone (no DMA duty in that step)
+  if (HALF == 1) {                      // global step 0: half 0's scores(0); half 1 stages its pieces of V_0
+    D3D_STEP_SYNC(4);
+    dma(2, tok0, hd);
+  }
 
   for (int i = 0; i < n; ++i) {
     const bool has_next = i + 1 < n;    // workgroup-uniform
     int hd_n = 0;
     size_t tok0_n = 0;
     if (has_next) unit_of(i + 1, hd_n, tok0_n);
-    // ================= this wave's S step (global step 3i + HALF)
+    // ================= this wave's score step (global step 4i + HALF)
     D3D_STEP_SYNC(0);
-    if (HALF == 1 && (!(D3D_ATTN_ABL & 1) || i == 0)) dma(2, tok0, hd);    // global step 3i+1: V_i
     if (po_valid) {
 #pragma unroll
       for (int it = 0; it < 4; ++it)
@@ -711,11 +732,11 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
         __builtin_amdgcn_sched_barrier(0);
       });
     }
-    // ================= softmax step (global step 3i + 1 + HALF)
+    // ================= softmax step (global step 4i + 1 + HALF)
     D3D_STEP_SYNC(1);
-    if (HALF == 0 && (!(D3D_ATTN_ABL & 1) || i == 0)) dma(2, tok0, hd);                         // global step 3i+1: V_i
-    if (HALF == 1 && has_next && !(D3D_ATTN_ABL & 1)) dma(1, tok0_n, hd_n);         // global step 3i+2: K_{i+1}
     D3D_ATTN_PRIO(D3D_ATTN_PRIO_SOFT);
+    if (HALF == 0) dma(2, tok0, hd);
+    else if (has_next) dma(1, tok0_n, hd_n);
     float m = -INFINITY;
 #pragma unroll
     for (int kt = ((D3D_ATTN_ABL & 4) ? NKT - 1 : 0); kt < NKT; ++kt)
@@ -735,26 +756,28 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     // the accumulator tile IS that operand after the pairwise conversion) -- the PV step then holds MFMAs, V reads and the
     // output arithmetic only.  lo = fp16(1024 e - hi) as ONE fused multiply-add (1024 e is exact, so the value is that of the
     // two-instruction form); the compiler selects v_fma_mix*_f16 for it.
-    u32x4 ehv[NKT][2], elv[NKT][2];
+    // (the packed halves go back into the registers of the score tile: slots 0-7 hold the hi pairs, 8-15 the lo pairs)
 #pragma unroll
-    for (int kt = 0; kt < ((D3D_ATTN_ABL & 4) ? 1 : NKT); ++kt)
+    for (int kt = 0; kt < ((D3D_ATTN_ABL & 4) ? 1 : NKT); ++kt) {
+      float e[16];
 #pragma unroll
-      for (int q = 0; q < 16; q += 2) {
-        const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][q], C_EXP, -mb));
-        const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[kt][q + 1], C_EXP, -mb));
-        l += e0;
-        l += e1;
-        unsigned hp, lp;
-        split_pair_f16(e0, e1, 1024.0f, hp, lp);
-        ehv[kt][q >> 3][(q & 7) >> 1] = hp;
-        elv[kt][q >> 3][(q & 7) >> 1] = lp;
+      for (int q = 0; q < 16; ++q) {
+        e[q] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][q], C_EXP, -mb));
+        l += e[q];
       }
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        unsigned hp, lp;
+        split_pair_f16(e[2 * pr], e[2 * pr + 1], 1024.0f, hp, lp);
+        sacc[kt][pr] = __builtin_bit_cast(float, hp);
+        sacc[kt][8 + pr] = __builtin_bit_cast(float, lp);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     l += __shfl_xor(l, 32, 64);
-    // ================= PV step (global step 3i + 2 + HALF)
+    // ================= PV product step (global step 4i + 2 + HALF)
     D3D_STEP_SYNC(2);
-    if (HALF == 0 && has_next && !(D3D_ATTN_ABL & 1)) dma(1, tok0_n, hd_n);         // global step 3i+2: K_{i+1}
     D3D_ATTN_PRIO(D3D_ATTN_PRIO_PV);
-    D3D_STAMP(6);
     // ---- O^T[d][query] = sum_key V^T[d][key] E^T[key][query]
     f32x16 oacc[2];
 #pragma unroll
@@ -788,7 +811,9 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
         constexpr int j = decltype(jc)::value, kt = j >> 1, s2 = j & 1;
         if (!(D3D_ATTN_ABL & 8)) {
           if constexpr (j + 1 < 2 * NKT) vread(std::integral_constant<int, j + 1>{}, vf[(j + 1) & 1]);
-          const h8 eh = __builtin_bit_cast(h8, ehv[kt][s2]), el = __builtin_bit_cast(h8, elv[kt][s2]);
+          typedef float f32x4_ __attribute__((ext_vector_type(4)));
+          const h8 eh = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 4 * s2, 4 * s2 + 1, 4 * s2 + 2, 4 * s2 + 3));
+          const h8 el = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 8 + 4 * s2, 9 + 4 * s2, 10 + 4 * s2, 11 + 4 * s2));
           lgkm_wait<(j + 1 < 2 * NKT) ? 8 : 0>();
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -804,27 +829,38 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (j == 9) { if (has_next) load_q(tok0_n, hd_n); }   // into the dead Q registers once two score tiles have been consumed
       });
     }
-    D3D_STAMP(7);
-    // ---- O = O^T / (2^13 l) - v_query (v_query from the V planes in LDS), packed as hi/lo of 8*o; stored in the next S step
+    // v_query (this wave's own rows of V) into registers: the V planes are released at the end of this step
+    h4 vqh[8], vql[8];
+    {
+      const int tqc = tq < T ? tq : 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int vo = vswz(tqc, c) + 8 * h;
+        vqh[c] = *reinterpret_cast<const h4*>(sVh + vo);
+        vql[c] = *reinterpret_cast<const h4*>(sVl + vo);
+      }
+    }
+    // ================= output step (global step 4i + 3 + HALF); the next queries are fetched here
+    D3D_STEP_SYNC(3);
+    D3D_ATTN_PRIO(D3D_ATTN_PRIO_SOFT);
+    if (has_next) dma(HALF == 0 ? 1 : 2, tok0_n, hd_n);
+    if (has_next) load_q(tok0_n, hd_n);
+    D3D_STAMP(10);
+    // ---- O = O^T / (2^13 l) - v_query, packed as hi/lo of 8*o; stored in the next score step
     {
       const float inv = 1.0f / (8192.0f * l);
-      const int tqc = tq < T ? tq : 0;
       float amax = 0.0f;   // range guard (rows tq >= T are never stored)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const int vo = vswz(tqc, dt * 4 + g4) + 8 * h;
-          const h4 vqh = *reinterpret_cast<const h4*>(sVh + vo);
-          const h4 vql = *reinterpret_cast<const h4*>(sVl + vo);
           h4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
-            const float o = oacc[dt][4 * g4 + e] * inv - vq;
+            const float vq = ((float)vqh[dt * 4 + g4][e] + (float)vql[dt * 4 + g4][e]) * 0.125f;
+            const float o = __builtin_fmaf(oacc[dt][4 * g4 + e], inv, -vq);   // stated: every form of this kernel must round the same way
             amax = fmaxf(amax, fabsf(o));
             const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
             oh[e] = (_Float16)sc;
@@ -846,18 +882,18 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
       po_ptr = out_x3 + (tok0 + (size_t)(32 * wave + (lane >> 3)) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
       po_valid = true;
     }
-    D3D_STAMP(8);
+    D3D_STAMP(12);
     hd = hd_n; tok0 = tok0_n;
 #ifdef D3D_ATTN_DIAG_BUILD
     if (rec && i < 8 && (threadIdx.x & 63) == 0) {
-      stamp[10] = __builtin_amdgcn_s_memrealtime();
-      stamp[11] = __builtin_amdgcn_s_memtime();
-      unsigned long long* d = diag + (((size_t)blockIdx.x * 2 + HALF) * 8 + i) * 12;
-      for (int k = 0; k < 12; ++k) d[k] = stamp[k];
+      stamp[13] = __builtin_amdgcn_s_memrealtime();
+      stamp[14] = __builtin_amdgcn_s_memtime();
+      unsigned long long* d = diag + (((size_t)blockIdx.x * 2 + HALF) * 8 + i) * 16;
+      for (int k = 0; k < 16; ++k) d[k] = stamp[k];
     }
 #endif
   }
-  if (HALF == 0) D3D_STEP_SYNC(3);      // global step 3n: half 1's last PV step
+  if (HALF == 0) D3D_STEP_SYNC(4);      // global step 4n: half 1's last output step
 #undef D3D_STEP_SYNC
 #undef D3D_STAMP
   {   // outputs of the last unit
@@ -933,7 +969,7 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
 
 #ifdef D3D_ATTN_DIAG_BUILD
 static unsigned long long* g_attn_diag = nullptr;
-constexpr size_t ATTN_DIAG_WORDS = 8 * 2 * 8 * 12;   // [workgroup < 8][half][unit < 8][6 stamps, 100 MHz stamp, clock stamp]
+constexpr size_t ATTN_DIAG_WORDS = 8 * 2 * 8 * 16;   // [workgroup < 8][half][unit < 8][6 stamps, 100 MHz stamp, clock stamp]
 #endif
 void attn_x3_diag_report() {
 #ifdef D3D_ATTN_DIAG_BUILD
@@ -944,17 +980,17 @@ void attn_x3_diag_report() {
     for (int half = 0; half < 2; ++half) {
       double ghz = 0;
       {
-        const unsigned long long* a = &h[((wg * 2 + half) * 8 + 2) * 12];
-        const unsigned long long* b = &h[((wg * 2 + half) * 8 + 7) * 12];
-        if (b[10] > a[10]) ghz = (double)(b[11] - a[11]) / (double)(b[10] - a[10]) * 0.1;
+        const unsigned long long* a = &h[((wg * 2 + half) * 8 + 2) * 16];
+        const unsigned long long* b = &h[((wg * 2 + half) * 8 + 7) * 16];
+        if (b[13] > a[13]) ghz = (double)(b[14] - a[14]) / (double)(b[13] - a[13]) * 0.1;
       }
-      fprintf(stderr, "[attn diag] wg %d half %d clock %.3f GHz; per unit, cycles: S wait|work  softmax wait|work  PV wait|work\n", wg, half, ghz);
+      fprintf(stderr, "[attn diag] wg %d half %d clock %.3f GHz; per unit, cycles wait|work: scores  softmax  PV products  outputs\n", wg, half, ghz);
       for (int i = 2; i < 7; ++i) {
-        const unsigned long long* d = &h[((wg * 2 + half) * 8 + i) * 12];
-        const unsigned long long* n = &h[((wg * 2 + half) * 8 + i + 1) * 12];
-        fprintf(stderr, "   unit %d: %6llu|%6llu  %6llu|%6llu  %6llu|%6llu   (unit %llu cycles)  PV: issue %llu  products %llu  outputs %llu  rest %llu\n",
-                i, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], n[0] - d[5], n[0] - d[0], d[6] - d[5], d[7] - d[6],
-                d[8] - d[7], n[0] - d[8]);
+        const unsigned long long* d = &h[((wg * 2 + half) * 8 + i) * 16];
+        const unsigned long long* n = &h[((wg * 2 + half) * 8 + i + 1) * 16];
+        fprintf(stderr, "   unit %d: %6llu|%6llu  %6llu|%6llu  %6llu|%6llu  %6llu|%6llu   (unit %llu cycles)  output step: issue %llu  arithmetic %llu\n",
+                i, d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], n[0] - d[7], n[0] - d[0],
+                d[10] - d[7], d[12] - d[10]);
       }
     }
 #endif
