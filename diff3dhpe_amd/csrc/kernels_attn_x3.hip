@@ -589,6 +589,9 @@ __device__ __forceinline__ const char* sgpr_ptr_(const char* p) {
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
+#ifndef D3D_ATTN_H0_MFMA_DMA
+#define D3D_ATTN_H0_MFMA_DMA 0   // 1: half 0 issues its DMA pieces at the start of its MFMA steps (one step earlier): measured 3 % slower
+#endif
 template <int NKT, int HALF>
 __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl, _Float16* __restrict__ out_x3,
                                               int T, int J, int H, int D, int units, unsigned char* const lds, const int wave,
@@ -700,6 +703,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
         }
     }
     D3D_ATTN_PRIO(D3D_ATTN_PRIO_S);
+    if (HALF == 0 && D3D_ATTN_H0_MFMA_DMA) dma(2, tok0, hd);                     // V_i
     // ---- S^T tiles (rows = keys, column = query tq); acc = 64 * s.  A step = one 16-deep d-slice of one key tile: two
     // ds_read_b128, three MFMAs; the fragments of step j + 2 are requested before the MFMAs of step j issue, which wait for
     // their own fragments only (lgkmcnt(4): the four younger reads stay in flight).
@@ -735,8 +739,8 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     // ================= softmax step (global step 4i + 1 + HALF)
     D3D_STEP_SYNC(1);
     D3D_ATTN_PRIO(D3D_ATTN_PRIO_SOFT);
-    if (HALF == 0) dma(2, tok0, hd);
-    else if (has_next) dma(1, tok0_n, hd_n);
+    if (HALF == 0) { if (!D3D_ATTN_H0_MFMA_DMA) dma(2, tok0, hd); }              // V_i
+    else if (has_next) dma(1, tok0_n, hd_n);                                     // K_{i+1}
     float m = -INFINITY;
 #pragma unroll
     for (int kt = ((D3D_ATTN_ABL & 4) ? NKT - 1 : 0); kt < NKT; ++kt)
@@ -778,6 +782,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     // ================= PV product step (global step 4i + 2 + HALF)
     D3D_STEP_SYNC(2);
     D3D_ATTN_PRIO(D3D_ATTN_PRIO_PV);
+    if (HALF == 0 && D3D_ATTN_H0_MFMA_DMA && has_next) dma(1, tok0_n, hd_n);      // K_{i+1}
     // ---- O^T[d][query] = sum_key V^T[d][key] E^T[key][query]
     f32x16 oacc[2];
 #pragma unroll
@@ -845,12 +850,14 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     // ================= output step (global step 4i + 3 + HALF); the next queries are fetched here
     D3D_STEP_SYNC(3);
     D3D_ATTN_PRIO(D3D_ATTN_PRIO_SOFT);
-    if (has_next) dma(HALF == 0 ? 1 : 2, tok0_n, hd_n);
+    if (has_next && (HALF == 1 || !D3D_ATTN_H0_MFMA_DMA)) dma(HALF == 0 ? 1 : 2, tok0_n, hd_n);
     if (has_next) load_q(tok0_n, hd_n);
     D3D_STAMP(10);
     // ---- O = O^T / (2^13 l) - v_query, packed as hi/lo of 8*o; stored in the next score step
     {
-      const float inv = 1.0f / (8192.0f * l);
+      // 8 o = oacc * (8 inv) - (vq_hi + vq_lo): the planes hold 8 v, so this is 8 * fma(oacc, inv, -v) bit for bit (powers of
+      // two commute with the rounding), without the two scalings per element; range guard on |8 o| accordingly
+      const float inv8 = 8.0f * (1.0f / (8192.0f * l));
       float amax = 0.0f;   // range guard (rows tq >= T are never stored)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -859,10 +866,10 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
           h4 oh, ol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float vq = ((float)vqh[dt * 4 + g4][e] + (float)vql[dt * 4 + g4][e]) * 0.125f;
-            const float o = __builtin_fmaf(oacc[dt][4 * g4 + e], inv, -vq);   // stated: every form of this kernel must round the same way
-            amax = fmaxf(amax, fabsf(o));
-            const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
+            const float vq8 = (float)vqh[dt * 4 + g4][e] + (float)vql[dt * 4 + g4][e];
+            const float o8 = __builtin_fmaf(oacc[dt][4 * g4 + e], inv8, -vq8);
+            amax = fmaxf(amax, fabsf(o8));
+            const float sc = __builtin_amdgcn_fmed3f(o8, -65504.0f, 65504.0f);
             oh[e] = (_Float16)sc;
             ol[e] = (_Float16)(sc - (float)oh[e]);
             if (D3D_ATTN_ABL & 64) { oh[e] = (_Float16)oacc[dt][4 * g4 + e]; ol[e] = oh[e]; }
@@ -878,7 +885,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
           po[dt * 4 + it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
         }
       }
-      if (tq < T && amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
+      if (tq < T && amax > X3_HALF_MAX) atomicOr(&g_range_attn, 1u);
       po_ptr = out_x3 + (tok0 + (size_t)(32 * wave + (lane >> 3)) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
       po_valid = true;
     }
