@@ -357,6 +357,13 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   h4 po_h[8], po_l[8];          // packed outputs of the previous unit, stored one barrier later
   size_t po_off = 0;
   bool po_valid = false;
+  // WAVEP: the outputs go through a wave-private 4 KiB LDS patch (32 rows x one 128-byte line, 16-byte chunks XOR-swizzled by
+  // row) and leave as whole lines, 16 B per lane, 8 lanes per row: 6 store instructions per unit instead of 16 that each wrote
+  // 16-byte pieces of 17 different lines (this kernel is bound by the rate at which a wave gets memory instructions through)
+  unsigned char* const patch = lds_all + MU * NPL * PL + (TP - T) * 128 + (int)(threadIdx.x >> 6) * 4096;
+  u32x4 pw[6];                  // [dt * 3 + it]: row 8 it + (lane >> 3), chunk lane & 7 of line dt
+  _Float16* pw_ptr = out_x3;    // row (lane >> 3), this lane's chunk of line 0 (row 8 it: + it * pw_stride)
+  const size_t pw_stride = (size_t)8 * J * 2 * D;
   int tq = 32 * wave + r;
 
   for (;;) {
@@ -364,7 +371,16 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     asm volatile("" : "+v"(lane));
     r = lane & 31; h = lane >> 5; tq = 32 * wave + r;
     if (!WAVEP) dma(2, tok0, hd);
-    if (po_valid && tq < T) {
+    if (WAVEP) {
+      if (po_valid) {
+#pragma unroll
+        for (int it = 0; it < 3; ++it)
+          if (8 * it + (lane >> 3) < T) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * 3 + it];
+          }
+      }
+    } else if (po_valid && tq < T) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -494,11 +510,25 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
             oh[e] = (_Float16)sc;
             ol[e] = (_Float16)(sc - (float)oh[e]);
           }
-          po_h[dt * 4 + g4] = oh;
-          po_l[dt * 4 + g4] = ol;
+          if (WAVEP) {   // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout)
+            const int sw = (r >> 1) & 7;
+            *reinterpret_cast<h4*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
+            *reinterpret_cast<h4*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
+            if (g4 == 3) {
+#pragma unroll
+              for (int it = 0; it < 3; ++it) {
+                const int row = 8 * it + (lane >> 3);
+                pw[dt * 3 + it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+              }
+            }
+          } else {
+            po_h[dt * 4 + g4] = oh;
+            po_l[dt * 4 + g4] = ol;
+          }
         }
       if (tq < T && amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
       po_off = (tok0 + (size_t)tqc * J) * 2 * D + hd * 2 * XDH;
+      if (WAVEP) pw_ptr = out_x3 + (tok0 + (size_t)(lane >> 3) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
       po_valid = true;
     }
     if (!has_next) break;
@@ -511,7 +541,14 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   }
 #undef D3D_ATTN_SYNC
   // outputs of the last unit
-  if (tq < T) {
+  if (WAVEP) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+      if (8 * it + (lane >> 3) < T) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * 3 + it];
+      }
+  } else if (tq < T) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -957,7 +994,7 @@ template <int NKT, int MU = 1>
 static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H,
                                  hipStream_t s) {
   // wave-private units (MU > 1, NKT == 1): 6 planes of T rows per wave (V double-buffered) + one zeroed pad behind the last
-  const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 : (size_t)4 * 32 * NKT * 128;
+  const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 + (size_t)MU * 4096 : (size_t)4 * 32 * NKT * 128;
   static std::atomic<unsigned long long> attr_set{0};   // one bit per device
   if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU>), MU > 1 ? (size_t)160 * 1024 : lds_bytes,
                                attr_set))
@@ -1036,9 +1073,9 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
     case 1:   // groups of <= 32 tokens (spatial blocks: the 17 joints of a frame).  8 units per workgroup = the 8 heads of one
               // frame at H = 8, so a workgroup reads whole token rows; measured 0.61 ms per launch at T=243, B=64 against
               // 0.82 / 0.68 / 0.69 ms with 1 / 2 / 4 units per workgroup.
-      if ((long long)B * J * H >= 4096 && !no_persist && (size_t)8 * 6 * T * 128 + (size_t)(32 - T) * 128 <= 160 * 1024) {
+      if ((long long)B * J * H >= 4096 && !no_persist && (size_t)8 * 6 * T * 128 + (size_t)(32 - T) * 128 + 8 * 4096 <= 160 * 1024) {
         static const int mu = getenv("D3D_ATTN_MU") ? atoi(getenv("D3D_ATTN_MU")) : 8;   // (experiments/)
-        if (mu == 12 && (size_t)12 * 6 * T * 128 + (size_t)(32 - T) * 128 <= 160 * 1024) return launch_x3p_nkt<1, 12>(ph, pl, ox, B, T, J, D, H, s);
+        if (mu == 12 && (size_t)12 * 6 * T * 128 + (size_t)(32 - T) * 128 + 12 * 4096 <= 160 * 1024) return launch_x3p_nkt<1, 12>(ph, pl, ox, B, T, J, D, H, s);
         return launch_x3p_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
       }
       if ((long long)B * J * H >= 4096) return launch_x3_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
