@@ -256,6 +256,13 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
 // MU > 1 (NKT == 1: groups of <= 32 tokens, the spatial blocks): every wave is its own persistent worker on its own LDS
 // slice (units blockIdx * MU + wave, + gridDim * MU, ...); the barriers become wave-local waits, so the MU waves of a
 // workgroup drift apart and their load / MFMA / VALU phases overlap.
+// wave-uniform pointer pinned into an SGPR pair (the DMA then takes the saddr + 32-bit voffset form)
+__device__ __forceinline__ const char* sgpr_ptr_x(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
 template <int NKT, int MU>
 __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
                                                                      _Float16* __restrict__ out_x3, int T, int J, int H, int D,
@@ -318,17 +325,22 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     const int drow = lane >> 3, dslot = lane & 7;
     unsigned char* const dVh = lds + (2 + 2 * vbuf) * PL;
     unsigned char* const dVl = dVh + PL;
+    // source address = (wave-uniform base: SGPR pair) + (32-bit per-lane byte offset): no 64-bit per-piece row arithmetic
+    const size_t ub = tok0 * D3 + (size_t)which * D + hd * XDH;
+    const char* const bh = sgpr_ptr_x(reinterpret_cast<const char*>(Ph + ub));
+    const char* const bl = sgpr_ptr_x(reinterpret_cast<const char*>(Pl + ub));
+    const int rowstep = J * D3 * 2;      // bytes between consecutive rows of the group
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int piece = wave + NKT * it;
       const int row = 8 * piece + drow;
       const int chunk = (which == 1) ? (dslot ^ ((row >> 1) & 7)) : (dslot ^ vkey(row));
-      const size_t o = (tok0 + (size_t)row * J) * D3 + (size_t)which * D + hd * XDH + chunk * 8;
+      const unsigned voff = (unsigned)(row * rowstep + chunk * 16);
       unsigned char* dh = (which == 1 ? sKh : dVh) + piece * 1024;
       unsigned char* dl = (which == 1 ? sKl : dVl) + piece * 1024;
       if (row < T) {
-        __builtin_amdgcn_global_load_lds(Ph + o, (__attribute__((address_space(3))) void*)(uintptr_t)dh, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(Pl + o, (__attribute__((address_space(3))) void*)(uintptr_t)dl, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(bh + voff, (__attribute__((address_space(3))) void*)(uintptr_t)dh, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(bl + voff, (__attribute__((address_space(3))) void*)(uintptr_t)dl, 16, 0, 0);
       }
     }
   };
@@ -619,13 +631,6 @@ __device__ __forceinline__ void split_pair_f16(float e0, float e1, float k, unsi
 #define D3D_ATTN_PRIO_SOFT 0
 #endif
 #define D3D_ATTN_PRIO(p) do { if ((p) >= 0) __builtin_amdgcn_s_setprio(p); } while (0)
-// wave-uniform pointer pinned into an SGPR pair (the DMA then takes the saddr + 32-bit voffset form)
-__device__ __forceinline__ const char* sgpr_ptr_(const char* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-}
-
 #ifndef D3D_ATTN_H0_MFMA_DMA
 #define D3D_ATTN_H0_MFMA_DMA 0   // 1: half 0 issues its DMA pieces at the start of its MFMA steps (one step earlier): measured 3 % slower
 #endif
@@ -675,8 +680,8 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     const int row0 = 8 * wave + (lane >> 3), dslot = lane & 7;
     const int chunk = (which == 1) ? (dslot ^ ((row0 >> 1) & 7)) : (dslot ^ vkey(row0));   // (both swizzles have period 32 in the row)
     const size_t ub = tok0 * D3 + (size_t)which * D + hd * XDH;
-    const char* const bh = sgpr_ptr_(reinterpret_cast<const char*>(Ph + ub));
-    const char* const bl = sgpr_ptr_(reinterpret_cast<const char*>(Pl + ub));
+    const char* const bh = sgpr_ptr_x(reinterpret_cast<const char*>(Ph + ub));
+    const char* const bl = sgpr_ptr_x(reinterpret_cast<const char*>(Pl + ub));
     unsigned voff = (unsigned)((row0 * J * D3 + chunk * 8) * 2);
     const unsigned dst = (unsigned)(uintptr_t)((which == 1 ? sKh : sVh) + wave * 1024);
 #pragma unroll
