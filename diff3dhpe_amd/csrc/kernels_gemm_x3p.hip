@@ -106,6 +106,20 @@ __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
+// LDS fragment read as inline asm: the compiler does not know it as an LDS operation and inserts no s_waitcnt for it -- the
+// k-loop places COUNTED lgkmcnt waits itself (LDS operations of one wave return in order).  Left to the compiler, every phase
+// opened with its 10-12 fragment reads followed by s_waitcnt lgkmcnt(0): ~350 cycles per phase in which neither wave of the
+// SIMD (both just released by the same barrier) had an MFMA to issue.
+__device__ __forceinline__ void lds_rd128(h8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); }
+// wait until at most N LDS operations of this wave are outstanding; the fragments named become usable (data dependence for
+// the scheduler: the MFMAs that read them cannot be moved above the wait)
+template <int N>
+__device__ __forceinline__ void lgkm_wait4(h8& a, h8& b, h8& c, h8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait2(h8& a, h8& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
 // Launch-time dispatch over (epilogue, output form): the five combinations the engine and the op hooks use.
 #define D3D_X3_DISPATCH(LAUNCH)                                                                                          \
   do {                                                                                                                   \
@@ -971,6 +985,72 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : ((DO_A) ? B_IT - W_ODD : 0));                   \
       else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
     } while (0)
+#ifndef D3D_X3_ASMREAD
+#define D3D_X3_ASMREAD 0   // measured (same box, 3 alternations): qkv 1.136 -> 1.145 ms, fc1 0.875 -> 0.878: no gain -- the ~350 cycles behind
+#endif                     // a phase's barrier are not what the k-loop loses (the staging instructions are: MI355X notes in DESIGN.md)
+    // The same phase for whole tiles (!SUB) with the fragment reads as inline asm and counted waits:
+    //   even phase: A(G0) pair and the 8 W fragments are requested behind the barrier; the first group's MFMAs for n-tile j wait
+    //               for THEIR fragments only (lgkmcnt 8, 6, 4, 2 with the next A pair already requested behind them);
+    //   every group requests the A pair of the next group first -- the last group of the even phase that of the ODD phase's first
+    //   group (those rows landed with the rest of A(KT) before the even phase's barrier), so the odd phase opens with MFMAs.
+    const unsigned lds_u = (unsigned)(uintptr_t)lds;
+#define D3D_PHASE_A(KT, H, DO_A, W_FULL1, DO_W)                                                                           \
+    do {                                                                                                                  \
+      wait_vm(issued_prev);                                                                                               \
+      __builtin_amdgcn_s_barrier();                                                                                       \
+      asm volatile("" : "+v"(lofs_) : : "memory");                                                                        \
+      const unsigned sb_ = lds_u + ((KT) & 1) * STAGE;                                                                    \
+      const unsigned aH_ = sb_ + aoff, aL_ = sb_ + (aoff ^ 64), bH_ = sb_ + boff, bL_ = sb_ + (boff ^ 64);                \
+      constexpr int G0 = (H) * (TM / 2), G1 = G0 + TM / 2;                                                                \
+      if ((H) == 0) {                                                                                                     \
+        lds_rd128(ah[G0 & 1], aH_ + G0 * 2048);                                                                           \
+        lds_rd128(al[G0 & 1], aL_ + G0 * 2048);                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+          lds_rd128(bh[j], bH_ + j * 2048);                                                                               \
+          lds_rd128(bl[j], bL_ + j * 2048);                                                                               \
+        }                                                                                                                 \
+      }                                                                                                                   \
+      _Pragma("unroll") for (int g = G0; g < G1; ++g) {                                                                   \
+        const bool pre_ = (g + 1 < G1) || ((H) == 0);       /* an A pair is requested for the next group */               \
+        if (pre_) {                                                                                                       \
+          lds_rd128(ah[(g + 1) & 1], aH_ + (g + 1) * 2048);                                                               \
+          lds_rd128(al[(g + 1) & 1], aL_ + (g + 1) * 2048);                                                               \
+        }                                                                                                                 \
+        constexpr int NP_ = ((H) == 0) ? A_IT + B_IT : W_ODD;                                                             \
+        constexpr int PPG_ = (NP_ + TM / 2 - 1) / (TM / 2);                                                               \
+        _Pragma("unroll") for (int pp = 0; pp < PPG_; ++pp) {                                                             \
+          const int sl = (g - G0) * PPG_ + pp;                                                                            \
+          if ((H) == 0) {                                                                                                 \
+            if (sl < A_IT) { if (DO_A) D3D_PIECE((KT) + 1, sl); }                                                         \
+            else if (sl < A_IT + B_IT) {                                                                                  \
+              if ((W_FULL1) || ((DO_A) && sl - A_IT >= W_ODD)) D3D_PIECE((KT) + 1, sl);                                   \
+            }                                                                                                             \
+          } else if (sl < W_ODD) {                                                                                        \
+            if (DO_W) D3D_PIECE((KT) + 2, A_IT + sl);                                                                     \
+          }                                                                                                               \
+        }                                                                                                                 \
+        if ((H) == 0 && g == G0) {                                                                                        \
+          lgkm_wait4<8>(bh[0], bl[0], ah[g & 1], al[g & 1]);                                                              \
+        } else if (pre_) {                                                                                                \
+          lgkm_wait2<2>(ah[g & 1], al[g & 1]);                                                                            \
+        } else {                                                                                                          \
+          lgkm_wait2<0>(ah[g & 1], al[g & 1]);                                                                            \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+          if ((H) == 0 && g == G0) {                                                                                      \
+            if (j == 1) lgkm_wait2<6>(bh[1], bl[1]);                                                                      \
+            if (j == 2) lgkm_wait2<4>(bh[2], bl[2]);                                                                      \
+            if (j == 3) lgkm_wait2<2>(bh[3], bl[3]);                                                                      \
+          }                                                                                                               \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                       \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                       \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                       \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+      }                                                                                                                   \
+      if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : ((DO_A) ? B_IT - W_ODD : 0));                   \
+      else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
+    } while (0)
     h8 bh[4], bl[4], ah[2], al[2];
 #ifndef D3D_X3_STAGGER
 #define D3D_X3_STAGGER 0
@@ -1047,23 +1127,30 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
 #undef D3D_SWFRAGS
     } else {
     // first k-tile: everything issued before this tile (stores of the previous epilogue included) has landed: vmcnt(0)
-    issued_prev = 0;
-    D3D_PHASE(0, 0, true, true, false);
-    D3D_PHASE(0, 1, false, false, nk > 2 || has_next);
-    int kt = 1;
-    for (; kt + 2 < nk; ++kt) {
-      D3D_PHASE(kt, 0, true, false, false);
-      D3D_PHASE(kt, 1, false, false, true);
+#define D3D_SCHEDULE(PH)                                                                                                  \
+    do {                                                                                                                  \
+      issued_prev = 0;                                                                                                    \
+      PH(0, 0, true, true, false);                                                                                        \
+      PH(0, 1, false, false, nk > 2 || has_next);                                                                         \
+      int kt = 1;                                                                                                         \
+      for (; kt + 2 < nk; ++kt) {                                                                                         \
+        PH(kt, 0, true, false, false);                                                                                    \
+        PH(kt, 1, false, false, true);                                                                                    \
+      }                                                                                                                   \
+      if (nk > 2) { /* k-tile nk-2: A(nk-1) of this tile, then W(0) of the next tile */                                   \
+        PH(kt, 0, true, false, false);                                                                                    \
+        PH(kt, 1, false, false, has_next);                                                                                \
+        ++kt;                                                                                                             \
+      }                                                                                                                   \
+      /* k-tile nk-1: A(0) of the next tile; W(1) of the next tile waits for its own phase 0 (the epilogue's patches) */   \
+      PH(kt, 0, has_next, false, false);                                                                                  \
+      PH(kt, 1, false, false, false);                                                                                     \
+    } while (0)
+    if constexpr (!SUB && D3D_X3_ASMREAD != 0) { D3D_SCHEDULE(D3D_PHASE_A); }
+    else { D3D_SCHEDULE(D3D_PHASE); }
+#undef D3D_SCHEDULE
     }
-    if (nk > 2) {   // k-tile nk-2: A(nk-1) of this tile, then W(0) of the next tile
-      D3D_PHASE(kt, 0, true, false, false);
-      D3D_PHASE(kt, 1, false, false, has_next);
-      ++kt;
-    }
-    // k-tile nk-1: A(0) of the next tile; W(1) of the next tile waits for its own phase 0 (the epilogue's patches live there)
-    D3D_PHASE(kt, 0, has_next, false, false);
-    D3D_PHASE(kt, 1, false, false, false);
-    }
+#undef D3D_PHASE_A
 #undef D3D_PHASE
 #undef D3D_PIECE
   } else {
