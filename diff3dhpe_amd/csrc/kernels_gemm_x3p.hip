@@ -898,6 +898,11 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     // earlier).  The stream runs on across tiles: W(0) / A(0) of the next tile are issued by phases 2nk-3 / 2nk-2 of this one, its
     // W(1) -- whose stage holds the epilogue's patches -- with A(1) in its own phase 0.  Same MFMAs in the same order per element
     // as the one-barrier form (values unchanged).
+#ifndef D3D_X3_DMASPREAD
+#define D3D_X3_DMASPREAD 0   // 1: the waves issue their staging pieces at different points of an MFMA group (two waves per n-tile slot,
+                             // SIMD partners in different slots) instead of all eight at its top: qkv 1.066 -> 1.094 ms, fc1 0.818 -> 0.831 (slower)
+#endif
+    const int jw_ = (wave + (wave >> 2)) & 3;      // SIMD partners (w, w + 4) get different slots
     auto wait_vm = [](int n) {   // s_waitcnt vmcnt(n), n wave-uniform (counts differ per wave only in tail slices)
       switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -962,19 +967,26 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
         }                                                                                                                 \
         constexpr int NP_ = ((H) == 0) ? A_IT + B_IT : W_ODD;      /* piece slots of this phase kind, spread over TM/2 groups */ \
         constexpr int PPG_ = (NP_ + TM / 2 - 1) / (TM / 2);                                                               \
-        _Pragma("unroll") for (int pp = 0; pp < PPG_; ++pp) {                                                             \
-          const int sl = (g - G0) * PPG_ + pp;                                                                            \
-          if ((H) == 0) {                                                                                                 \
-            if (sl < A_IT) { if (DO_A) D3D_PIECE((KT) + 1, sl); }                                                         \
-            else if (sl < A_IT + B_IT) {                                                                                  \
-              if ((W_FULL1) || ((DO_A) && sl - A_IT >= W_ODD)) D3D_PIECE((KT) + 1, sl);                                   \
+        auto pieces_ = [&]() {                                                                                            \
+          _Pragma("unroll") for (int pp = 0; pp < PPG_; ++pp) {                                                           \
+            const int sl = (g - G0) * PPG_ + pp;                                                                          \
+            if ((H) == 0) {                                                                                               \
+              if (sl < A_IT) { if (DO_A) D3D_PIECE((KT) + 1, sl); }                                                       \
+              else if (sl < A_IT + B_IT) {                                                                                \
+                if ((W_FULL1) || ((DO_A) && sl - A_IT >= W_ODD)) D3D_PIECE((KT) + 1, sl);                                 \
+              }                                                                                                           \
+            } else if (sl < W_ODD) {                                                                                      \
+              if (DO_W) D3D_PIECE((KT) + 2, A_IT + sl);                                                                   \
             }                                                                                                             \
-          } else if (sl < W_ODD) {                                                                                        \
-            if (DO_W) D3D_PIECE((KT) + 2, A_IT + sl);                                                                     \
           }                                                                                                               \
-        }                                                                                                                 \
+        };                                                                                                                \
+        if (!D3D_X3_DMASPREAD || SUB) pieces_();                                                                          \
         if (g_act) {                                                                                                      \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
+            if (D3D_X3_DMASPREAD && !SUB) {                                                                               \
+              if (j == jw_) pieces_();                                                                                    \
+              __builtin_amdgcn_sched_barrier(0);                                                                          \
+            }                                                                                                             \
             acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                     \
             acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
             acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
