@@ -141,13 +141,15 @@ def sq(dirpath, out):
 def traffic(pmc_json, traffic_json, T, B, prec):
     """Mean HBM-side bytes per launch of each bench.py kernel class -> profiles/hbm_traffic.json (read by bench.py)."""
     k = json.load(open(pmc_json))["kernels"]
-    cls = {"linear": "k_linear", "attn_temporal": "(temporal blocks)", "attn_spatial": "(spatial blocks)", "layernorm": "k_layernorm"}
-    if not any("(spatial blocks)" in n for n in k):
-        cls["attn_spatial"] = "k_attn_spatial"
-        cls["attn_temporal"] = "k_attn_temporal"
+    # kernel name patterns per class; the fp16-MFMA attention serves both block types from one template: <1, MU> = groups of
+    # <= 32 tokens = the spatial blocks, everything else (x3s<8>, x3p<3, 1>, x3p<8, 1>, x3<NKT, 1>) the temporal blocks
+    def is_spatial(n):
+        return "k_attn_spatial" in n or "k_attn_temporal_x3p<1," in n or "k_attn_temporal_x3<1," in n or "(spatial blocks)" in n
+    cls = {"linear": lambda n: "k_linear" in n, "layernorm": lambda n: "k_layernorm" in n,
+           "attn_spatial": is_spatial, "attn_temporal": lambda n: "k_attn_temporal" in n and not is_spatial(n)}
     tj = json.load(open(traffic_json)) if os.path.exists(traffic_json) else {}
     for c, pat in cls.items():
-        sel = [v for n, v in k.items() if pat in n]
+        sel = [v for n, v in k.items() if pat(n)]
         n = sum(v["launches"] for v in sel)
         if n:
             tj["{}:T{}:B{}:{}".format(c, T, B, prec)] = round(sum(v["hbm_bytes"] * v["launches"] for v in sel) / n)
