@@ -640,9 +640,8 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
                                               unsigned long long* diag) {
   constexpr int TP = 32 * NKT;
   constexpr int PLANE = TP * 128;
-  unsigned char* const sKh = lds;
-  unsigned char* const sKl = lds + PLANE;
-  unsigned char* const sVh = lds + 2 * PLANE;
+  unsigned char* const sKh = lds;                 // K hi plane; lo plane at + PLANE
+  unsigned char* const sVh = lds + 2 * PLANE;     // V hi plane; lo plane at + PLANE
   unsigned char* const sVl = lds + 3 * PLANE;
   int lane = (int)threadIdx.x & 63;
   asm volatile("" : "+v"(lane));
