@@ -1132,6 +1132,11 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
     return launch_linear_x3p(ap.dev, wp.dev, bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s);
   };
   HIP_TRY(once());
+  if (getenv("D3D_GEMM_PHASE_DIAG") && precision == D3D_PREC_F16X3 && variant == 0) {
+    for (int i = 0; i < 10; ++i) HIP_TRY(once());              // warm clocks
+    HIP_TRY(hipStreamSynchronize(s));
+    x3_phase_diag_report();
+  }
   if (getenv("D3D_GEMM_DIAG") && precision == D3D_PREC_F16X3 && (variant == 13)) {
     // diagnostic: in-kernel clock and k-loop / epilogue split from s_memtime / s_memrealtime stamps (256x256 tiles, 8 waves)
     const size_t nwg = (size_t)(((M + 255) / 256 + 7) / 8 * 8) * ((N + 255) / 256), nrec = nwg * 8;

@@ -106,6 +106,24 @@ __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
+#ifdef D3D_X3_PHASE_DIAG   // timing experiments: shader-clock stamps inside the two phases of k-tile 5 (workgroup 3, every wave)
+__device__ unsigned long long g_x3_phase_diag[8 * 2 * 8];
+#endif
+void x3_phase_diag_report() {
+#ifdef D3D_X3_PHASE_DIAG
+  unsigned long long h[8 * 2 * 8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_x3_phase_diag), sizeof(h)) != hipSuccess) return;
+  fprintf(stderr, "[phase diag] cycles per wave: even phase wait | barrier->reads | group 0..3   odd phase wait | - | group 4..7   (k-tile 5, workgroup 3)\n");
+  for (int w = 0; w < 8; ++w) {
+    const unsigned long long* e = &h[(w * 2 + 0) * 8];
+    const unsigned long long* o = &h[(w * 2 + 1) * 8];
+    fprintf(stderr, "  wave %d: %5llu | %5llu | %5llu %5llu %5llu %5llu      %5llu | %5llu | %5llu %5llu %5llu %5llu    k-tile %llu\n", w, e[1] - e[0],
+            e[2] - e[1], e[3] - e[2], e[4] - e[3], e[5] - e[4], e[6] - e[5], o[1] - o[0], o[2] - o[1], o[3] - o[2], o[4] - o[3], o[5] - o[4],
+            o[6] - o[5], o[6] - e[0]);
+  }
+#endif
+}
+
 // LDS fragment read as inline asm: the compiler does not know it as an LDS operation and inserts no s_waitcnt for it -- the
 // k-loop places COUNTED lgkmcnt waits itself (LDS operations of one wave return in order).  Left to the compiler, every phase
 // opened with its 10-12 fragment reads followed by s_waitcnt lgkmcnt(0): ~350 cycles per phase in which neither wave of the
@@ -787,6 +805,9 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, q = lane >> 4;
+#if D3D_X3_YOUNG_PRIO
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // (experiment: static priority for the later-dispatched SIMD partners)
+#endif
   // (a compile-time switch: with run-time ranges in the whole-tile path too, the whole GEMM ran 3.5 % slower)
   const bool w_act = !SUB || sub_wm < 0 || wm == sub_wm;          // wave-uniform
   const int gl = SUB ? (w_act ? g_lo : 0) : 0, gh = SUB ? (w_act ? g_hi : 0) : TM;
@@ -887,6 +908,121 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   // Measured (same box, experiments/ab_libs.sh, two alternations): qkv 1.122 -> 1.095 ms per launch, fc1 0.829 -> 0.830, proj 0.491 ->
   // 0.502 (its epilogue's residual loads then queue behind more staging in flight), whole-row fc2 0.841 -> 0.885: on for the two
   // forms without a residual read (D3D_X3_PIPE2=2 forces it everywhere, =0 nowhere -- experiments/build_variant.sh).
+#ifndef D3D_X3_YOUNG_PRIO
+#define D3D_X3_YOUNG_PRIO 0
+#endif
+#ifndef D3D_X3_HPSTAG
+#define D3D_X3_HPSTAG 0          // measured: qkv 1.10 -> 1.23 ms, fc1 0.84 -> 0.94 (+11 %): four barriers per k-tile cost more than the
+#endif                           // hidden k-tile openings give back (the MFMA work per barrier interval is the same for both rows)
+#ifndef D3D_X3_HPSTAG_ALL
+#define D3D_X3_HPSTAG_ALL 0      // 1: the forms with a residual read (proj) too
+#endif
+  if constexpr (D3D_X3_HPSTAG != 0 && PERSIST && !SUB && TM == 8 && WM == 2 && WN == 4 && (D3D_X3_HPSTAG_ALL || EPI != EPI_RESIDUAL)) {
+    // ---- Four steps per k-tile, the two wave rows ONE STEP APART (whole tiles of the persistent walk).  In-kernel stamps of the
+    // two-phase form (experiments/gemm_bench.py with a -DD3D_X3_PHASE_DIAG library) show where a phase loses its time: the two
+    // waves of a SIMD (w, w + 4) leave the barrier together, wait ~300 cycles for their first fragments together, then the OLDER
+    // wave wins every MFMA arbitration, finishes its 48 MFMAs in ~1200 cycles and sits at the barrier for ~700 while the younger
+    // one runs its last ~24 alone at ~20 cycles per MFMA (16 when the pipe is shared).  Here a k-tile is four steps of two m-tile
+    // groups (24 MFMAs per wave), every step opens with a counted vmcnt wait + workgroup barrier, and wave row 1 (waves 4-7, the
+    // SIMD partners of 0-3) runs one step BEHIND wave row 0: a wave opens its k-tile (8 W fragment reads + the first A pair, the
+    // only reads that cannot be requested across a barrier) while its partner is in the middle of one.
+    //   A operand: each wave row stages the 128 rows IT reads (pieces (w & 3) + 4 it of its band): A(t+1) in its own steps (t, 0),
+    //              (t, 1) -- the band's previous contents, A(t-1), were last read in its own step (t-1, 3);
+    //   W operand: all eight waves, W(t+2) in steps (t, 2), (t, 3) -- W(t) went to registers in step (t, 0) of either row;
+    //   waits:     vmcnt(pieces of this wave's last two steps): a piece has two to three steps (~2000 cycles) to land; in the
+    //              first k-tile of a tile (whose W(1) is staged late: its stage held the epilogue's patches) one step.
+    // Same MFMAs in the same order per output element as every other form.
+    auto wait_vm_ = [](int n) {
+      switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      }
+    };
+    static_assert(A_IT == 4 && B_IT == 4, "four A and four W pieces per wave and k-tile");
+    const int half = wm;                                                        // wave row = SIMD-partner half
+    const char* ubAh = reinterpret_cast<const char*>(Ap) + (size_t)(m0 + 128 * half + 8 * (wave & 3)) * K2_ * 2;
+    const char* ubAhn = reinterpret_cast<const char*>(Ap) + (size_t)(m0n + 128 * half + 8 * (wave & 3)) * K2_ * 2;
+    const size_t itA_ = (size_t)32 * K2_ * 2;                                   // bytes between this wave's A pieces (32 rows)
+    const int dstAh = (128 * half + 8 * (wave & 3)) * 128 + lane * 16;          // (+ 4096 per piece; the swizzle of lofs_ fits: piece parity = wave parity)
+#define D3D_HP_A(KTT, IT)                                                                                                 \
+    do {                                                                                                                  \
+      const char* b_ = ((KTT) >= nk) ? ubAhn + (IT) * itA_ : ubAh + ((size_t)(KTT) * 128 + (IT) * itA_);                   \
+      D3D_GLDS(sgpr_ptr(b_) + lofs_, ((KTT) & 1) * STAGE + dstAh + (IT) * 4096);                                          \
+    } while (0)
+#define D3D_HP_W(KTT, IT)                                                                                                 \
+    do {                                                                                                                  \
+      const char* b_ = ((KTT) >= nk) ? ubBn + (IT) * it_stride : ubB + ((size_t)(KTT) * 128 + (IT) * it_stride);           \
+      D3D_GLDS(sgpr_ptr(b_) + lofs_, ((KTT) & 1) * STAGE + dstB + (IT) * NW * 1024);                                      \
+    } while (0)
+    h8 bh[4], bl[4], ah[2], al[2];
+    int n1 = 0, n2 = 0;                                                          // pieces this wave issued in its last / last but one step
+    // one step: Q = 0..3, m-tile groups 2Q, 2Q+1
+#define D3D_HP(KT, Q, DO_A, DO_W1, DO_W, STRICT)                                                                          \
+    do {                                                                                                                  \
+      wait_vm_((STRICT) ? n1 : n1 + n2);                                                                                  \
+      __builtin_amdgcn_s_barrier();                                                                                       \
+      asm volatile("" : "+v"(lofs_) : : "memory");                                                                        \
+      const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                 \
+      if ((Q) == 0) {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+          bh[j] = *reinterpret_cast<const h8*>(sb + boff + j * 2048);                                                     \
+          bl[j] = *reinterpret_cast<const h8*>(sb + ((boff + j * 2048) ^ 64));                                            \
+        }                                                                                                                 \
+        ah[0] = *reinterpret_cast<const h8*>(sb + aoff);                                                                  \
+        al[0] = *reinterpret_cast<const h8*>(sb + (aoff ^ 64));                                                           \
+      }                                                                                                                   \
+      int issued_ = 0;                                                                                                    \
+      _Pragma("unroll") for (int g = 2 * (Q); g < 2 * (Q) + 2; ++g) {                                                     \
+        if (g + 1 < TM) {     /* the next group's A pair: across the step barrier too (A(KT) landed before step 0) */     \
+          ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                     \
+          al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                            \
+        }                                                                                                                 \
+        if ((Q) < 2) {                                                                                                    \
+          if (DO_A) { D3D_HP_A((KT) + 1, 2 * (Q) + (g & 1)); ++issued_; }                                                 \
+          if (DO_W1) { D3D_HP_W(1, 2 * (Q) + (g & 1)); ++issued_; }                                                       \
+        } else if (DO_W) {                                                                                                \
+          D3D_HP_W((KT) + 2, 2 * ((Q) - 2) + (g & 1));                                                                    \
+          ++issued_;                                                                                                      \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                       \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                       \
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                       \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+      }                                                                                                                   \
+      n2 = n1;                                                                                                            \
+      n1 = issued_;                                                                                                       \
+    } while (0)
+    if (half == 1) {      // wave row 1 sits out global step 0
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+      const bool do_a = (t + 1 < nk) || has_next;                       // A(t+1): of this tile, or k-tile 0 of the next one
+      const bool do_w = (t + 2 < nk) || (t + 2 == nk && has_next);      // W(t+2): of this tile, or W(0) of the next one (W(1) waits)
+      const bool first = t == 0;
+      D3D_HP(t, 0, do_a, first, false, first);
+      D3D_HP(t, 1, do_a, first, false, first);
+      D3D_HP(t, 2, false, false, do_w, first);
+      D3D_HP(t, 3, false, false, do_w, first);
+    }
+    if (half == 0) {      // wave row 0 sits out the last global step
+      wait_vm_(n1 + n2);
+      __builtin_amdgcn_s_barrier();
+    }
+#undef D3D_HP
+#undef D3D_HP_A
+#undef D3D_HP_W
+  } else
   if constexpr (PERSIST && TM % 2 == 0 && (D3D_X3_PIPE2 > 1 || (D3D_X3_PIPE2 == 1 && WM == 2 && EPI != EPI_RESIDUAL))) {
     // ---- Two phases per k-tile, staging two phases ahead (persistent walk).  A k-tile is split where its buffers die: the W
     // fragments go to registers at the top of the first phase, the A rows of m-tiles 0..TM/2-1 are read in the first phase, those
@@ -941,10 +1077,18 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     // W(1) in a tile's first phase, W_FULL1); odd phase: the W pieces 0..W_ODD-1 of W(KT+2) if DO_W.  W_ODD = B_IT where A and W
     // are the same size (256 x 256 tiles: 4 + 4 pieces per wave and k-tile), B_IT / 2 for the whole-row tiles (2 + 8).
     constexpr int W_ODD = (WM == 2) ? B_IT : B_IT / 2;
+#ifdef D3D_X3_PHASE_DIAG
+#define D3D_PSTAMP(KT, H, I) do { if (bid == 3 && (KT) == 5) pst_[H][I] = __builtin_amdgcn_s_memtime(); } while (0)
+    unsigned long long pst_[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+#else
+#define D3D_PSTAMP(KT, H, I) do { } while (0)
+#endif
 #define D3D_PHASE(KT, H, DO_A, W_FULL1, DO_W)                                                                             \
     do {                                                                                                                  \
+      D3D_PSTAMP(KT, H, 0);                                                                                               \
       wait_vm(issued_prev);                                                                                               \
       __builtin_amdgcn_s_barrier();                                                                                       \
+      D3D_PSTAMP(KT, H, 1);                                                                                               \
       asm volatile("" : "+v"(lofs_) : : "memory");                                                                        \
       const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                 \
       constexpr int G0 = (H) * (TM / 2), G1 = G0 + TM / 2;                                                                \
@@ -959,6 +1103,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
         ah[gf & 1] = *reinterpret_cast<const h8*>(sb + aoff + gf * 2048);                                                 \
         al[gf & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + gf * 2048) ^ 64));                                        \
       }                                                                                                                   \
+      D3D_PSTAMP(KT, H, 2);                                                                                               \
       _Pragma("unroll") for (int g = G0; g < G1; ++g) {                                                                   \
         const bool g_act = g >= gl && g < gh;                                                                             \
         if (g_act && g + 1 < gh && g + 1 < G1) {                                                                          \
@@ -993,6 +1138,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           }                                                                                                               \
         }                                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
+        D3D_PSTAMP(KT, H, 3 + (g - G0));                                                                                  \
       }                                                                                                                   \
       if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : ((DO_A) ? B_IT - W_ODD : 0));                   \
       else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
@@ -1008,8 +1154,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     const unsigned lds_u = (unsigned)(uintptr_t)lds;
 #define D3D_PHASE_A(KT, H, DO_A, W_FULL1, DO_W)                                                                           \
     do {                                                                                                                  \
+      D3D_PSTAMP(KT, H, 0);                                                                                               \
       wait_vm(issued_prev);                                                                                               \
       __builtin_amdgcn_s_barrier();                                                                                       \
+      D3D_PSTAMP(KT, H, 1);                                                                                               \
       asm volatile("" : "+v"(lofs_) : : "memory");                                                                        \
       const unsigned sb_ = lds_u + ((KT) & 1) * STAGE;                                                                    \
       const unsigned aH_ = sb_ + aoff, aL_ = sb_ + (aoff ^ 64), bH_ = sb_ + boff, bL_ = sb_ + (boff ^ 64);                \
@@ -1022,6 +1170,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           lds_rd128(bl[j], bL_ + j * 2048);                                                                               \
         }                                                                                                                 \
       }                                                                                                                   \
+      D3D_PSTAMP(KT, H, 2);                                                                                               \
       _Pragma("unroll") for (int g = G0; g < G1; ++g) {                                                                   \
         const bool pre_ = (g + 1 < G1) || ((H) == 0);       /* an A pair is requested for the next group */               \
         if (pre_) {                                                                                                       \
@@ -1059,6 +1208,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                       \
         }                                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
+        D3D_PSTAMP(KT, H, 3 + (g - G0));                                                                                  \
       }                                                                                                                   \
       if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : ((DO_A) ? B_IT - W_ODD : 0));                   \
       else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
@@ -1161,6 +1311,12 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     if constexpr (!SUB && D3D_X3_ASMREAD != 0) { D3D_SCHEDULE(D3D_PHASE_A); }
     else { D3D_SCHEDULE(D3D_PHASE); }
 #undef D3D_SCHEDULE
+#ifdef D3D_X3_PHASE_DIAG
+    if (bid == 3 && lane == 0 && nk > 5 && has_next) {
+      for (int hh = 0; hh < 2; ++hh)
+        for (int i = 0; i < 8; ++i) g_x3_phase_diag[(wave * 2 + hh) * 8 + i] = pst_[hh][i];
+    }
+#endif
     }
 #undef D3D_PHASE_A
 #undef D3D_PHASE
