@@ -1053,24 +1053,37 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
         case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
       }
     };
     const int nA = SUB ? __builtin_popcount(amask & ((1u << A_IT) - 1u)) : A_IT;   // A pieces this wave issues per k-tile
     int issued_prev = 0;                                                            // pieces this wave issued in the previous phase
     // piece `it` (A: 0..A_IT-1, W: A_IT..N_IT-1) of k-tile KTT of this tile (KTT < nk) or of k-tile 0 of the next one (KTT == nk)
+#ifndef D3D_X3_DMA_OLD4
+#define D3D_X3_DMA_OLD4 0   // 1 (whole tiles): waves 0-3 issue the staging pieces of their SIMD partners 4-7 as well (experiment)
+#endif
+    constexpr bool OLD4 = D3D_X3_DMA_OLD4 != 0 && !SUB && NW == 8;
+    const size_t half_rows_ = (size_t)32 * K2_ * 2;      // bytes between the pieces of waves w and w + 4 (32 rows)
 #define D3D_PIECE(KTT, IT)                                                                                               \
     do {                                                                                                                 \
       const bool nxt_ = (KTT) >= nk;                                                                                     \
       const int st_ = ((KTT) & 1) * STAGE;                                                                               \
-      if ((IT) < A_IT) {                                                                                                 \
-        if ((amask >> (IT)) & 1u) {                                                                                      \
-          const char* b_ = nxt_ ? ubAn + (IT) * it_stride : ubA + ((size_t)(KTT) * 128 + (IT) * it_stride);              \
-          D3D_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstA + (IT) * NW * 1024);                                                 \
+      if (!OLD4 || wave < 4) {                                                                                           \
+        if ((IT) < A_IT) {                                                                                               \
+          if ((amask >> (IT)) & 1u) {                                                                                    \
+            const char* b_ = nxt_ ? ubAn + (IT) * it_stride : ubA + ((size_t)(KTT) * 128 + (IT) * it_stride);            \
+            D3D_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstA + (IT) * NW * 1024);                                               \
+            if (OLD4) D3D_GLDS(sgpr_ptr(b_ + half_rows_) + lofs_, st_ + dstA + (IT) * NW * 1024 + 4096);                 \
+          }                                                                                                              \
+        } else {                                                                                                         \
+          const char* b_ = nxt_ ? ubBn + ((IT) - A_IT) * it_stride : ubB + ((size_t)(KTT) * 128 + ((IT) - A_IT) * it_stride); \
+          D3D_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstB + ((IT) - A_IT) * NW * 1024);                                        \
+          if (OLD4) D3D_GLDS(sgpr_ptr(b_ + half_rows_) + lofs_, st_ + dstB + ((IT) - A_IT) * NW * 1024 + 4096);          \
         }                                                                                                                \
-      } else {                                                                                                           \
-        const char* b_ = nxt_ ? ubBn + ((IT) - A_IT) * it_stride : ubB + ((size_t)(KTT) * 128 + ((IT) - A_IT) * it_stride); \
-        D3D_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstB + ((IT) - A_IT) * NW * 1024);                                          \
       }                                                                                                                  \
     } while (0)
     // one phase: H = 0 / 1.  Even phase (H = 0) of k-tile KT: A(KT+1) and the W pieces W_ODD..B_IT-1 of W(KT+1) if DO_A (all of
@@ -1142,6 +1155,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       }                                                                                                                   \
       if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : ((DO_A) ? B_IT - W_ODD : 0));                   \
       else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
+      if (OLD4) issued_prev = wave < 4 ? 2 * issued_prev : 0;                                                             \
     } while (0)
 #ifndef D3D_X3_ASMREAD
 #define D3D_X3_ASMREAD 0   // measured (same box, 3 alternations): qkv 1.136 -> 1.145 ms, fc1 0.875 -> 0.878: no gain -- the ~350 cycles behind
@@ -1212,6 +1226,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       }                                                                                                                   \
       if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : ((DO_A) ? B_IT - W_ODD : 0));                   \
       else issued_prev = (DO_W) ? W_ODD : 0;                                                                              \
+      if (OLD4) issued_prev = wave < 4 ? 2 * issued_prev : 0;                                                             \
     } while (0)
     h8 bh[4], bl[4], ah[2], al[2];
 #ifndef D3D_X3_STAGGER
