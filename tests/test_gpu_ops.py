@@ -173,6 +173,30 @@ def test_attention_core(B, T, J, D, H, temporal, generic):
         assert maxabs(out3, ref.cpu()) < 5e-6
 
 
+@pytest.mark.parametrize("B,T,J,temporal", [(8, 243, 17, True), (8, 256, 17, True), (8, 230, 17, True), (24, 81, 17, True),
+                                            (3, 243, 17, False), (9, 81, 17, False)])
+def test_attention_persistent_kernels(B, T, J, temporal):
+    """The forms only large launches take -- the staggered persistent temporal kernel (k_attn_temporal_x3s: >= 1024 units and 8
+    key tiles, here with 13, 0 and 26 pad rows in the last tile), the persistent 3-tile kernel (T = 81) and the wave-private
+    persistent spatial kernel (>= 4096 units) -- against fp64 math on a sample of rows, and bit for bit against the same rows
+    computed as a small launch (the non-persistent kernels the other tests cover)."""
+    E = _eng()
+    D, H = 512, 8
+    qkv = hashed(f"pers{T}_{B}_{int(temporal)}", (B * T * J, 3 * D), 23, 2.0).cuda()
+    if not temporal:     # the engine runs spatial blocks as groups of J consecutive tokens: B*T groups of length J, stride 1
+        B, T, J = B * T, J, 1
+    out = E.op_attention(qkv, B, T, J, H, True, precision="f16x3")
+    n1 = (1 if T > 32 else 8) * T * J                       # a launch small enough for the non-persistent kernels
+    b1 = n1 // (T * J)
+    one = slice(0, n1)
+    ref = _attn_ref(qkv[one], b1, T, J, H, True)
+    assert maxabs(out[one], ref.cpu()) < 5e-6
+    small = E.op_attention(qkv[one].contiguous(), b1, T, J, H, True, precision="f16x3")
+    assert torch.equal(out[one], small)
+    last = slice(B * T * J - n1, B * T * J)
+    assert torch.equal(out[last], E.op_attention(qkv[last].contiguous(), b1, T, J, H, True, precision="f16x3"))
+
+
 def test_attention_fast_kernels_agree_with_generic_on_sharp_softmax():
     """Large logits (|s| up to ~100, near one-hot softmax) exercise the max-subtraction and the -inf key mask.
     fp32 logits carry ~3e-5 absolute error at this scale (64-term dots of products up to 81), which exp() turns into a
