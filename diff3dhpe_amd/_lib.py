@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "d3d_last_error", "d3d_version", "d3d_engine_create", "d3d_engine_destroy", "d3d_engine_num_weights",
     "d3d_engine_weight_info", "d3d_engine_set_weight", "d3d_engine_set_time_freqs", "d3d_engine_commit_weights",
     "d3d_engine_set_schedule", "d3d_engine_set_sqrt_alphas_cumprod", "d3d_ddim_times", "d3d_workspace_bytes",
-    "d3d_denoise", "d3d_ddim_sample", "d3d_q_sample", "d3d_tta_mpjpe", "d3d_op_linear", "d3d_op_layernorm",
+    "d3d_denoise", "d3d_ddim_sample", "d3d_q_sample", "d3d_tta_mpjpe", "d3d_allgather_pred", "d3d_op_linear", "d3d_op_layernorm",
     "d3d_op_attention", "d3d_op_time_embedding", "d3d_engine_set_profiling", "d3d_engine_profile_reset",
     "d3d_engine_profile_read", "d3d_kernel_class_name", "d3d_op_linear_bench", "d3d_op_linear_postnorm", "d3d_engine_set_graph_mode", "d3d_num_windows", "d3d_window_gather",
     "d3d_engine_set_trace", "d3d_engine_trace_read", "d3d_engine_range_flags", "d3d_op_head",
@@ -57,6 +57,7 @@ def _bind(lib: C.CDLL) -> None:
         "d3d_denoise": (C.c_int, [vp, vp, vp, i32, vp, i32, vp, i32, vp, sz, vp]),
         "d3d_ddim_sample": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
         "d3d_q_sample": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, vp]),
+        "d3d_allgather_pred": (C.c_int, [vp, vp, vp, i64, vp]),
         "d3d_tta_mpjpe": (C.c_int, [vp, vp, vp, vp, f32, C.POINTER(i32), C.POINTER(i32), i32, vp, vp, i32, i32, i32, vp]),
         "d3d_engine_set_profiling": (C.c_int, [vp, i32]),
         "d3d_engine_set_graph_mode": (C.c_int, [vp, i32]),

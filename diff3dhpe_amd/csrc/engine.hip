@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -944,6 +945,25 @@ int d3d_engine_set_sqrt_alphas_cumprod(d3d_engine* e, const float* host, int32_t
   HIP_TRY(hipMalloc(&e->sqrt_ac_dev, n * sizeof(float)));
   HIP_TRY(hipMemcpy(e->sqrt_ac_dev, host, n * sizeof(float), hipMemcpyHostToDevice));
   e->has_sqrt_ac = true;
+  return D3D_OK;
+}
+
+int d3d_allgather_pred(void* nccl_comm, const float* send, float* recv, int64_t count_per_rank, void* stream) {
+  if (!nccl_comm || !send || !recv || count_per_rank <= 0) return fail(D3D_EINVAL, "bad argument");
+  // ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t)
+  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+  static allgather_fn fn = []() -> allgather_fn {
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+      if (sym) break;
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) sym = dlsym(h, "ncclAllGather");   // only a library the process already holds
+    }
+    return reinterpret_cast<allgather_fn>(sym);
+  }();
+  if (!fn) return fail(D3D_EUNSUP, "no RCCL library is loaded in this process (ncclAllGather not found)");
+  constexpr int NCCL_FLOAT32 = 7;   // ncclDataType_t: ncclFloat32 (rccl.h)
+  const int rc = fn(send, recv, (size_t)count_per_rank, NCCL_FLOAT32, nccl_comm, reinterpret_cast<hipStream_t>(stream));
+  if (rc != 0) return fail(D3D_EHIP, "ncclAllGather failed");
   return D3D_OK;
 }
 

@@ -130,6 +130,13 @@ int d3d_tta_mpjpe(const float* pred_dev, const float* pred_flip_dev, const float
                   float scale, const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr,
                   float* merged_dev, double* sums_dev, int32_t B, int32_t T, int32_t J, void* stream);
 
+/* The path's one exchange step (RUN:216-218: nn.DataParallel's gather of the replicas' outputs) for hosts that do not go through
+ * torch.distributed: all-gather of count_per_rank fp32 values (the rank's predicted sequences) over an RCCL communicator the
+ * CALLER owns (nccl_comm: ncclComm_t), asynchronous on `stream`; recv_dev holds world_size * count_per_rank values in rank
+ * order.  libd3d_hip.so does not link RCCL: ncclAllGather is resolved at run time from the RCCL library already loaded into the
+ * process (D3D_EUNSUP if there is none).  The Python host uses torch.distributed instead (parallel.all_gather_pred). */
+int d3d_allgather_pred(void* nccl_comm, const float* send_dev, float* recv_dev, int64_t count_per_rank, void* stream);
+
 /* Evaluation windows of one whole sequence, on the device: ChunkedGenerator(out_all=True, pad=0) (common/nosiy_generators.py:27-48
  * window table, :247-276 slicing, edge padding, target_mask, horizontal flip).  seq (n_frames, J, C) -> out
  * (d3d_num_windows, T, J, C); mask (nullable) (windows, T) uint8, 0 for the frames of the shifted last window that its

@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol():
     assert L.d3d_version() >= 100
 
 
+def test_allgather_entry_rejects_bad_arguments_without_touching_rccl():
+    """d3d_allgather_pred (RUN:216-218 exchange for non-torch hosts): argument checks come first, no collective is attempted."""
+    L = _lib.lib()
+    assert L.d3d_allgather_pred(None, None, None, 0, None) == -1       # D3D_EINVAL
+    assert b"bad argument" in L.d3d_last_error()
+
+
 def test_ddim_times_bit_exact_for_every_S():
     g = gold("ddim_times_N1000")
     flat, offs = g["flat"], g["offsets"]

@@ -605,3 +605,39 @@ def test_bench_graph_flag_times_the_main_leg_under_replay():
     assert graph["mpjpe_vs_synthetic_gt"] == eager["mpjpe_vs_synthetic_gt"]
     assert graph["selfcheck_batch_vs_pair_bit_identical"] and graph["roofline"]["frac"] > 0
     assert graph["roofline"]["kernel"].startswith("whole path")
+
+
+def test_c_abi_allgather_on_a_one_rank_rccl_communicator():
+    """d3d_allgather_pred over a communicator made with RCCL's own C API (ncclGetUniqueId / ncclCommInitRank, world size 1) from
+    the RCCL library torch has loaded: the entry resolves ncclAllGather at run time and the gathered buffer equals the send
+    buffer.  Runs in a child process (a communicator beside torch's own state is nothing to leave behind in the test process)."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent("""
+        import ctypes as C, glob, os, sys, torch
+        sys.path.insert(0, %r)
+        from diff3dhpe_amd import _lib
+        torch.cuda.init(); torch.cuda.set_device(0)
+        cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so"]
+        R = C.CDLL(cands[0], mode=C.RTLD_GLOBAL)
+        class UID(C.Structure):
+            _fields_ = [("b", C.c_char * 128)]
+        uid = UID()
+        assert R.ncclGetUniqueId(C.byref(uid)) == 0
+        comm = C.c_void_p()
+        R.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+        assert R.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+        x = torch.randn(4, 27, 17, 3, device="cuda")
+        y = torch.zeros_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().d3d_allgather_pred(comm, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), x.numel(), C.c_void_p(st))
+        torch.cuda.synchronize()
+        assert rc == 0, _lib.lib().d3d_last_error()
+        assert torch.equal(x, y)
+        R.ncclCommDestroy.argtypes = [C.c_void_p]
+        R.ncclCommDestroy(comm)
+        print("allgather ok")
+    """ % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert run.returncode == 0 and "allgather ok" in run.stdout, run.stderr[-2000:]
