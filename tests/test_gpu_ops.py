@@ -275,3 +275,22 @@ def test_block_golden(tag, D, shape, prec):
     if prec == "f16x3" and D == 512:      # the fused form the engine runs: fc2 + post-norm in one GEMM epilogue
         y, _, _ = E.op_linear_postnorm(hid, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"], x2, sd[post + ".weight"], sd[post + ".bias"], 1e-6)
         assert maxabs(y.reshape(shape), g[tag + "/postnorm"]) < 2e-5, tag
+
+
+@pytest.mark.parametrize("rows", [1, 33, 4131, 40000])
+def test_head_kernel(rows):
+    """k_head (S2S:217-220: LayerNorm eps 1e-5 + Linear D -> 3) on its own, through d3d_op_head: against fp64 math, for row counts
+    below, at and far above the 32 rows a workgroup owns, and twice in a row bit for bit."""
+    from diff3dhpe_amd.engine import Engine
+    cfg = DenoiserConfig(num_frame=27, embed_dim=512, depth=2)
+    sd = torch_sd(cfg, 11)
+    eng = Engine(cfg, precision="f16x3")
+    eng.load_weights(sd)
+    X = hashed(f"head{rows}", (rows, 512), 12, 1.7).cuda() + 0.3
+    out = eng.head(X)
+    g, b = sd["head.0.weight"].double().cuda(), sd["head.0.bias"].double().cuda()
+    W, c = sd["head.1.weight"].double().cuda(), sd["head.1.bias"].double().cuda()
+    xd = X.double()
+    ref = ((xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5) * g + b) @ W.t() + c
+    assert maxabs(out, ref.cpu()) < 3e-6
+    assert torch.equal(out, eng.head(X))
