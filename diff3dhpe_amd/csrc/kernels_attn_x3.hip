@@ -37,6 +37,10 @@ __device__ __forceinline__ int vkey(int row) { return (((row >> 1) & 1) << 2) ^ 
 __device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ vkey(row)) << 4); }
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// the output patches are written as fp16 quads and read back as 16-byte words: through may_alias types, or type-based alias
+// analysis is free to move the read-back above the writes (it did, in the four-pass form of the T = 81 kernel)
+typedef _Float16 h4_alias __attribute__((ext_vector_type(4), may_alias));
+typedef unsigned u32x4_alias __attribute__((ext_vector_type(4), may_alias));
 
 // F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = an output clamp fired
 __device__ unsigned g_range_attn;
@@ -373,6 +377,9 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   // row) and leave as whole lines, 16 B per lane, 8 lanes per row: 6 store instructions per unit instead of 16 that each wrote
   // 16-byte pieces of 17 different lines (this kernel is bound by the rate at which a wave gets memory instructions through)
   unsigned char* const patch = lds_all + MU * NPL * PL + (TP - T) * 128 + (int)(threadIdx.x >> 6) * 4096;
+  // !WAVEP (T = 81: three workgroups per CU, LDS is what limits them): a 1 KiB patch per wave (8 rows), four passes per line
+  unsigned char* const patch1 = lds_all + 4 * PLANE + (int)(threadIdx.x >> 6) * 1024;
+  u32x4 pq[8];                  // [dt * 4 + p]: row 32 wave + 8 p + (lane >> 3), chunk lane & 7 of line dt
   u32x4 pw[6];                  // [dt * 3 + it]: row 8 it + (lane >> 3), chunk lane & 7 of line dt
   _Float16* pw_ptr = out_x3;    // row (lane >> 3), this lane's chunk of line 0 (row 8 it: + it * pw_stride)
   const size_t pw_stride = (size_t)8 * J * 2 * D;
@@ -392,14 +399,12 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
             for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * 3 + it];
           }
       }
-    } else if (po_valid && tq < T) {
+    } else if (po_valid) {
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int pp = 0; pp < 4; ++pp)
+        if (32 * wave + 8 * pp + (lane >> 3) < T) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int d = dt * 32 + 8 * g4 + 4 * h;
-          *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d)) = po_h[dt * 4 + g4];
-          *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d) + PAIR_LO) = po_l[dt * 4 + g4];
+          for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + pp * pw_stride + dt * 64) = pq[dt * 4 + pp];
         }
     }
 
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
       const int tqc = tq < T ? tq : 0;
       float amax = 0.0f;   // range guard (rows tq >= T are never stored)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int vo = vswz(tqc, dt * 4 + g4) + 8 * h;
@@ -524,23 +529,43 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
           }
           if (WAVEP) {   // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout)
             const int sw = (r >> 1) & 7;
-            *reinterpret_cast<h4*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
-            *reinterpret_cast<h4*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
+            *reinterpret_cast<h4_alias*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
+            *reinterpret_cast<h4_alias*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
             if (g4 == 3) {
+              asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
 #pragma unroll
               for (int it = 0; it < 3; ++it) {
                 const int row = 8 * it + (lane >> 3);
-                pw[dt * 3 + it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+                pw[dt * 3 + it] = *reinterpret_cast<const u32x4_alias*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
               }
             }
           } else {
-            po_h[dt * 4 + g4] = oh;
-            po_l[dt * 4 + g4] = ol;
+            po_h[g4] = oh;       // (this line's four column groups, transposed below)
+            po_l[g4] = ol;
           }
         }
+        if (!WAVEP) {      // 8 rows at a time through the 1 KiB patch: rows 8 pp .. 8 pp + 7 of this wave's 32, written by their own lanes
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) {
+            if ((r >> 3) == pp) {
+              const int rr = r & 7, sw = (rr >> 1) & 3;
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4) {
+                *reinterpret_cast<h4_alias*>(patch1 + rr * 128 + ((g4 ^ sw) << 4) + 8 * h) = po_h[g4];
+                *reinterpret_cast<h4_alias*>(patch1 + rr * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = po_l[g4];
+              }
+            }
+            // other lanes' writes are read below: a compiler-level barrier, or the read of a lane that did not write in this
+            // pass is "optimised" into the value it read in the previous one (single-thread reasoning: it was)
+            asm volatile("" ::: "memory");
+            const int row = lane >> 3;
+            pq[dt * 4 + pp] = *reinterpret_cast<const u32x4_alias*>(patch1 + row * 128 + (((lane & 7) ^ ((row >> 1) & 3)) << 4));
+          }
+        }
+      }
       if (tq < T && amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
       po_off = (tok0 + (size_t)tqc * J) * 2 * D + hd * 2 * XDH;
-      if (WAVEP) pw_ptr = out_x3 + (tok0 + (size_t)(lane >> 3) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
+      pw_ptr = out_x3 + (tok0 + (size_t)((WAVEP ? 0 : 32 * wave) + (lane >> 3)) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
       po_valid = true;
     }
     if (!has_next) break;
@@ -560,14 +585,12 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * 3 + it];
       }
-  } else if (tq < T) {
+  } else {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int pp = 0; pp < 4; ++pp)
+      if (32 * wave + 8 * pp + (lane >> 3) < T) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int d = dt * 32 + 8 * g4 + 4 * h;
-        *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d)) = po_h[dt * 4 + g4];
-        *reinterpret_cast<h4*>(out_x3 + po_off + pair_col(d) + PAIR_LO) = po_l[dt * 4 + g4];
+        for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + pp * pw_stride + dt * 64) = pq[dt * 4 + pp];
       }
   }
 }
@@ -917,13 +940,14 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
           }
           // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout), 8 h bytes in
           const int sw = (r >> 1) & 7;
-          *reinterpret_cast<h4*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
-          *reinterpret_cast<h4*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
+          *reinterpret_cast<h4_alias*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
+          *reinterpret_cast<h4_alias*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
         }
+        asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int row = 8 * it + (lane >> 3);
-          po[dt * 4 + it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+          po[dt * 4 + it] = *reinterpret_cast<const u32x4_alias*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
         }
       }
       if (tq < T && amax > X3_HALF_MAX) atomicOr(&g_range_attn, 1u);
@@ -998,7 +1022,7 @@ template <int NKT, int MU = 1>
 static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H,
                                  hipStream_t s) {
   // wave-private units (MU > 1, NKT == 1): 6 planes of T rows per wave (V double-buffered) + one zeroed pad behind the last
-  const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 + (size_t)MU * 4096 : (size_t)4 * 32 * NKT * 128;
+  const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 + (size_t)MU * 4096 : (size_t)4 * 32 * NKT * 128 + (size_t)NKT * 1024;
   static std::atomic<unsigned long long> attr_set{0};   // one bit per device
   if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU>), MU > 1 ? (size_t)160 * 1024 : lds_bytes,
                                attr_set))
