@@ -124,6 +124,14 @@ void x3_phase_diag_report() {
 #endif
 }
 
+// Between a wave's writes to its LDS patch and its reads of OTHER lanes' rows of it: nothing orders them for the compiler (one
+// thread's load does not alias its own stores), LDS itself executes a wave's operations in order.  A compiler-level barrier.
+#ifndef D3D_NO_PATCH_FENCE
+#define D3D_PATCH_FENCE() asm volatile("" ::: "memory")
+#else
+#define D3D_PATCH_FENCE() do { } while (0)
+#endif
+
 // LDS fragment read as inline asm: the compiler does not know it as an LDS operation and inserts no s_waitcnt for it -- the
 // k-loop places COUNTED lgkmcnt waits itself (LDS operations of one wave return in order).  Left to the compiler, every phase
 // opened with its 10-12 fragment reads followed by s_waitcnt lgkmcnt(0): ~350 cycles per phase in which neither wave of the
@@ -321,6 +329,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    D3D_PATCH_FENCE();   // the strip is read back transposed: other lanes' rows
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = rrow + 4 * p;
@@ -449,6 +458,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    D3D_PATCH_FENCE();   // the strip is read back transposed: other lanes' rows
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = rrow + 8 * p;
@@ -637,6 +647,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    D3D_PATCH_FENCE();   // the strip is read back transposed: other lanes' rows
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = rrow + 8 * p;
