@@ -909,6 +909,17 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
         }                                                                                                                \
       }                                                                                                                  \
+      if (D3D_X3_SGBQ && !SUB) {                                                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                               \
+      }                                                                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }                                                                                                                    \
   } while (0)
@@ -921,6 +932,17 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   // forms without a residual read (D3D_X3_PIPE2=2 forces it everywhere, =0 nowhere -- experiments/build_variant.sh).
 #ifndef D3D_X3_YOUNG_PRIO
 #define D3D_X3_YOUNG_PRIO 0
+#endif
+// Instruction order inside an m-tile group (12 MFMAs, the next group's two A-fragment reads, 1-4 staging pieces), stated with
+// sched_group_barrier: 2 MFMAs, a read, 2 MFMAs, a read, 2 MFMAs, a piece, 2 MFMAs, the other pieces, 4 MFMAs.  Left alone the
+// scheduler puts the reads and the pieces at the top of the group and the 12 MFMAs behind them.  Same-box A/B (two alternations
+// each): qkv 1.110 -> 1.084 ms, fc1 0.849 -> 0.830, fc2 + post-norm 0.851 -> 0.827, proj unchanged; patterns with the reads at
+// the top and only the pieces spread (10), coarser ones (1, 3, 4, 7) or single MFMAs between the reads (5) gain less or nothing.
+#ifndef D3D_X3_SGB
+#define D3D_X3_SGB 2      // two-phase k-loop (qkv, fc1)
+#endif
+#ifndef D3D_X3_SGBQ
+#define D3D_X3_SGBQ 1     // one-barrier k-loop (proj, fc2 + post-norm)
 #endif
 #ifndef D3D_X3_HPSTAG
 #define D3D_X3_HPSTAG 0          // measured: qkv 1.10 -> 1.23 ms, fc1 0.84 -> 0.94 (+11 %): four barriers per k-tile cost more than the
@@ -1160,6 +1182,89 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
             acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
             acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
           }                                                                                                               \
+        }                                                                                                                 \
+        if (D3D_X3_SGB == 1 && !SUB) {   /* 4 MFMAs, the A-pair reads, 4 MFMAs, the staging pieces, 4 MFMAs */             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+        } else if (D3D_X3_SGB == 2 && !SUB) {   /* finer: 2 MFMAs between single reads / pieces */                         \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+        } else if (D3D_X3_SGB == 5 && !SUB) {                                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                              \
+        } else if (D3D_X3_SGB == 6 && !SUB) {                                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+        } else if (D3D_X3_SGB == 7 && !SUB) {                                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+        } else if (D3D_X3_SGB == 8 && !SUB) {                                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+        } else if (D3D_X3_SGB == 9 && !SUB) {                                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+        } else if (D3D_X3_SGB == 10 && !SUB) {                                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                              \
+        } else if (D3D_X3_SGB == 3 && !SUB) {   /* 6 MFMAs, reads and pieces, 6 MFMAs */                                   \
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                              \
+        } else if (D3D_X3_SGB == 4 && !SUB) {   /* 8 MFMAs first, then reads, pieces, 4 MFMAs */                           \
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
         }                                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
         D3D_PSTAMP(KT, H, 3 + (g - G0));                                                                                  \
