@@ -927,9 +927,9 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
 #ifndef D3D_X3_PIPE2
 #define D3D_X3_PIPE2 1
 #endif
-  // Measured (same box, experiments/ab_libs.sh, two alternations): qkv 1.122 -> 1.095 ms per launch, fc1 0.829 -> 0.830, proj 0.491 ->
-  // 0.502 (its epilogue's residual loads then queue behind more staging in flight), whole-row fc2 0.841 -> 0.885: on for the two
-  // forms without a residual read (D3D_X3_PIPE2=2 forces it everywhere, =0 nowhere -- experiments/build_variant.sh).
+  // Measured (same box, experiments/ab_libs.sh, two alternations): qkv 1.122 -> 1.095 ms per launch, fc1 0.829 -> 0.830; proj 0.491 ->
+  // 0.502 before the group order was stated (D3D_X3_SGB), 0.497 -> 0.492 with it; whole-row fc2 0.826 -> 0.889 (8 W pieces per wave
+  // and phase): on for the 256 x 256 forms (D3D_X3_PIPE2=2 forces it everywhere, =0 nowhere -- experiments/build_variant.sh).
 #ifndef D3D_X3_YOUNG_PRIO
 #define D3D_X3_YOUNG_PRIO 0
 #endif
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
 #undef D3D_HP_A
 #undef D3D_HP_W
   } else
-  if constexpr (PERSIST && TM % 2 == 0 && (D3D_X3_PIPE2 > 1 || (D3D_X3_PIPE2 == 1 && WM == 2 && EPI != EPI_RESIDUAL))) {
+  if constexpr (PERSIST && TM % 2 == 0 && (D3D_X3_PIPE2 > 1 || (D3D_X3_PIPE2 == 1 && WM == 2))) {
     // ---- Two phases per k-tile, staging two phases ahead (persistent walk).  A k-tile is split where its buffers die: the W
     // fragments go to registers at the top of the first phase, the A rows of m-tiles 0..TM/2-1 are read in the first phase, those
     // of TM/2..TM-1 in the second.  So the pieces of a LATER k-tile can be issued into a stage while its other half is still read:
@@ -1255,6 +1255,38 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                              \
+        } else if (D3D_X3_SGB == 11 && !SUB) {                                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+        } else if (D3D_X3_SGB == 12 && !SUB) {                                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+        } else if (D3D_X3_SGB == 13 && !SUB) {                                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
         } else if (D3D_X3_SGB == 3 && !SUB) {   /* 6 MFMAs, reads and pieces, 6 MFMAs */                                   \
           __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
