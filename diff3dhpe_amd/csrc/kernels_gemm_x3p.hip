@@ -939,7 +939,8 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
 // each): qkv 1.110 -> 1.084 ms, fc1 0.849 -> 0.830, fc2 + post-norm 0.851 -> 0.827, proj unchanged; patterns with the reads at
 // the top and only the pieces spread (10), coarser ones (1, 3, 4, 7) or single MFMAs between the reads (5) gain less or nothing.
 #ifndef D3D_X3_SGB
-#define D3D_X3_SGB 2      // two-phase k-loop (qkv, fc1)
+#define D3D_X3_SGB 14     // two-phase k-loop (qkv, proj, fc1): 2 = the pattern above in every group; 14 = also the k-tile opening group stated
+                          // (A pair + first W pair, then a W pair ahead of each MFMA triple): proj 0.483 -> 0.479, fc1 0.823 -> 0.818
 #endif
 #ifndef D3D_X3_SGBQ
 #define D3D_X3_SGBQ 1     // one-barrier k-loop (proj, fc2 + post-norm)
@@ -1138,16 +1139,16 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       asm volatile("" : "+v"(lofs_) : : "memory");                                                                        \
       const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                 \
       constexpr int G0 = (H) * (TM / 2), G1 = G0 + TM / 2;                                                                \
+      const int gf = gl > G0 ? gl : G0;                     /* first active m-tile of this phase */                       \
+      if (gf < gh && gf < G1) {                                                                                           \
+        ah[gf & 1] = *reinterpret_cast<const h8*>(sb + aoff + gf * 2048);                                                 \
+        al[gf & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + gf * 2048) ^ 64));                                        \
+      }                                                                                                                   \
       if ((H) == 0) {                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
           bh[j] = *reinterpret_cast<const h8*>(sb + boff + j * 2048);                                                     \
           bl[j] = *reinterpret_cast<const h8*>(sb + ((boff + j * 2048) ^ 64));                                            \
         }                                                                                                                 \
-      }                                                                                                                   \
-      const int gf = gl > G0 ? gl : G0;                     /* first active m-tile of this phase */                       \
-      if (gf < gh && gf < G1) {                                                                                           \
-        ah[gf & 1] = *reinterpret_cast<const h8*>(sb + aoff + gf * 2048);                                                 \
-        al[gf & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + gf * 2048) ^ 64));                                        \
       }                                                                                                                   \
       D3D_PSTAMP(KT, H, 2);                                                                                               \
       _Pragma("unroll") for (int g = G0; g < G1; ++g) {                                                                   \
@@ -1183,7 +1184,28 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
             acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
           }                                                                                                               \
         }                                                                                                                 \
-        if (D3D_X3_SGB == 1 && !SUB) {   /* 4 MFMAs, the A-pair reads, 4 MFMAs, the staging pieces, 4 MFMAs */             \
+        if (D3D_X3_SGB == 14 && !SUB && (H) == 0 && g == G0) {   /* the k-tile opening: fragments just ahead of their MFMAs */\
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                              \
+        } else if ((D3D_X3_SGB == 2 || D3D_X3_SGB == 14) && !SUB) {                                                       \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
+        } else if (D3D_X3_SGB == 1 && !SUB) {   /* 4 MFMAs, the A-pair reads, 4 MFMAs, the staging pieces, 4 MFMAs */     \
           __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                              \
