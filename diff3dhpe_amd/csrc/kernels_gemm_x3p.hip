@@ -881,12 +881,12 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     const int nst = ((KT) + 1) & 1;                                                                                      \
     const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                  \
     h8 bh[4], bl[4], ah[2], al[2];                                                                                       \
+    ah[0] = *reinterpret_cast<const h8*>(sb + aoff + gl * 2048);                                                         \
+    al[0] = *reinterpret_cast<const h8*>(sb + ((aoff + gl * 2048) ^ 64));                                                \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
       bh[j] = *reinterpret_cast<const h8*>(sb + boff + j * 2048);                                                        \
       bl[j] = *reinterpret_cast<const h8*>(sb + ((boff + j * 2048) ^ 64));                                               \
     }                                                                                                                    \
-    ah[0] = *reinterpret_cast<const h8*>(sb + aoff + gl * 2048);                                                         \
-    al[0] = *reinterpret_cast<const h8*>(sb + ((aoff + gl * 2048) ^ 64));                                                \
     _Pragma("unroll") for (int g = 0; g < TM; ++g) {                                                                     \
       const bool g_act = g >= gl && g < gh;                                                                              \
       if (g_act && g + 1 < gh) {                                                                                         \
@@ -909,7 +909,18 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
         }                                                                                                                \
       }                                                                                                                  \
-      if (D3D_X3_SGBQ && !SUB) {                                                                                         \
+      if (D3D_X3_SGBQ == 2 && !SUB && g == 0) {   /* the k-tile opening (see D3D_X3_SGB 14) */                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                               \
+      } else if (D3D_X3_SGBQ && !SUB) {                                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                               \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                               \
@@ -943,7 +954,8 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
                           // (A pair + first W pair, then a W pair ahead of each MFMA triple): proj 0.483 -> 0.479, fc1 0.823 -> 0.818
 #endif
 #ifndef D3D_X3_SGBQ
-#define D3D_X3_SGBQ 1     // one-barrier k-loop (proj, fc2 + post-norm)
+#define D3D_X3_SGBQ 2     // one-barrier k-loop (fc2 + post-norm; tail slices keep the scheduler's order): 1 = the pattern in every group, 2 = the
+                          // k-tile opening group stated as well (fc2 0.838 -> 0.816 ms)
 #endif
 #ifndef D3D_X3_HPSTAG
 #define D3D_X3_HPSTAG 0          // measured: qkv 1.10 -> 1.23 ms, fc1 0.84 -> 0.94 (+11 %): four barriers per k-tile cost more than the
