@@ -9,9 +9,10 @@ B=64 sequences per GPU (weak scaling: the 8-GPU run is the full B=512 of that co
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` (dominant kernel class, timed
-live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = a port of the reference's op
-sequence, timed on this node's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement).  The timed region runs the engine exactly as a user gets
+it (per-kernel event timing OFF; `headline_under` names the launch mode: eager / graph / 2-stream); `roofline` comes from a
+separate profiled pass right after it (same batch, ONE stream, HIP events around every kernel on the launch stream), and
+`cpu_baseline` is the CPU oracle (a port of the reference's op sequence) timed on this node's host cores on a bounded sample.
 """
 import argparse
 import json
@@ -114,13 +115,21 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) / n, r
 
-    te, ye = timed(lambda: eng.ddim_sample(x2d, noise))
-    eng.set_graph_mode(True)
-    tg, yg = timed(lambda: eng.ddim_sample(x2d, noise))
+    modes, ref, same = {}, None, True
+    for name, st, gr in (("eager_1stream", 1, False), ("eager_2stream", 2, False), ("graph_1stream", 1, True), ("graph_2stream", 2, True)):
+        eng.set_option("streams", st)
+        eng.set_graph_mode(gr)
+        t, y = timed(lambda: eng.ddim_sample(x2d, noise))
+        modes[name] = round(t * 1e3, 3)
+        ref = y if ref is None else ref
+        same = same and bool(torch.equal(y, ref))
     eng.set_graph_mode(False)
-    out["graph_vs_eager"] = {"eager_ms": round(te * 1e3, 3), "graph_ms": round(tg * 1e3, 3), "graph_over_eager": round(tg / te, 4),
-                             "bit_identical": bool(torch.equal(ye, yg)),
-                             "note": "whole S-step loop captured once per (B, workspace), replayed with one hipGraphLaunch; profiling off in both"}
+    eng.set_option("streams", a.streams)
+    out["launch_modes"] = {"ms_per_sampling": modes, "bit_identical_across_modes": same,
+                           "note": "the same sampling (profiling off) as eager launches / as ONE hipGraph replay of the whole S-step loop "
+                                   "(d3d_engine_set_graph_mode), on one stream / as two half-batches on two streams (\"streams\" option)"}
+    out["graph_vs_eager"] = {"eager_ms": modes["eager_1stream"], "graph_ms": modes["graph_1stream"],
+                             "graph_over_eager": round(modes["graph_1stream"] / modes["eager_1stream"], 4), "bit_identical": same}
     batch = {"inputs_2d": x2d, "inputs_3d": gt[:x2d.shape[0]], "init_noise": noise, "init_noise_flip": noise}
     tv, res = timed(lambda: evaluate(diff, [batch], scale=1.0, device=dev, verbose=False), n=1)
     out["evaluate_equiv_frames_per_s"] = {"value": round(Bl * T / tv, 1), "unit": "frames/s", "windows_per_s": round(Bl / tv, 3),
@@ -147,8 +156,15 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
     ap.add_argument("--frames", type=int, default=243)
     ap.add_argument("--sampling", type=int, default=9)
-    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"],
-                    help="f16x3: fp32-accurate GEMMs from 3 fp16 MFMAs (default; passes the same 1e-4 parity gate); fp32: fp32 MFMA")
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "bf16"],
+                    help="f16x3: fp32-accurate GEMMs from 3 fp16 MFMAs (default; passes the same 1e-4 parity gate); fp32: fp32 MFMA; "
+                         "bf16: bf16 MFMA operands, second-class (cannot meet the 1e-4 gate: never the headline)")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="2 (default): the sampling runs as two half-batches on two HIP streams inside the engine (bit-identical, "
+                         "fills the partly idle kernel tails); 1: one stream")
+    ap.add_argument("--profile-steps", type=int, default=2, help="samplings of the separate profiled pass behind the roofline object (0: none)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="d3d_engine_set_option switch for A/B runs (experiments/ab_option.sh), e.g. fused_postnorm=0")
     ap.add_argument("--seq2frame", action="store_true", help="BASELINE configs[4]: ...S2F... model, (B,1,J,3) targets")
     ap.add_argument("--no-time-emb", action="store_true", help="with_time_emb=False (3DHP command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,10 +229,21 @@ def main():
     if a.seq2frame:   # one target frame per window (DIFF-S2F): noise / ground truth of the centre frame
         noise, gt = noise[:, :1].contiguous(), gt[:, T // 2:T // 2 + 1].contiguous()
     eng = diff._engine(dev)
+    eng.set_option("streams", a.streams)
+    for kv in a.option:
+        k, v = kv.split("=", 1)
+        eng.set_option(k, int(v))
+    ag_events = []                                # (start, end) event pairs around the exchange step of every timed step
 
-    def step():
+    def step(record=False):
         pred = eng.ddim_sample(x2d, noise)
+        if record and use_dist:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         pred = parallel.all_gather_pred(pred, Bg, force=force_dist)          # RCCL all-gather (no-op at N=1 unless forced)
+        if record and use_dist:
+            e1.record()                           # (the current stream waits for the collective before anything behind it)
+            ag_events.append((e0, e1))
         return tta_mpjpe(pred, None, gt if world > 1 else gt[lo:hi], None, 1.0, [], [])
 
     def fence():
@@ -229,22 +256,45 @@ def main():
         eng.set_graph_mode(True)
     for _ in range(a.warmup):
         step()
-    eng.profile_reset()
-    eng.set_profiling(not a.graph)      # graph replay and per-kernel event timing exclude each other (include/d3d.h)
+    # ---- timed region: the engine as a user gets it -- per-kernel event timing OFF
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        err, cnt = step()
+        err, cnt = step(record=True)
     fence()
     elapsed = time.perf_counter() - t0
-    eng.set_profiling(False)
+    rank_ms = elapsed / a.steps * 1e3
+    rank_stats = None
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        cdev = dev if backend == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        ag_ms = sum(e0.elapsed_time(e1) for e0, e1 in ag_events) / max(len(ag_events), 1)
+        agt = torch.tensor([ag_ms], dtype=torch.float64, device=cdev)
+        dist.all_reduce(agt, op=dist.ReduceOp.MAX)
+        rank_stats = {"ms_per_step_min_over_ranks": round(float(tmin[0]) / a.steps * 1e3, 3),
+                      "ms_per_step_max_over_ranks": round(float(tmax[0]) / a.steps * 1e3, 3),
+                      "this_rank_ms_per_step": round(rank_ms, 3),
+                      "allgather_ms_per_step_max_over_ranks": round(float(agt[0]), 4),
+                      "allgather_bytes_per_rank": int(noise.numel() * 4),
+                      "allgather_note": "event-timed on the launch stream around parallel.all_gather_pred (includes waiting for the slowest rank's sampling)"}
         elapsed = float(tmax[0])
-    prof = eng.profile_read()
     if a.graph:
         eng.set_graph_mode(False)
+    # ---- profiled pass (outside the timed region): same batch, ONE stream, HIP events around every kernel
+    eng.profile_reset()
+    if a.profile_steps > 0:
+        eng.set_option("streams", 1)
+        eng.set_profiling(True)
+        for _ in range(a.profile_steps):
+            eng.ddim_sample(x2d, noise)
+        torch.cuda.synchronize(dev)
+        eng.set_profiling(False)
+        eng.set_option("streams", a.streams)
+    prof = eng.profile_read()
+    psteps = max(a.profile_steps, 1)
     # self-check of the timed configuration (no oracle runs at this size): the first two sequences of the batch, sampled
     # again as a batch of two (the small-problem kernels the golden-vector tests cover), must come out bit-identical
     selfcheck = None
@@ -260,7 +310,7 @@ def main():
         tot_ms = sum(v["ms"] for v in prof.values()) or 1.0
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
-        if not d["ms"]:                         # --graph: no per-kernel events; the whole-path figures are filled in below
+        if not d["ms"]:                         # --profile-steps 0: no per-kernel events; the whole-path figures are filled in below
             roof = {"bound": "mfma", "achieved": None, "peak": round(PEAK_TFLOPS[a.precision], 1), "unit": "TFLOP/s", "frac": None}
         elif dom == "linear" or dom == "attn_temporal":
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -274,7 +324,9 @@ def main():
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4)}
         roof.update({"kernel": dom, "launches": d["launches"], "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                      "share_of_gpu_time": round(d["ms"] / tot_ms, 4), "traffic": None,
-                     "by_kernel_ms_per_step": {k: round(v["ms"] / a.steps, 3) for k, v in prof.items() if v["launches"]}})
+                     "timed_in": f"separate profiled pass of {a.profile_steps} samplings right after the timed region (one stream, HIP events "
+                                 "around every kernel on the launch stream)",
+                     "by_kernel_ms_per_step": {k: round(v["ms"] / psteps, 3) for k, v in prof.items() if v["launches"]}})
         if any(v["launches"] for v in gemm_kinds.values()):
             pk = PEAK_TFLOPS[a.precision]
             roof["by_gemm"] = {k[7:]: {"avg_launch_ms": round(v["ms"] / v["launches"], 4),
@@ -309,17 +361,20 @@ def main():
             "whole_step_tflops": round(whole, 2),
             "mpjpe_vs_synthetic_gt": round(err / max(cnt, 1), 6),
             "selfcheck_batch_vs_pair_bit_identical": selfcheck,
+            "headline_under": ("2-stream" if a.streams == 2 else "eager") + ("+graph" if a.graph else ""),
             "roofline": roof,
         }
+        if rank_stats:
+            line["ranks"] = rank_stats
         if a.precision == "f16x3":
             line["precision_note"] = ("f16x3 = fp32-accurate arithmetic from three fp16 MFMAs per product (same 1e-4 parity gate as fp32); "
                                       "it also serves BASELINE configs[1], whose 'bf16' cannot meet that gate (SURVEY appendix B) "
                                       "and is not implemented -- no number of this repository is a bf16 number")
         if a.graph:
             line["graph_replay"] = True
-            roof["note"] = (roof.get("note", "") + "; main leg timed under hipGraph replay: per-kernel event timing is off, "
-                            "'achieved' is the whole-path figure").lstrip("; ")
-            roof.update({"kernel": "whole path (graph replay)", "achieved": round(whole, 2), "frac": round(whole / PEAK_TFLOPS[a.precision], 4),
+        if not d["ms"]:
+            roof["note"] = "no profiled pass (--profile-steps 0): 'achieved' is the whole-path figure of the timed region"
+            roof.update({"kernel": "whole path", "achieved": round(whole, 2), "frac": round(whole / PEAK_TFLOPS[a.precision], 4),
                          "launches": a.steps, "avg_launch_ms": round(elapsed / a.steps * 1e3, 3), "share_of_gpu_time": 1.0,
                          "by_kernel_ms_per_step": {}, "traffic": None})
             roof.pop("traffic_source", None)

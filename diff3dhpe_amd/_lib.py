@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libd3d_hip.so")
 
 PREC_FP32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 KC_COUNT = 11
-RANGE_ACT, RANGE_WEIGHT = 1, 2
+RANGE_ACT, RANGE_WEIGHT, RANGE_STATS = 1, 2, 4
 PRECISIONS = {"fp32": PREC_FP32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
 
 # every symbol include/d3d.h declares (tests/test_abi.py checks the library exports all of them)
@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "d3d_denoise", "d3d_ddim_sample", "d3d_q_sample", "d3d_tta_mpjpe", "d3d_allgather_pred", "d3d_op_linear", "d3d_op_layernorm",
     "d3d_op_attention", "d3d_op_time_embedding", "d3d_engine_set_profiling", "d3d_engine_profile_reset",
     "d3d_engine_profile_read", "d3d_kernel_class_name", "d3d_op_linear_bench", "d3d_op_linear_postnorm", "d3d_engine_set_graph_mode", "d3d_num_windows", "d3d_window_gather",
-    "d3d_engine_set_trace", "d3d_engine_trace_read", "d3d_engine_range_flags", "d3d_op_head",
+    "d3d_engine_set_trace", "d3d_engine_trace_read", "d3d_engine_range_flags", "d3d_op_head", "d3d_engine_set_option",
 ]
 
 
@@ -61,6 +61,7 @@ def _bind(lib: C.CDLL) -> None:
         "d3d_tta_mpjpe": (C.c_int, [vp, vp, vp, vp, f32, C.POINTER(i32), C.POINTER(i32), i32, vp, vp, i32, i32, i32, vp]),
         "d3d_engine_set_profiling": (C.c_int, [vp, i32]),
         "d3d_engine_set_graph_mode": (C.c_int, [vp, i32]),
+        "d3d_engine_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "d3d_num_windows": (C.c_int, [i32, i32]),
         "d3d_window_gather": (C.c_int, [vp, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), i32, vp, vp, vp]),
         "d3d_engine_range_flags": (C.c_int, [vp, C.POINTER(C.c_uint32), i32, vp]),

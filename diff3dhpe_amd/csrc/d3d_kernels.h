@@ -113,9 +113,8 @@ int x3q_ntiles(int M, int N);   // statistics partials per row an st_out launch 
 hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
 hipError_t launch_unsplit_x3(const void* pair, float* x, size_t rows, int cols, const float* part, int np, float* stats,
                              hipStream_t s);   // op hooks only
-// diagnostic launches (variants 13 / 11): per (workgroup, wave) six u64 stamps {clk, 100 MHz} x {start, k-loop end, end}
+// diagnostic launches (variant 13): per (workgroup, wave) six u64 stamps {clk, 100 MHz} x {start, k-loop end, end}
 void set_linear_x3_diag(unsigned long long* dev_buf);
-void x3_phase_diag_report();  // -DD3D_X3_PHASE_DIAG builds only: stamps inside the two phases of one k-tile of the persistent walk
 void attn_x3_diag_report();   // -DD3D_ATTN_DIAG_BUILD builds only: prints the step stamps of the last staggered temporal-attention launch
 
 // ---- kernels_elem.hip -------------------------------------------------------------------------------------------

@@ -20,6 +20,8 @@ using namespace d3d;
 namespace {
 
 thread_local std::string g_err;
+// process-wide diagnostic switches (d3d_engine_set_option with a NULL engine): in-kernel stamp reports of the op hooks
+std::atomic<int> g_opt_gemm_diag{0}, g_opt_attn_diag{0};
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -62,6 +64,13 @@ struct d3d_engine {
   bool freqs_set = false;
   bool committed = false;
   bool weights_clamped = false;   // F16X3: a GEMM weight left the fp16 range of 4096*w at commit (range guard)
+  // d3d_engine_set_option: the F16X3 block flow with the post-norm inside the fc2 epilogue / with norm1, norm2 folded into
+  // the consuming GEMMs (both on by default; experiments/ and the A/B tests switch them off)
+  bool opt_fused_postnorm = true, opt_fold_layernorm = true;
+  // "streams" = 2: d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by events)
+  int opt_streams = 1;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int device = -1;                // ordinal of the device the weights were committed on
 
   float* arena = nullptr;  // all weights, device
@@ -115,6 +124,9 @@ struct d3d_engine {
     drop_graphs();
     (void)hipFree(trace_dev);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : ev_pool) (void)hipEventDestroy(ev);
     (void)hipFree(arena); (void)hipFree(arena16); (void)hipFree(arena_fold); (void)hipFree(tblk_w); (void)hipFree(tblk_b); (void)hipFree(freqs_dev);
@@ -324,8 +336,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   const int np2 = x3q_ntiles(M, D);                     // statistics partials per row written by a GEMM epilogue
   int np1 = 1;                                          // ... per row in w.ST1 (1 after a row kernel)
   // post-norm inside the fc2 epilogue (X3PostNorm) where the tile shape for it exists; else fp32 + the row kernel
-  static const bool pn_off = getenv("D3D_NO_PN") != nullptr;   // (switch for experiments/)
-  const bool pn = !pn_off && x3q_postnorm_ok(D, e->Dm);
+  const bool pn = e->opt_fused_postnorm && x3q_postnorm_ok(D, e->Dm);
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
@@ -415,7 +426,7 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   const int M = B * T * J;
   const double MD4 = (double)M * D * 4.0;
   if (e->cfg.precision == D3D_PREC_F16X3 && attn_temporal_x3_ok(T, D, e->H) && attn_temporal_x3_ok(J, D, e->H) && D % 32 == 0 &&
-      !getenv("D3D_NO_FOLD"))
+      e->opt_fold_layernorm)
     return run_blocks_fold(e, x2d, y, y_bcast, tvec, tvec_stride, B, w, s);
   {
     Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
@@ -536,7 +547,7 @@ int check_ready(const d3d_engine* e, int B, const void* ws, size_t ws_bytes) {
 extern "C" {
 
 const char* d3d_last_error(void) { return g_err.c_str(); }
-int d3d_version(void) { return 100; }
+int d3d_version(void) { return 110; }
 
 int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out) {
   // torch.linspace(-1, N-1, S+1) in fp32 (two-sided evaluation around the midpoint), .int() truncation, reversed
@@ -799,7 +810,11 @@ int d3d_engine_set_schedule(d3d_engine* e, int32_t num_timesteps, const float* a
 
 size_t d3d_workspace_bytes(const d3d_engine* e, int32_t B) {
   if (!e || B <= 0) return 0;
-  return carve(e, B, nullptr).total_bytes + 256;
+  // one carve-up for the whole batch, or two for its halves ("streams" = 2): sized for either, so the option can change
+  // without a new workspace
+  size_t one = carve(e, B, nullptr).total_bytes, two = 0;
+  if (B >= 2) two = align_up(carve(e, (B + 1) / 2, nullptr).total_bytes, 256) + carve(e, B / 2, nullptr).total_bytes;
+  return std::max(one, two) + 256;
 }
 
 int d3d_denoise(d3d_engine* e, const float* x2d, const float* y, int32_t y_frames, const float* times_dev,
@@ -835,10 +850,12 @@ int d3d_denoise(d3d_engine* e, const float* x2d, const float* y, int32_t y_frame
 
 namespace {
 // The S-step loop of DIFF:262-300 as a launch sequence on `s` (also what gets captured into a hipGraph).
+// step_stride: elements between the draws of consecutive steps in step_noise (the WHOLE batch's rows * 3 when B is a half-batch)
 int ddim_loop(d3d_engine* e, const float* x2d, const float* init_noise, const float* step_noise, float* out, float* traj_rev,
-              float* traj_x0, int B, const Workspace& w, hipStream_t s) {
+              float* traj_x0, int B, const Workspace& w, hipStream_t s, size_t step_stride = 0) {
   const int S = e->S;
   const size_t yel = (size_t)head_rows(e, B) * 3;
+  if (!step_stride) step_stride = yel;
   for (int i = 0; i < S; ++i) {
     const int t = e->times[i], tn = e->times[i + 1];
     const float* y_cur = (i == 0) ? init_noise : ((i & 1) ? w.Y0 : w.Y1);
@@ -857,7 +874,7 @@ int ddim_loop(d3d_engine* e, const float* x2d, const float* init_noise, const fl
     } else {
       h.mode = 1;
       h.alpha = e->ac[t]; h.alpha_next = e->ac[tn]; h.somac = e->somac[t]; h.eta = e->eta;
-      h.noise = (e->eta != 0.0f) ? step_noise + (size_t)i * yel : nullptr;
+      h.noise = (e->eta != 0.0f) ? step_noise + (size_t)i * step_stride : nullptr;
     }
     {
       Prof p(e, D3D_KC_HEAD, 14.0 * h.rows * e->D, 4.0 * h.rows * e->D, s);
@@ -877,6 +894,40 @@ int ddim_loop(d3d_engine* e, const float* x2d, const float* init_noise, const fl
   }
   return D3D_OK;
 }
+
+// "streams" = 2: rows [0, B0) on `s`, rows [B0, B) on the engine's side stream, each half in its own carve-up of the
+// workspace; the side stream is forked from and joined back into `s` by events (inside a stream capture this makes two
+// branches of the graph).  Every output element is independent of the batch it is computed in, so the result is bit-identical
+// to the one-stream call.  The gain is the overlap of one half's partly filled kernel tails with the other half's work.
+struct SplitWs { int B0, B1; Workspace w0, w1; };
+SplitWs carve_split(const d3d_engine* e, int B, void* base) {
+  SplitWs sw{};
+  sw.B0 = (B + 1) / 2; sw.B1 = B - sw.B0;
+  sw.w0 = carve(e, sw.B0, base);
+  sw.w1 = carve(e, sw.B1, reinterpret_cast<char*>(base) + align_up(sw.w0.total_bytes, 256));
+  return sw;
+}
+int ddim_loop_split(d3d_engine* e, const float* x2d0, const float* x2d1, const float* noise0, const float* noise1,
+                    const float* step_noise, float* out0, float* out1, float* traj_rev, float* traj_x0, int B, const SplitWs& sw,
+                    hipStream_t s) {
+  if (!e->side_stream) HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+  if (!e->ev_fork) HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  if (!e->ev_join) HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  const size_t rows0 = (size_t)head_rows(e, sw.B0) * 3, rows_all = (size_t)head_rows(e, B) * 3;
+  HIP_TRY(hipEventRecord(e->ev_fork, s));
+  HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+  int rc = ddim_loop(e, x2d0, noise0, step_noise, out0, traj_rev, traj_x0, sw.B0, sw.w0, s, rows_all);
+  if (!rc)
+    rc = ddim_loop(e, x2d1, noise1, step_noise ? step_noise + rows0 : nullptr, out1, traj_rev ? traj_rev + rows0 * e->S : nullptr,
+                   traj_x0 ? traj_x0 + rows0 * e->S : nullptr, sw.B1, sw.w1, e->side_stream, rows_all);
+  // join even after a failed launch, so that `s` never runs ahead of work already queued on the side stream
+  hipError_t j1 = hipEventRecord(e->ev_join, e->side_stream);
+  hipError_t j2 = hipStreamWaitEvent(s, e->ev_join, 0);
+  if (rc) return rc;
+  HIP_TRY(j1);
+  HIP_TRY(j2);
+  return D3D_OK;
+}
 }  // namespace
 
 int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, const float* step_noise, float* out,
@@ -889,7 +940,16 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Workspace w = carve(e, B, ws);
   const bool use_graph = e->graph_mode && !traj_rev && !traj_x0 && e->eta == 0.0f && !e->profiling && !e->tracing;
-  if (!use_graph) return ddim_loop(e, x2d, init_noise, step_noise, out, traj_rev, traj_x0, B, w, s);
+  const bool split = e->opt_streams == 2 && B >= 2 && !e->profiling && !e->tracing;
+  const size_t xin_row = (size_t)e->T * e->J * e->cfg.in_chans;                 // x2d elements per sequence
+  SplitWs sw{};
+  if (split) sw = carve_split(e, B, ws);
+  const size_t xin0 = split ? (size_t)sw.B0 * xin_row : 0, y0 = split ? (size_t)head_rows(e, sw.B0) * 3 : 0;
+  if (!use_graph) {
+    if (split)
+      return ddim_loop_split(e, x2d, x2d + xin0, init_noise, init_noise + y0, step_noise, out, out + y0, traj_rev, traj_x0, B, sw, s);
+    return ddim_loop(e, x2d, init_noise, step_noise, out, traj_rev, traj_x0, B, w, s);
+  }
 
   // Graph replay: the captured launch sequence reads its inputs from / writes its result to fixed staging buffers
   // inside the workspace, so one instantiated graph serves every call with the same (B, workspace).
@@ -900,13 +960,18 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
     if (g.B == B && g.ws == ws) exec = g.exec;
   if (!exec) {
     if (!e->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    auto run = [&](hipStream_t st) {   // (split: each half stages in its own carve-up -- the whole-batch one overlays them)
+      if (split)
+        return ddim_loop_split(e, sw.w0.XIN, sw.w1.XIN, sw.w0.NIN, sw.w1.NIN, nullptr, sw.w0.OUTB, sw.w1.OUTB, nullptr, nullptr, B, sw, st);
+      return ddim_loop(e, w.XIN, w.NIN, nullptr, w.OUTB, nullptr, nullptr, B, w, st);
+    };
     {   // one eager pass first: kernels set their max-LDS attribute on first launch, which must not happen mid-capture
-      rc = ddim_loop(e, w.XIN, w.NIN, nullptr, w.OUTB, nullptr, nullptr, B, w, s);
+      rc = run(s);
       if (rc) return rc;
       HIP_TRY(hipStreamSynchronize(s));
     }
     HIP_TRY(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-    rc = ddim_loop(e, w.XIN, w.NIN, nullptr, w.OUTB, nullptr, nullptr, B, w, e->cap_stream);
+    rc = run(e->cap_stream);
     hipGraph_t graph = nullptr;
     hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -915,10 +980,37 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
     if (ie != hipSuccess) { (void)hipGraphDestroy(graph); HIP_TRY(ie); }
     e->graphs.push_back({B, ws, graph, exec});
   }
+  if (split) {
+    HIP_TRY(hipMemcpyAsync(sw.w0.XIN, x2d, xin0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sw.w1.XIN, x2d + xin0, xin_bytes - xin0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sw.w0.NIN, init_noise, y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sw.w1.NIN, init_noise + y0, y_bytes - y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipGraphLaunch(exec, s));
+    HIP_TRY(hipMemcpyAsync(out, sw.w0.OUTB, y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(out + y0, sw.w1.OUTB, y_bytes - y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return D3D_OK;
+  }
   HIP_TRY(hipMemcpyAsync(w.XIN, x2d, xin_bytes, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(w.NIN, init_noise, y_bytes, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipGraphLaunch(exec, s));
   HIP_TRY(hipMemcpyAsync(out, w.OUTB, y_bytes, hipMemcpyDeviceToDevice, s));
+  return D3D_OK;
+}
+
+int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
+  if (!key) return fail(D3D_EINVAL, "null key");
+  const std::string k(key);
+  if (k == "gemm_diag") { g_opt_gemm_diag = value != 0; return D3D_OK; }     // process-wide: e may be NULL
+  if (k == "attn_diag") { g_opt_attn_diag = value != 0; return D3D_OK; }
+  if (!e) return fail(D3D_EINVAL, "null engine");
+  if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
+  else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;
+  else if (k == "streams") {
+    if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
+    e->opt_streams = (int)value;
+  }
+  else return fail(D3D_EINVAL, "unknown option: " + k);
+  e->drop_graphs();   // captured launch sequences embody the old setting
   return D3D_OK;
 }
 
@@ -952,15 +1044,19 @@ int d3d_allgather_pred(void* nccl_comm, const float* send, float* recv, int64_t 
   if (!nccl_comm || !send || !recv || count_per_rank <= 0) return fail(D3D_EINVAL, "bad argument");
   // ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t)
   typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
-  static allgather_fn fn = []() -> allgather_fn {
+  // resolved lazily; only a SUCCESSFUL lookup is cached (RCCL may be loaded into the process after the first call)
+  static std::atomic<allgather_fn> cached{nullptr};
+  allgather_fn fn = cached.load(std::memory_order_acquire);
+  if (!fn) {
     void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
     for (const char* name : {"librccl.so", "librccl.so.1"}) {
       if (sym) break;
       if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) sym = dlsym(h, "ncclAllGather");   // only a library the process already holds
     }
-    return reinterpret_cast<allgather_fn>(sym);
-  }();
-  if (!fn) return fail(D3D_EUNSUP, "no RCCL library is loaded in this process (ncclAllGather not found)");
+    fn = reinterpret_cast<allgather_fn>(sym);
+    if (!fn) return fail(D3D_EUNSUP, "no RCCL library is loaded in this process (ncclAllGather not found)");
+    cached.store(fn, std::memory_order_release);
+  }
   constexpr int NCCL_FLOAT32 = 7;   // ncclDataType_t: ncclFloat32 (rccl.h)
   const int rc = fn(send, recv, (size_t)count_per_rank, NCCL_FLOAT32, nccl_comm, reinterpret_cast<hipStream_t>(stream));
   if (rc != 0) return fail(D3D_EHIP, "ncclAllGather failed");
@@ -1014,7 +1110,8 @@ int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* 
   HIP_TRY(range_flags_elem(&b, clear != 0));
   HIP_TRY(range_flags_attn(&c, clear != 0));
   HIP_TRY(range_flags_attn32(&d, clear != 0));
-  *flags = ((a | b | c | d) ? D3D_RANGE_ACT : 0u) | (e->weights_clamped ? D3D_RANGE_WEIGHT : 0u);
+  *flags = ((((a & 1u) | b | c | d) ? D3D_RANGE_ACT : 0u)) | (e->weights_clamped ? D3D_RANGE_WEIGHT : 0u) |
+           ((a & 2u) ? D3D_RANGE_STATS : 0u);
   return D3D_OK;
 }
 
@@ -1152,12 +1249,7 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
     return launch_linear_x3p(ap.dev, wp.dev, bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s);
   };
   HIP_TRY(once());
-  if (getenv("D3D_GEMM_PHASE_DIAG") && precision == D3D_PREC_F16X3 && variant == 0) {
-    for (int i = 0; i < 10; ++i) HIP_TRY(once());              // warm clocks
-    HIP_TRY(hipStreamSynchronize(s));
-    x3_phase_diag_report();
-  }
-  if (getenv("D3D_GEMM_DIAG") && precision == D3D_PREC_F16X3 && (variant == 13)) {
+  if (g_opt_gemm_diag && precision == D3D_PREC_F16X3 && (variant == 13)) {
     // diagnostic: in-kernel clock and k-loop / epilogue split from s_memtime / s_memrealtime stamps (256x256 tiles, 8 waves)
     const size_t nwg = (size_t)(((M + 255) / 256 + 7) / 8 * 8) * ((N + 255) / 256), nrec = nwg * 8;
     unsigned long long* dbuf = nullptr;
@@ -1186,7 +1278,7 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
     fprintf(stderr, "[gemm diag] N=%d K=%d v%d: waves %zu, in-kernel clock %.3f GHz, k-loop %.2f us, epilogue %.2f us (medians), "
             "kernel span %.1f us\n", N, K, variant, ghz.size(), med(ghz), med(loop_us), med(epi_us), (double)(rmax - rmin) * 0.01);
   }
-  if (getenv("D3D_GEMM_DIAG") && precision == D3D_PREC_F16X3 && variant == 0) {
+  if (g_opt_gemm_diag && precision == D3D_PREC_F16X3 && variant == 0) {
     // diagnostic: start / end stamps (100 MHz) of the persistent walk's workgroups -- how evenly do the CUs finish?
     unsigned long long* dbuf = nullptr;
     const size_t nwg = 1024;
@@ -1326,7 +1418,7 @@ int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t
     (void)hipFree(tmp);
     HIP_TRY(e3);
     HIP_TRY(e4);
-    if (getenv("D3D_ATTN_DIAG")) attn_x3_diag_report();
+    if (g_opt_attn_diag) attn_x3_diag_report();
     return D3D_OK;
   }
   if (!force_generic && !temporal && attn_spatial_fast_ok(J, D, H)) {

@@ -16,7 +16,6 @@
 #include "d3d_kernels.h"
 
 #include <math.h>
-#include <stdlib.h>
 #include <stdio.h>
 #include <utility>
 
@@ -642,21 +641,9 @@ __device__ __forceinline__ void split_pair_f16(float e0, float e1, float k, unsi
   asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(e1), "s"(k), "v"(hi));
 }
 
-#ifndef D3D_ATTN_ABL
-#define D3D_ATTN_ABL 0   // timing experiments only (wrong results), bit mask: 1 = stage K / V of the first unit only, 2 = no score phase,
-                         // 4 = no softmax, 8 = no PV phase, 16 = PV without the E conversions, 32 = PV without the V reads, 64 = no output arithmetic
-#endif
 // wave priority per phase (s_setprio): the two waves of a SIMD are in different phases; without it the OLDER wave's VALU stream
 // (softmax) wins every issue arbitration and the younger wave's MFMAs starve
-#ifndef D3D_ATTN_PRIO_S
-#define D3D_ATTN_PRIO_S 2
-#define D3D_ATTN_PRIO_PV 1
-#define D3D_ATTN_PRIO_SOFT 0
-#endif
-#define D3D_ATTN_PRIO(p) do { if ((p) >= 0) __builtin_amdgcn_s_setprio(p); } while (0)
-#ifndef D3D_ATTN_H0_MFMA_DMA
-#define D3D_ATTN_H0_MFMA_DMA 0   // 1: half 0 issues its DMA pieces at the start of its MFMA steps (one step earlier): measured 3 % slower
-#endif
+constexpr int ATTN_PRIO_S = 2, ATTN_PRIO_PV = 1, ATTN_PRIO_SOFT = 0;
 template <int NKT, int HALF>
 __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl, _Float16* __restrict__ out_x3,
                                               int T, int J, int H, int D, int units, unsigned char* const lds, const int wave,
@@ -698,7 +685,6 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
   // at the end of the step -- were 0 to 15 % slower.  Source address = (wave-uniform base: SGPR pair) + (one 32-bit per-lane
   // byte offset, advanced by a uniform step per piece); the bank swizzles are applied to the per-lane SOURCE chunk.
   auto dma = [&](int which, size_t tok0, int hd) {   // which: 1 = K, 2 = V
-    if (D3D_ATTN_ABL & 1) return;
     const int row0 = 8 * wave + (lane >> 3), dslot = lane & 7;
     const int chunk = (which == 1) ? (dslot ^ ((row0 >> 1) & 7)) : (dslot ^ vkey(row0));   // (both swizzles have period 32 in the row)
     const size_t ub = tok0 * D3 + (size_t)which * D + hd * XDH;
@@ -766,8 +752,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
           for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(po_ptr + it * po_stride + dt * 64) = po[dt * 4 + it];
         }
     }
-    D3D_ATTN_PRIO(D3D_ATTN_PRIO_S);
-    if (HALF == 0 && D3D_ATTN_H0_MFMA_DMA) dma(2, tok0, hd);                     // V_i
+    __builtin_amdgcn_s_setprio(ATTN_PRIO_S);
     // ---- S^T tiles (rows = keys, column = query tq); acc = 64 * s.  A step = one 16-deep d-slice of one key tile: two
     // ds_read_b128, three MFMAs; the fragments of step j + 2 are requested before the MFMAs of step j issue, which wait for
     // their own fragments only (lgkmcnt(4): the four younger reads stay in flight).
@@ -792,22 +777,20 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
 #pragma unroll
           for (int q = 0; q < 16; ++q) sacc[kt][q] = 0.f;
         }
-        if (!(D3D_ATTN_ABL & 2)) {
-          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[j % 3], qh[ks], sacc[kt], 0, 0, 0);
-          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[j % 3], ql[ks], sacc[kt], 0, 0, 0);
-          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[j % 3], qh[ks], sacc[kt], 0, 0, 0);
-        }
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[j % 3], qh[ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[j % 3], ql[ks], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[j % 3], qh[ks], sacc[kt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
     // ================= softmax step (global step 4i + 1 + HALF)
     D3D_STEP_SYNC(1);
-    D3D_ATTN_PRIO(D3D_ATTN_PRIO_SOFT);
-    if (HALF == 0) { if (!D3D_ATTN_H0_MFMA_DMA) dma(2, tok0, hd); }              // V_i
+    __builtin_amdgcn_s_setprio(ATTN_PRIO_SOFT);
+    if (HALF == 0) dma(2, tok0, hd);                                             // V_i
     else if (has_next) dma(1, tok0_n, hd_n);                                     // K_{i+1}
     float m = -INFINITY;
 #pragma unroll
-    for (int kt = ((D3D_ATTN_ABL & 4) ? NKT - 1 : 0); kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         if (kt == NKT - 1) {
@@ -826,7 +809,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     // two-instruction form); the compiler selects v_fma_mix*_f16 for it.
     // (the packed halves go back into the registers of the score tile: slots 0-7 hold the hi pairs, 8-15 the lo pairs)
 #pragma unroll
-    for (int kt = 0; kt < ((D3D_ATTN_ABL & 4) ? 1 : NKT); ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       float e[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -845,8 +828,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     l += __shfl_xor(l, 32, 64);
     // ================= PV product step (global step 4i + 2 + HALF)
     D3D_STEP_SYNC(2);
-    D3D_ATTN_PRIO(D3D_ATTN_PRIO_PV);
-    if (HALF == 0 && D3D_ATTN_H0_MFMA_DMA && has_next) dma(1, tok0_n, hd_n);      // K_{i+1}
+    __builtin_amdgcn_s_setprio(ATTN_PRIO_PV);
     // ---- O^T[d][query] = sum_key V^T[d][key] E^T[key][query]
     f32x16 oacc[2];
 #pragma unroll
@@ -875,29 +857,27 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
           lds_read_tr16_b64<off + PLANE>(f[4 * dt + 3], vaddr[2 * dt + 1]);
         }
       };
-      if (!(D3D_ATTN_ABL & 8)) vread(std::integral_constant<int, 0>{}, vf[0]);
+      vread(std::integral_constant<int, 0>{}, vf[0]);
       static_for<2 * NKT>([&](auto jc) {
         constexpr int j = decltype(jc)::value, kt = j >> 1, s2 = j & 1;
-        if (!(D3D_ATTN_ABL & 8)) {
-          if constexpr (j + 1 < 2 * NKT) vread(std::integral_constant<int, j + 1>{}, vf[(j + 1) & 1]);
-          typedef float f32x4_ __attribute__((ext_vector_type(4)));
-          const h8 eh = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 4 * s2, 4 * s2 + 1, 4 * s2 + 2, 4 * s2 + 3));
-          const h8 el = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 8 + 4 * s2, 9 + 4 * s2, 10 + 4 * s2, 11 + 4 * s2));
-          lgkm_wait<(j + 1 < 2 * NKT) ? 8 : 0>();
-          __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j + 1 < 2 * NKT) vread(std::integral_constant<int, j + 1>{}, vf[(j + 1) & 1]);
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        const h8 eh = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 4 * s2, 4 * s2 + 1, 4 * s2 + 2, 4 * s2 + 3));
+        const h8 el = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 8 + 4 * s2, 9 + 4 * s2, 10 + 4 * s2, 11 + 4 * s2));
+        lgkm_wait<(j + 1 < 2 * NKT) ? 8 : 0>();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            h8 vh, vl;
-            const h4 a0h = __builtin_bit_cast(h4, vf[j & 1][4 * dt]), a1h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 1]);
-            const h4 c0h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 2]), c1h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 3]);
+        for (int dt = 0; dt < 2; ++dt) {
+          h8 vh, vl;
+          const h4 a0h = __builtin_bit_cast(h4, vf[j & 1][4 * dt]), a1h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 1]);
+          const h4 c0h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 2]), c1h = __builtin_bit_cast(h4, vf[j & 1][4 * dt + 3]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { vh[e] = a0h[e]; vh[4 + e] = a1h[e]; vl[e] = c0h[e]; vl[4 + e] = c1h[e]; }
-            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, eh, oacc[dt], 0, 0, 0);
-            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, el, oacc[dt], 0, 0, 0);
-            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, eh, oacc[dt], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 4; ++e) { vh[e] = a0h[e]; vh[4 + e] = a1h[e]; vl[e] = c0h[e]; vl[4 + e] = c1h[e]; }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, eh, oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, el, oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, eh, oacc[dt], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       });
     }
     // v_query (this wave's own rows of V) into registers: the V planes are released at the end of this step
@@ -913,8 +893,8 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
     }
     // ================= output step (global step 4i + 3 + HALF); the next queries are fetched here
     D3D_STEP_SYNC(3);
-    D3D_ATTN_PRIO(D3D_ATTN_PRIO_SOFT);
-    if (has_next && (HALF == 1 || !D3D_ATTN_H0_MFMA_DMA)) dma(HALF == 0 ? 1 : 2, tok0_n, hd_n);
+    __builtin_amdgcn_s_setprio(ATTN_PRIO_SOFT);
+    if (has_next) dma(HALF == 0 ? 1 : 2, tok0_n, hd_n);
     if (has_next) load_q(tok0_n, hd_n);
     D3D_STAMP(10);
     // ---- O = O^T / (2^13 l) - v_query, packed as hi/lo of 8*o; stored in the next score step
@@ -936,7 +916,6 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
             const float sc = __builtin_amdgcn_fmed3f(o8, -65504.0f, 65504.0f);
             oh[e] = (_Float16)sc;
             ol[e] = (_Float16)(sc - (float)oh[e]);
-            if (D3D_ATTN_ABL & 64) { oh[e] = (_Float16)oacc[dt][4 * g4 + e]; ol[e] = oh[e]; }
           }
           // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout), 8 h bytes in
           const int sw = (r >> 1) & 7;
@@ -1095,17 +1074,13 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
   _Float16* ox = (_Float16*)out_x3;
   // persistent, DMA-staged form where a launch has several units per CU (instantiated for the frame counts of the
   // reference configs: T = 81 -> 3 key tiles, T = 243 -> 8)
-  static const bool no_persist = getenv("D3D_ATTN_NO_PERSIST") != nullptr;   // experiments only
-  const bool persist = !no_persist && (long long)B * J * H >= 1024;
+  const bool persist = (long long)B * J * H >= 1024;
   switch ((T + 31) / 32) {
     case 1:   // groups of <= 32 tokens (spatial blocks: the 17 joints of a frame).  8 units per workgroup = the 8 heads of one
               // frame at H = 8, so a workgroup reads whole token rows; measured 0.61 ms per launch at T=243, B=64 against
               // 0.82 / 0.68 / 0.69 ms with 1 / 2 / 4 units per workgroup.
-      if ((long long)B * J * H >= 4096 && !no_persist && (size_t)8 * 6 * T * 128 + (size_t)(32 - T) * 128 + 8 * 4096 <= 160 * 1024) {
-        static const int mu = getenv("D3D_ATTN_MU") ? atoi(getenv("D3D_ATTN_MU")) : 8;   // (experiments/)
-        if (mu == 12 && (size_t)12 * 6 * T * 128 + (size_t)(32 - T) * 128 + 12 * 4096 <= 160 * 1024) return launch_x3p_nkt<1, 12>(ph, pl, ox, B, T, J, D, H, s);
+      if ((long long)B * J * H >= 4096 && (size_t)8 * 6 * T * 128 + (size_t)(32 - T) * 128 + 8 * 4096 <= 160 * 1024)
         return launch_x3p_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
-      }
       if ((long long)B * J * H >= 4096) return launch_x3_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
       return launch_x3_nkt<1, 1>(ph, pl, ox, B, T, J, D, H, s);
     case 2: return launch_x3_nkt<2>(ph, pl, ox, B, T, J, D, H, s);
@@ -1114,11 +1089,7 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
     case 5: return launch_x3_nkt<5>(ph, pl, ox, B, T, J, D, H, s);
     case 6: return launch_x3_nkt<6>(ph, pl, ox, B, T, J, D, H, s);
     case 7: return launch_x3_nkt<7>(ph, pl, ox, B, T, J, D, H, s);
-    default: {
-      static const bool lockstep = getenv("D3D_ATTN_LOCKSTEP") != nullptr;   // experiments only: all eight waves in one phase
-      if (persist && !lockstep) return launch_x3s(ph, pl, ox, B, T, J, D, H, s);
-      return (persist ? launch_x3p_nkt<8> : launch_x3_nkt<8, 1>)(ph, pl, ox, B, T, J, D, H, s);
-    }
+    default: return (persist ? launch_x3s : launch_x3_nkt<8, 1>)(ph, pl, ox, B, T, J, D, H, s);
   }
 }
 

@@ -28,9 +28,9 @@ constexpr int WAVES_PER_BLOCK = 4;
 constexpr int LN_MAXV = 4;  // float4 per lane -> D <= 1024
 
 // Sum over the 64 lanes of a wave, the total in every lane.  In-row (16 lanes) butterfly by DPP -- quad xor 1, xor 2,
-// half-row mirror, row mirror --, then the four row totals through v_readlane: no ds_bpermute (what __shfl_xor compiles to).
-// History: with the __shfl_xor butterfly, three of which the head kernel issues back to back, single outputs of the head
-// changed from run to run while a second process used the GPU.
+// half-row mirror, row mirror --, then the four row totals through v_readlane: no ds_bpermute (what __shfl_xor compiles to), no
+// LDS traffic.  (The ds_bpermute butterfly was once suspected of the head kernel's deviation on a shared GPU and was EXCLUDED
+// by experiment -- 0 wrong sums of 10^10 in experiments/bperm_probe.hip, and this DPP form deviated as well; see k_head.)
 __device__ __forceinline__ float wave_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
@@ -349,12 +349,12 @@ hipError_t launch_frame_reduce(const float* X, const float* w, const float* bias
 // A workgroup owns HEAD_ROWS = 32 consecutive rows: 32 rows x 3 floats = 384 bytes = three WHOLE 128-byte lines of every
 // (rows, 3) output, written by one wave-instruction of lanes 0..95 after the row results have met in LDS.  With one row per
 // wave and four rows per workgroup (the first form of this kernel) a line of y_next was shared by three or four
-// workgroups on different XCDs, each storing 12-byte pieces of it -- and exactly those stores were what changed from run
-// to run when a second process used the GPU (found with the per-kernel trace of
-// experiments/bisect_two_proc.py; experiments/false_share_probe.hip shows the same without any kernel of this library).
-// Rule kept everywhere in this library since: no two workgroups ever store into the same 128-byte line.
+// workgroups on different XCDs, each storing 12-byte pieces of it.  That sharing was once suspected of the head's
+// run-to-run deviation on a GPU used by two processes and was EXCLUDED by experiment (experiments/false_share_probe.hip: 0
+// wrong words; this whole-line form deviated as well) -- what decides it is the instruction stream of the 3-row dot product
+// below.  Whole-line ownership is kept as a performance rule: no two workgroups store into the same 128-byte line.
 constexpr int HEAD_ROWS = 32;
-template <int NV, int VAR = 0>
+template <int NV>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
   static_assert(HEAD_ROWS % WAVES_PER_BLOCK == 0 && (HEAD_ROWS * 3 * 4) % 128 == 0, "whole lines per workgroup");
   __shared__ float so[HEAD_ROWS * 3];
@@ -378,38 +378,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
     for (int i = 0; i < NV; ++i) {
       const int c = 4 * (lane + 64 * i);
       if (c < D) {
-        if (VAR == 1) {        // experiment: all three weight loads waited for together (vmcnt(0)) before any is used
-          float4 w[3];
+        // One weight fragment loaded and consumed at a time, and the three sums kept out of packed (v_pk_*) register pairs by an
+        // opaque barrier after every update.  This is the instruction stream that never deviated on a GPU shared with a second
+        // process (0 of ~900 traced samplings); the compiler's free schedule -- three loads in flight behind counted waits,
+        // o[0] / o[1] in v_pk_fma_f32 pairs -- returned ONE wrong o[0] in about 1 launch of 60 there.  The mechanism below the
+        // instruction stream is not identified (experiments/NOTES.md); tests/test_abi_host.py checks the built kernel's ISA
+        // for exactly these two properties, so that a toolchain change cannot silently bring the other stream back.
 #pragma unroll
-          for (int k = 0; k < 3; ++k) w[k] = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0].x), "+v"(w[0].y), "+v"(w[0].z), "+v"(w[0].w), "+v"(w[1].x), "+v"(w[1].y), "+v"(w[1].z),
-                       "+v"(w[1].w), "+v"(w[2].x), "+v"(w[2].y), "+v"(w[2].z), "+v"(w[2].w));
-#pragma unroll
-          for (int k = 0; k < 3; ++k) o[k] += (v[i].x * w[k].x + v[i].y * w[k].y) + (v[i].z * w[k].z + v[i].w * w[k].w);
-        } else if (VAR == 2) { // experiment: rows of Wh visited 2, 1, 0
-#pragma unroll
-          for (int k = 2; k >= 0; --k) {
-            const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
-            o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else if (VAR == 4) {   // experiment: no SLP packing of o[0] / o[1] (opaque after every update)
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
-            o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
-            asm volatile("" : "+v"(o[k]));
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
-            o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
-          }
+        for (int k = 0; k < 3; ++k) {
+          const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
+          o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+          asm volatile("" : "+v"(o[k]));
+          __builtin_amdgcn_sched_barrier(0);   // the next fragment's load stays behind this one's use (every NV)
         }
       }
     }
-    if (VAR == 5) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]));   // experiment: idle before the reductions
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = wave_sum(o[k]);
     if (lane < 3) so[lr * 3 + lane] = (lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]));
@@ -449,25 +432,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
   if (a.rows <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
   const int grid = (a.rows + HEAD_ROWS - 1) / HEAD_ROWS;
-  // D3D_HEAD_VARIANT (experiments/bisect_two_proc.py): the instruction streams compared on a GPU shared by two processes.
-  // Default 4 = one weight fragment loaded, waited for and consumed at a time, o[0] / o[1] never packed into one register pair
-  // (clean: 0 of 224 samplings, as variant 1, 0 of 416); 0 = the compiler's free schedule (three loads in flight behind
-  // counted waits, o[0] / o[1] in v_pk_* pairs: about 1 launch in 60 returned ONE wrong o[0]), 2 and 5 likewise.
-  static const int var = getenv("D3D_HEAD_VARIANT") ? atoi(getenv("D3D_HEAD_VARIANT")) : 4;
   if (a.D <= 256)
-    hipLaunchKernelGGL((k_head<1, 4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
-  else if (a.D <= 512 && var == 1)
-    hipLaunchKernelGGL((k_head<2, 1>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
-  else if (a.D <= 512 && var == 2)
-    hipLaunchKernelGGL((k_head<2, 2>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
-  else if (a.D <= 512 && var == 0)
-    hipLaunchKernelGGL((k_head<2, 0>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
-  else if (a.D <= 512 && var == 5)
-    hipLaunchKernelGGL((k_head<2, 5>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_head<1>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else if (a.D <= 512)
-    hipLaunchKernelGGL((k_head<2, 4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_head<2>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   else
-    hipLaunchKernelGGL((k_head<4, 4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_head<4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 

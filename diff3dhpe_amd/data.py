@@ -84,21 +84,24 @@ class EvalData:
         self.kps_left, self.kps_right = list(symmetry[0]), list(symmetry[1])
         self.joints_left, self.joints_right = _sides(dataset)
         cams = dataset.cameras()
-        # scale: over every subject / action / camera of the data set, as the dataset constructor computes it
-        lo, hi = np.inf, -np.inf
-        for subject in (all_subjects if all_subjects is not None else list(cams.keys())):
-            try:
-                acts = dataset[subject]
-            except KeyError:
-                continue
-            for action in acts.keys():
-                for cam in cams[subject]:
-                    p = world_to_camera(acts[action]["positions"], R=cam["orientation"], t=cam["translation"])
-                    c = p - p[:, :1]
-                    lo, hi = min(lo, float(c.min())), max(hi, float(c.max()))
+        # scale: a reference dataset object has already computed it over every subject / action / camera and all its joints
+        # (h36m_dataset.py:260-275, BEFORE remove_joints); without one (MocapMeta) it is taken the same way over the joints
+        # SUPPLIED -- a 17-joint custom set therefore gets the extremes of its 17 joints, not of the 32 of the raw H36M skeleton
         pre = getattr(dataset, "_pos_3d_min", None)
-        if pre is not None:     # a reference dataset object has already done exactly this
+        if pre is not None:
             lo, hi = float(dataset._pos_3d_min), float(dataset._pos_3d_max)
+        else:
+            lo, hi = np.inf, -np.inf
+            for subject in (all_subjects if all_subjects is not None else list(cams.keys())):
+                try:
+                    acts = dataset[subject]
+                except KeyError:
+                    continue
+                for action in acts.keys():
+                    for cam in cams[subject]:
+                        p = world_to_camera(acts[action]["positions"], R=cam["orientation"], t=cam["translation"])
+                        c = p - p[:, :1]
+                        lo, hi = min(lo, float(c.min())), max(hi, float(c.max()))
         self.scale = float(abs(hi) if abs(hi) >= abs(lo) else abs(lo))
         self.sequences: List = []       # (key, poses_2d (n, J, 2+), poses_3d (n, J, 3))
         for subject in subjects:

@@ -88,7 +88,7 @@ class GaussianDiffusion(nn.Module):
         self._sched_sig = {}
         # debug mode (or D3D_CHECK_RANGE=1): after every sampling ask the engine's F16X3 range guard whether an operand left the
         # fp16 range of its planes and raise D3DError if so (one stream synchronisation per call; include/d3d.h)
-        self.check_range = bool(os.environ.get("D3D_CHECK_RANGE"))
+        self.check_range = os.environ.get("D3D_CHECK_RANGE", "").strip().lower() in ("1", "true", "yes", "on")
 
     # ------------------------------------------------------------------ engine plumbing
     def _engine(self, device: torch.device):

@@ -155,8 +155,13 @@ class Engine:
         """Replay the whole DDIM loop as one hipGraph per (B, workspace) (eta == 0, no trajectory capture)."""
         _lib.check(_lib.lib().d3d_engine_set_graph_mode(self._h, int(on)))
 
+    def set_option(self, key: str, value: int) -> None:
+        """Explicit engine switch (include/d3d.h: "fused_postnorm", "fold_layernorm", "streams"); the library reads no environment."""
+        _lib.check(_lib.lib().d3d_engine_set_option(self._h, key.encode(), int(value)))
+
     def range_flags(self, clear: bool = True) -> int:
-        """F16X3 range guard (include/d3d.h): _lib.RANGE_ACT | _lib.RANGE_WEIGHT bits; synchronises the current stream."""
+        """F16X3 range guard (include/d3d.h): _lib.RANGE_ACT | RANGE_WEIGHT | RANGE_STATS bits; synchronises the current stream.
+        The activation / statistics words are per DEVICE, cleared on read: engines (or streams) sharing a device share them."""
         f = C.c_uint32(0)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().d3d_engine_range_flags(self._h, C.byref(f), int(clear), self._stream()))
@@ -166,7 +171,9 @@ class Engine:
         """Raise D3DError if an F16X3 operand left the fp16 range since the last check (use precision='fp32' then)."""
         f = self.range_flags(clear=True)
         if f:
-            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a GEMM weight (|w| > 15.99)")) if f & b]
+            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a GEMM weight (|w| > 15.99)"),
+                                   (_lib.RANGE_STATS, "a LayerNorm input row with |mean| > 16 standard deviations (one-pass statistics)"))
+                    if f & b]
             raise _lib.D3DError("F16X3 operand range exceeded by " + " and ".join(what) +
                                 ": results are not fp32-accurate for this checkpoint/input -- use precision='fp32'")
 

@@ -56,6 +56,10 @@ class _MixSTEDenoiser(nn.Module):
     # engine arithmetic mode ("f16x3": fp32-accurate GEMMs/temporal attention from 3 fp16 MFMAs on hi/lo operand
     # splits; "fp32": fp32 MFMA).  Both pass the 1e-4 parity gate; override per instance before first use.
     precision = "f16x3"
+    # One process per GPU is the supported multi-GPU form (torchrun; parallel.py).  nn.DataParallel over SEVERAL devices in one
+    # process (RUN:216-218 with --gpu_id 0,1,...) would need one engine per device driven from DataParallel's worker threads:
+    # that path has never run on hardware, so it fails loudly instead of being trusted.  Flip this to try it anyway.
+    allow_multi_device = False
 
     def __init__(self, num_frame=9, num_joints=17, in_chans=2, embed_dim=32, depth=4, num_heads=8, mlp_ratio=2.,
                  qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None,
@@ -117,6 +121,12 @@ class _MixSTEDenoiser(nn.Module):
         if device.type != "cuda":
             raise _lib.D3DError("engine_for() needs a HIP device")
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        if not self.allow_multi_device and self._engines and idx not in self._engines:
+            raise _lib.D3DError(
+                f"this model already runs on cuda:{next(iter(self._engines))} and is now asked to run on cuda:{idx}: diff3dhpe_amd "
+                "supports ONE device per process (launch one process per GPU: torchrun --nproc-per-node N, or pass one id to "
+                "--gpu_id); nn.DataParallel over several devices in one process is untested -- set allow_multi_device = True on "
+                "the model class to try it")
         eng = self._engines.get(idx)
         if eng is None or eng.precision != self.precision:
             eng = Engine(self.cfg, precision=self.precision, device=torch.device("cuda", idx))

@@ -36,7 +36,41 @@ def hash_uniform(name: str, numel: int, seed: int) -> np.ndarray:
     return bits.astype(np.float64) * (2.0 / float(1 << 53)) - 1.0
 
 
-def synth_param(name: str, shape, kind: str, fan_in: int, seed: int) -> np.ndarray:
+def _trainedlike_param(name: str, shape, kind: str, fan_in: int, seed: int) -> np.ndarray:
+    """Second weight family, "trained-like" statistics (the reference's checkpoints cannot be fetched): heavy-tailed Linear
+    weights -- the U(+-1/sqrt(fan_in)) bulk plus a few entries per matrix with |w| in [4, 8] --, LayerNorm gains spread
+    log-uniformly over [0.05, 6] with biases up to +-3 gamma, position embeddings of order 1, biases of order 0.5.  It drives the
+    F16X3 planes (fp16 exponent range, one-pass LayerNorm statistics) and the softmax (sharp logits) far harder than the
+    default family does."""
+    n = int(np.prod(shape))
+    u = hash_uniform(name, n, seed)
+    if kind == "linear_w":
+        v = u / np.sqrt(float(fan_in))
+        if n >= 4096:        # a few heavy entries (about 1 in 32768, at least 4), positions and values from a second stream
+            k = max(4, n // 32768)
+            h = hash_uniform(name + "/heavy", 2 * k, seed)
+            pos = np.minimum((0.5 * (h[:k] + 1.0) * n).astype(np.int64), n - 1)
+            mag = 4.0 + 2.0 * (hash_uniform(name + "/heavy_mag", k, seed) + 1.0)          # [4, 8)
+            v[pos] = np.where(h[k:] < 0.0, -mag, mag)
+    elif kind == "linear_b":
+        v = 0.5 * u
+    elif kind == "ln_w":
+        v = np.exp(np.log(0.05) + 0.5 * (u + 1.0) * (np.log(6.0) - np.log(0.05)))
+    elif kind == "ln_b":
+        g = np.exp(np.log(0.05) + 0.5 * (hash_uniform(name.replace(".bias", ".weight"), n, seed) + 1.0) * (np.log(6.0) - np.log(0.05)))
+        v = 3.0 * g * u
+    elif kind == "pos":
+        v = 1.0 * u
+    else:
+        raise ValueError(f"unknown init kind {kind}")
+    return v.astype(np.float32).reshape(shape)
+
+
+def synth_param(name: str, shape, kind: str, fan_in: int, seed: int, family: str = "uniform") -> np.ndarray:
+    if family == "trainedlike":
+        return _trainedlike_param(name, shape, kind, fan_in, seed)
+    if family != "uniform":
+        raise ValueError(f"unknown weight family {family}")
     n = int(np.prod(shape))
     u = hash_uniform(name, n, seed)
     if kind in ("linear_w", "linear_b"):
@@ -52,9 +86,10 @@ def synth_param(name: str, shape, kind: str, fan_in: int, seed: int) -> np.ndarr
     return v.astype(np.float32).reshape(shape)
 
 
-def synth_state_dict(cfg: DenoiserConfig, seed: int = 0, prefix: str = "") -> Dict[str, np.ndarray]:
-    """Denoiser weights keyed by the reference state-dict names (optionally prefixed, e.g. 'model.')."""
-    return {prefix + name: synth_param(name, shape, kind, fan_in, seed)
+def synth_state_dict(cfg: DenoiserConfig, seed: int = 0, prefix: str = "", family: str = "uniform") -> Dict[str, np.ndarray]:
+    """Denoiser weights keyed by the reference state-dict names (optionally prefixed, e.g. 'model.').
+    family: "uniform" (U(+-1/sqrt(fan_in)), LayerNorm gamma = 1 + 0.1 u) or "trainedlike" (see _trainedlike_param)."""
+    return {prefix + name: synth_param(name, shape, kind, fan_in, seed, family)
             for name, shape, kind, fan_in in denoiser_param_spec(cfg)}
 
 

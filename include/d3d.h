@@ -117,6 +117,17 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d_dev, const float* init_noise
  * the result go through staging buffers inside the workspace.  Weights / schedule changes drop the captured graphs. */
 int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
 
+/* Explicit switches (the library reads NO environment variables).  Engine options (results stay within the parity gate either way;
+ * used by the A/B scripts under experiments/ and by tests that exercise the alternative flows):
+ *   "fused_postnorm"  1 (default) / 0: F16X3 block flow with the block's post-norm inside the fc2 GEMM epilogue / as a row kernel
+ *   "fold_layernorm"  1 (default) / 0: F16X3 flow with norm1 / norm2 folded into the qkv / fc1 GEMMs / as row kernels
+ *   "streams"         1 (default) / 2: d3d_ddim_sample runs the batch as two half-batches on two HIP streams (the caller's and one
+ *                     the engine owns, forked and joined by events; bit-identical results: every output element is independent of
+ *                     the batch it is computed in).  Per-kernel profiling and the trace force one stream.
+ * Process-wide diagnostics (e may be NULL): "gemm_diag", "attn_diag" 0 / 1: the op hooks print in-kernel stamp reports to stderr
+ * (attn_diag needs a -DD3D_ATTN_DIAG_BUILD library).  Unknown key: D3D_EINVAL. */
+int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value);
+
 /* q_sample (DIFF:360-366, extract DIFF:21-24): out = sqrt_ac[t_b] * x_start + sqrt(1-ac)[t_b] * noise, per row b.
  * n = elements per batch row. */
 int d3d_q_sample(d3d_engine* e, const float* x_start_dev, const float* noise_dev, const int32_t* t_dev, float* out_dev,
@@ -125,7 +136,9 @@ int d3d_q_sample(d3d_engine* e, const float* x_start_dev, const float* noise_dev
 /* evaluate() tail (RUN:583-590, LOSS:15-22): un-flip + average the TTA pair, multiply by scale, and reduce the masked
  * per-joint L2 error.  sums_dev[0] += sum of joint errors over frames with mask != 0, sums_dev[1] += number of such
  * joints (caller zeroes sums_dev).  merged_dev (nullable) receives the merged, de-normalised prediction (B,T,J,3).
- * pred_flip_dev may be NULL (no TTA).  joints_left/right: host index lists of equal length. */
+ * pred_flip_dev may be NULL (no TTA).  joints_left/right: host index lists of equal length.
+ * Asynchronous on `stream` (since ABI version 110; it used to synchronise): sums_dev / merged_dev are valid only after the stream
+ * has been synchronised.  J <= 64 (the joint permutation travels as a kernel argument); more: D3D_EUNSUP. */
 int d3d_tta_mpjpe(const float* pred_dev, const float* pred_flip_dev, const float* gt_dev, const uint8_t* mask_dev,
                   float scale, const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr,
                   float* merged_dev, double* sums_dev, int32_t B, int32_t T, int32_t J, void* stream);
@@ -140,7 +153,8 @@ int d3d_allgather_pred(void* nccl_comm, const float* send_dev, float* recv_dev, 
 /* Evaluation windows of one whole sequence, on the device: ChunkedGenerator(out_all=True, pad=0) (common/nosiy_generators.py:27-48
  * window table, :247-276 slicing, edge padding, target_mask, horizontal flip).  seq (n_frames, J, C) -> out
  * (d3d_num_windows, T, J, C); mask (nullable) (windows, T) uint8, 0 for the frames of the shifted last window that its
- * predecessor already covers.  flip != 0 writes the flipped copy (channel 0 negated, left/right joints swapped). */
+ * predecessor already covers.  flip != 0 writes the flipped copy (channel 0 negated, left/right joints swapped).
+ * Asynchronous on `stream`: out_dev / mask_dev are valid only after the stream has been synchronised.  J <= 64, else D3D_EUNSUP. */
 int d3d_num_windows(int32_t n_frames, int32_t T);
 int d3d_window_gather(const float* seq_dev, int32_t n_frames, int32_t T, int32_t J, int32_t C, int32_t flip,
                       const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr, float* out_dev,
@@ -174,11 +188,17 @@ const char* d3d_kernel_class_name(int32_t kernel_class);
  * d3d_engine_commit_weights notes clamped weights.  d3d_engine_range_flags synchronises `stream` and returns
  *   D3D_RANGE_ACT    an activation was clamped on this device since the flag was last cleared (any engine of the process)
  *   D3D_RANGE_WEIGHT a weight of this engine was clamped at commit
- * clear != 0 resets the activation flag.  A set flag means the F16X3 result is NOT fp32-accurate for this checkpoint / input:
+ *   D3D_RANGE_STATS  a LayerNorm folded into a GEMM met a row with |mean| > 16 standard deviations: the folded form works from
+ *                    one-pass row statistics (sum, sum of squares), whose variance loses accuracy like eps (1 + mean^2 / var)
+ *                    -- beyond ~25 sigma the 1e-4 parity gate is no longer guaranteed (post-norm biases that dwarf the gains)
+ * clear != 0 resets the activation and statistics flags.  The flag words are per DEVICE (one per kernel translation unit), not
+ * per engine: two engines, or two streams, on one device share them -- a read with clear != 0 by one consumes what the other
+ * raised.  A set flag means the F16X3 result is NOT fp32-accurate for this checkpoint / input:
  * run the engine with D3D_PREC_FP32 (RUN:226-235 loads arbitrary checkpoints; random-init and LayerNorm-ed streams stay far
  * inside the range). */
 #define D3D_RANGE_ACT 1u
 #define D3D_RANGE_WEIGHT 2u
+#define D3D_RANGE_STATS 4u
 int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* stream);
 
 /* ---- debug trace: while on (capacity > 0 slots), every kernel of the F16X3 block flow and the head is followed on `stream`
@@ -204,7 +224,7 @@ int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, floa
 int d3d_op_linear(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,
                   int32_t M, int32_t N, int32_t K, int32_t epi, int32_t precision, void* stream);
 /* d3d_op_linear with a choice of tile variant (F16X3: 0 = the engine's choice, 13 = 256x256, 4 = 256x128, 9 = on-the-fly A
- * split; 5/7/8/10 = shapes kept for experiments/gemm_bench.py only)
+ * split)
  * and a timing leg: after one untimed call, `reps` back-to-back launches are timed with HIP events on `stream` and the
  * mean written to *avg_ms (nullable).  Operand conversion for F16X3 happens once, outside the timed launches. */
 int d3d_op_linear_bench(const float* A_dev, const float* W_dev, const float* bias_dev, const float* R_dev, float* C_dev,

@@ -108,6 +108,39 @@ def ddim_times_scalar(num_timesteps: int, sampling_timesteps: int) -> List[int]:
     return list(reversed(out))
 
 
+# --------------------------------------------------------------------------- operand-rounding emulation (bf16 engine mode)
+# SURVEY.md section 8(d) "Parity gates": the bf16 engine cannot meet the fp32 gate (bf16 operands alone cost ~4e-2 max-abs,
+# Appendix B), so it is gated against THIS restatement run with the same roundings: the operands of the matrix-core products of
+# a block -- the qkv / proj / fc1 / fc2 Linears (x and W) and the two attention products (q, k and softmax - I, v) -- rounded to
+# bf16 (round-to-nearest-even), everything else fp32: accumulation, bias, residual stream, LayerNorm, softmax, GELU, time
+# embedding, fusion layer, head, DDIM update.  Off by default (the fp32 restatement pinned against the reference).
+_OPERAND_DTYPE = None
+
+
+class operand_rounding:
+    """``with operand_rounding(torch.bfloat16): ...`` -- the block GEMM / attention operands are rounded to that dtype."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _OPERAND_DTYPE
+        self._prev, _OPERAND_DTYPE = _OPERAND_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_DTYPE
+        _OPERAND_DTYPE = self._prev
+
+
+def _rnd(x: Tensor) -> Tensor:
+    return x if _OPERAND_DTYPE is None else x.to(_OPERAND_DTYPE).to(x.dtype)
+
+
+def _block_linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    return F.linear(_rnd(x), _rnd(w), b)
+
+
 # --------------------------------------------------------------------------- denoiser (S2S / S2F)
 
 def sinusoid(time: Tensor, dim: int) -> Tensor:
@@ -131,13 +164,13 @@ def grand_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int) -> Ten
     """S2S:73-86. x: (G, N, C). (softmax(q k^T * scale) - I) v, then proj. Identity is materialised as in the reference."""
     G, N, C = x.shape
     dh = C // heads
-    qkv = F.linear(x, sd[p + ".qkv.weight"], sd.get(p + ".qkv.bias")).reshape(G, N, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    qkv = _block_linear(x, sd[p + ".qkv.weight"], sd.get(p + ".qkv.bias")).reshape(G, N, 3, heads, dh).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    a = (q @ k.transpose(-2, -1)) * (dh ** -0.5)
+    a = (_rnd(q) @ _rnd(k).transpose(-2, -1)) * (dh ** -0.5)
     a = a.softmax(dim=-1)
     eye = torch.eye(N, dtype=a.dtype).view(1, 1, N, N).repeat(G, heads, 1, 1)
-    o = ((a - eye) @ v).transpose(1, 2).reshape(G, N, C)
-    return F.linear(o, sd[p + ".proj.weight"], sd[p + ".proj.bias"])
+    o = (_rnd(a - eye) @ _rnd(v)).transpose(1, 2).reshape(G, N, C)
+    return _block_linear(o, sd[p + ".proj.weight"], sd[p + ".proj.bias"])
 
 
 def mixste_block(sd: Dict[str, Tensor], p: str, x: Tensor, spatial: bool, temb: Optional[Tensor], heads: int) -> Tensor:
@@ -153,9 +186,9 @@ def mixste_block(sd: Dict[str, Tensor], p: str, x: Tensor, spatial: bool, temb: 
     h = F.layer_norm(x, (c,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6)
     x = x + grand_attention(sd, p + ".attn", h, heads)
     h = F.layer_norm(x, (c,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-6)
-    h = F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])
+    h = _block_linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])
     h = F.gelu(h)
-    h = F.linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    h = _block_linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
     x = x + h
     if spatial:
         return x.reshape(b, f, j, c)

@@ -64,12 +64,12 @@ def import_reference():
 HPE_model, GD_S2S, GD_S2F, ref_mpjpe = import_reference()
 
 
-def build_ref(cfg: DenoiserConfig, seed: int, timesteps=1000, sampling=9, eta=0.0, clip=True):
+def build_ref(cfg: DenoiserConfig, seed: int, timesteps=1000, sampling=9, eta=0.0, clip=True, family="uniform"):
     name = S2F_NAME if cfg.seq2frame else S2S_NAME
     net = HPE_model(name)(num_frame=cfg.num_frame, num_joints=cfg.num_joints, in_chans=cfg.in_chans,
                           embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
                           qkv_bias=True, qk_scale=None, drop_path_rate=0.1, with_time_emb=cfg.with_time_emb)
-    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed).items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed, family=family).items()}
     missing, unexpected = net.load_state_dict(sd, strict=True), None
     GD = GD_S2F if cfg.seq2frame else GD_S2S
     diff = GD(model=net, timesteps=timesteps, sampling_timesteps=sampling, loss_type="l2", clip_denoised=clip,
@@ -439,10 +439,52 @@ def gen_dataset():
     save("dataset_eval", **out)
 
 
+def gen_trainedlike():
+    """Second weight family ("trained-like": heavy-tailed Linear weights, LayerNorm gains in [0.05, 6] with biases up to 3 gamma,
+    position embeddings of order 1 -- diff3dhpe_amd.synth._trainedlike_param), through the imported reference: raw denoiser
+    outputs at T = 27 / 243 and a full 9-step sampling at T = 81 (B = 2, D = 512, depth 8)."""
+    for T, ts in ((27, (999, 443, 0)), (243, (443,))):
+        cfg = cfg_full(T)
+        net, _, sd = build_ref(cfg, 11, family="trainedlike")
+        inp = synth_inputs(2, T, seed=500)
+        x2d = torch.from_numpy(inp["x2d"])
+        y_t = torch.from_numpy(inp["noise"]) * 0.7
+        out = {}
+        for t in ts:
+            tv = torch.full((2,), t, dtype=torch.long)
+            t0 = time.time()
+            with torch.no_grad():
+                r = net.forward_denoise(torch.cat([x2d, y_t], dim=-1), tv)
+            dt = time.time() - t0
+            o = orc.forward_denoise(sd, torch.cat([x2d, y_t], dim=-1), tv, depth=cfg.depth)
+            check(f"denoise trainedlike T={T} t={t} ({dt:.1f}s)", o, r)
+            out[f"t{t}"] = r.numpy()
+        if T == 27:
+            tv = torch.tensor([905, 17], dtype=torch.long)
+            with torch.no_grad():
+                out["tmixed"] = net.forward_denoise(torch.cat([x2d, y_t], dim=-1), tv).numpy()
+            out["tmixed_t"] = tv.numpy().astype(np.int32)
+        save(f"denoise_trainedlike_T{T}", seed=np.int32(11), input_seed=np.int32(500), B=np.int32(2), y_scale=np.float32(0.7), **out)
+    cfg = cfg_full(81)
+    net, diff, sd = build_ref(cfg, 12, sampling=9, family="trainedlike")
+    inp = synth_inputs(2, 81, seed=600)
+    x2d, noise = torch.from_numpy(inp["x2d"]), torch.from_numpy(inp["noise"])
+    t0 = time.time()
+    with inject_noise(noise), torch.no_grad():
+        _, y0, rev, x0s = diff(torch.zeros_like(noise), x2d, None, True, False)
+    dt = time.time() - t0
+    o = orc.ddim_sample_loop(sd, orc.diffusion_tables("cosine", 1000), x2d, noise, num_timesteps=1000, sampling_timesteps=9, depth=8,
+                             return_trajectory=True)
+    check(f"ddim trainedlike T=81 S=9 y0 ({dt:.1f}s)", o[0], y0, 5e-6)
+    check("ddim trainedlike x0s", o[2], x0s, 5e-6)
+    save("ddim_trainedlike_T81_S9", seed=np.int32(12), input_seed=np.int32(600), B=np.int32(2), S=np.int32(9), y0=y0.numpy(),
+         x_start_est=x0s.numpy())
+
+
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
-    "dataset": gen_dataset,
+    "dataset": gen_dataset, "trainedlike": gen_trainedlike,
 }
 
 if __name__ == "__main__":

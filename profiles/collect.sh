@@ -2,10 +2,12 @@
 # Run ON THE GPU BOX (through gpurun, from the repo root): every rocprofv3 pass of the default bench workload, each in
 # its own run (kernel trace + stats; FETCH_SIZE; WRITE_SIZE; SQ/GRBM counters -- counters never combined with traces),
 # condensed into profiles/<tag>_*.  Raw output stays under gpurun_out/ (scratch).
-#   profiles/collect.sh r01_f16x3 [bench.py args...]
+#   profiles/collect.sh r03_f16x3 [bench.py args...]          e.g.  profiles/collect.sh r03_T81 --frames 81 --batch 128
+# The profiled bench runs ONE stream, without its own event-timed pass (--streams 1 --profile-steps 0): kernel durations in the
+# trace are then those of kernels running alone, which is what the per-kernel roofline figures mean.
 set -eo pipefail
-tag=${1:-r01_f16x3}; shift || true
-args="--steps 1 --warmup 1 --no-cpu-baseline --no-selfcheck --no-extras $*"
+tag=${1:-r03_f16x3}; shift || true
+args="--steps 1 --warmup 1 --no-cpu-baseline --no-selfcheck --no-extras --streams 1 --profile-steps 0 $*"
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 export TMPDIR=/tmp
@@ -24,8 +26,14 @@ python3 profiles/summarize.py pmc $out/fetch $out/write profiles/${tag}_pmc.json
 python3 profiles/summarize.py sq $out/sq profiles/${tag}_sq_counters.json > /dev/null
 grep '^{' $out/stats.log | tail -1 > profiles/${tag}_bench_under_rocprof.json || true
 # per-class HBM bytes for bench.py's roofline.traffic (tagged there as coming from these passes, not from the bench run itself)
-prec=f16x3; case "$*" in *fp32*) prec=fp32;; esac
-python3 profiles/summarize.py traffic profiles/${tag}_pmc.json profiles/hbm_traffic.json 243 64 $prec > /dev/null || true
+prec=f16x3; case "$*" in *fp32*) prec=fp32;; *bf16*) prec=bf16;; esac
+T=243; B=64; prev=""
+for w in "$@"; do
+  [ "$prev" = "--frames" ] && T=$w
+  [ "$prev" = "--batch" ] && B=$w
+  prev=$w
+done
+python3 profiles/summarize.py traffic profiles/${tag}_pmc.json profiles/hbm_traffic.json $T $B $prec > /dev/null || true
 python3 - <<PY
 import json, time
 p = "profiles/hbm_traffic.json"; d = json.load(open(p)); d["_collected"] = "${tag}, " + time.strftime("%Y-%m-%d"); json.dump(d, open(p, "w"), indent=1)

@@ -99,11 +99,12 @@ def test_ddim_loop_golden(tag, cfg, traj, clip, prec):
         assert y0.abs().max().item() <= 1.0
 
 
-def test_repeat_n_and_stochastic_eta():
+@pytest.mark.parametrize("prec", PRECS)
+def test_repeat_n_and_stochastic_eta(prec):
     g = gold("ddim_small_T27_S4_eta05_rep3")
     cfg = cfg_small(27)
     B, S, R = int(g["B"]), int(g["S"]), int(g["R"])
-    _, diff = build_product(cfg, int(g["seed"]), sampling=S, eta=0.5)
+    _, diff = build_product(cfg, int(g["seed"]), sampling=S, eta=0.5, precision=prec)
     inp = inputs(B * R, 27, int(g["input_seed"]))
     step_noise = torch.stack([hashed(f"eta_noise/{i}", tuple(inp["noise"].shape), 6) for i in range(S)])
     _, y0 = diff(clean_3d_pose=torch.zeros(B, 27, 17, 3).cuda(), noisy_2d_pose=inp["x2d"][:B].cuda(), output_loss=False,
@@ -111,11 +112,12 @@ def test_repeat_n_and_stochastic_eta():
     assert maxabs(y0, g["y0"]) <= GATE
 
 
-def test_p_losses_and_q_sample():
+@pytest.mark.parametrize("prec", PRECS)
+def test_p_losses_and_q_sample(prec):
     g = gold("plosses_small_T27")
     cfg = cfg_small(27)
     B = int(g["B"])
-    _, diff = build_product(cfg, int(g["seed"]), sampling=5)
+    _, diff = build_product(cfg, int(g["seed"]), sampling=5, precision=prec)
     inp = inputs(B, 27, int(g["input_seed"]))
     gt = (inp["gt3d"] * float(g["gt_scale"])).cuda()
     t = torch.from_numpy(g["t"]).long().cuda()
@@ -228,11 +230,12 @@ def test_large_batch_kernels_match_the_small_batch_path():
         assert torch.equal(eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous()), big[lo:hi])
 
 
-def test_engine_matches_oracle_on_fresh_seeded_inputs():
+@pytest.mark.parametrize("prec", PRECS)
+def test_engine_matches_oracle_on_fresh_seeded_inputs(prec):
     """HIP path vs the CPU oracle on inputs no fixture holds (small enough for the oracle to finish in seconds)."""
     from oracle import d3d_oracle as orc
     for cfg, B, S in ((cfg_small(27), 5, 6), (cfg_full(27), 3, 4), (cfg_full(9, seq2frame=True), 2, 3)):
-        _, diff = build_product(cfg, 31, sampling=S)
+        _, diff = build_product(cfg, 31, sampling=S, precision=prec)
         inp = inputs(B, cfg.num_frame, 555)
         noise = inp["noise"][:, :1].contiguous() if cfg.seq2frame else inp["noise"]
         _, y0 = diff(clean_3d_pose=torch.zeros_like(noise).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False,
@@ -290,11 +293,12 @@ def test_folded_layernorm_statistics_with_offset_rows(off):
     assert e <= GATE / 4
 
 
-def test_evaluate_harness_flip_tta():
+@pytest.mark.parametrize("prec", PRECS)
+def test_evaluate_harness_flip_tta(prec):
     from diff3dhpe_amd.evaluate import evaluate, flip_2d, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
     from oracle import d3d_oracle as orc
     cfg = cfg_small(27)
-    _, diff = build_product(cfg, 12, sampling=3)
+    _, diff = build_product(cfg, 12, sampling=3, precision=prec)
     inp = inputs(4, 27, 99)
     mask = torch.ones(4, 27, dtype=torch.bool)
     mask[3, 20:] = False
@@ -360,12 +364,13 @@ def test_sequence_windows_on_device_bit_exact():
         assert torch.equal(m.cpu(), om) and np.array_equal(m.cpu().numpy(), g[f"n{n}_T{T}/mask"]), (n, T)
 
 
-def test_evaluate_sequence_end_to_end():
+@pytest.mark.parametrize("prec", PRECS)
+def test_evaluate_sequence_end_to_end(prec):
     """A 70-frame video through windows -> DDIM (flip TTA) -> merge -> masked MPJPE, against the oracle doing the same."""
     from diff3dhpe_amd.evaluate import evaluate_sequence, H36M_JOINTS_LEFT as JL, H36M_JOINTS_RIGHT as JR
     from oracle import d3d_oracle as orc
     cfg = cfg_small(27)
-    _, diff = build_product(cfg, 14, sampling=3)
+    _, diff = build_product(cfg, 14, sampling=3, precision=prec)
     n = 70
     rng = np.random.RandomState(5)
     p2 = torch.from_numpy(np.clip(rng.normal(0, 0.4, (n, 17, 2)), -1, 1).astype(np.float32))
@@ -421,7 +426,8 @@ def test_c_abi_error_behaviour_on_device():
     assert torch.isfinite(res).all()
 
 
-def test_dataset_adaptor_feeds_evaluate():
+@pytest.mark.parametrize("prec", PRECS)
+def test_dataset_adaptor_feeds_evaluate(prec):
     """Section 8f row 4 end to end: windows from diff3dhpe_amd.data (bit-equal to the reference loader, tests/test_data_adaptor.py)
     through evaluate() -- two samplings per window, merge, de-normalise by the data set's scale, masked MPJPE (RUN:562-606) --
     against the oracle doing the same on the same windows."""
@@ -432,7 +438,7 @@ def test_dataset_adaptor_feeds_evaluate():
     pos, cams, kp, meta = synth_mocap(0)
     ed = EvalData(MocapMeta(pos, cams, JL, JR), kp, meta["keypoints_symmetry"], ["S9"], 27)      # 8 windows
     cfg = cfg_small(27)
-    _, diff = build_product(cfg, 31, sampling=3)
+    _, diff = build_product(cfg, 31, sampling=3, precision=prec)
     batches = []
     for i, b in enumerate(ed.batches(5)):
         n = b["inputs_2d"].shape[0]
@@ -454,11 +460,12 @@ def test_dataset_adaptor_feeds_evaluate():
     assert abs(res["mpjpe_mm"] - err / cnt * 1000) < 0.05
 
 
-def test_rng_is_consumed_as_the_reference_consumes_it():
+@pytest.mark.parametrize("prec", PRECS)
+def test_rng_is_consumed_as_the_reference_consumes_it(prec):
     """Without supplied noise a sampling draws randn(target_shape) once and then S - 1 more tensors of that shape from the global
     generator, eta or not (DIFF:275, 293): the next sampling of an unchanged runner starts from the same generator state."""
     cfg = cfg_small(27)
-    _, diff = build_product(cfg, 12, sampling=4)
+    _, diff = build_product(cfg, 12, sampling=4, precision=prec)
     x2d = inputs(2, 27, 7)["x2d"].cuda()
     shape = (2, 27, 17, 3)
     torch.manual_seed(1234)
@@ -537,13 +544,13 @@ def test_bench_two_ranks_on_one_device():
     """The N>1 code path of bench.py (sharding, all-gather of predictions, max-over-ranks timing, rank-0 JSON) run as two
     torch.distributed ranks that share cuda:0 through gloo (RCCL cannot form a communicator on one device).  The gathered
     MPJPE must equal the 1-rank value for the same global batch (per-sample noise is a slice of the global tensor).
-    Runs the DEFAULT kernels (post-norm GEMM form included): the run-to-run differences two processes on one GPU used to show
-    were single outputs of the head kernel's __shfl_xor (ds_bpermute) butterflies, not the GEMM (DESIGN.md section 4.1;
-    experiments/bisect_two_proc.py); the row kernels reduce by DPP + v_readlane since."""
+    Runs the DEFAULT kernels.  Two processes on one GPU once showed run-to-run different single outputs of the head kernel; the
+    cause was narrowed to the instruction stream of its 3-row dot product (the mechanism below it is not identified:
+    experiments/NOTES.md), the kept stream is pinned by tests/test_abi_host.py::test_head_kernel_instruction_stream_..., and
+    experiments/two_rank_repeat.sh is the many-iteration form of this test (one step here barely sees a 1-in-60 event)."""
     import json, os, subprocess, sys
     from conftest import ROOT
     env = dict(os.environ, D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo")
-    env.pop("D3D_NO_PN", None)
     common = ["--steps", "1", "--warmup", "0", "--frames", "27", "--sampling", "3", "--no-cpu-baseline", "--no-extras"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "3"] + common,
@@ -551,7 +558,6 @@ def test_bench_two_ranks_on_one_device():
     assert two.returncode == 0, two.stderr[-2000:]
     line2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     env1 = dict(os.environ)
-    env1.pop("D3D_NO_PN", None)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "6"] + common,
                          capture_output=True, text=True, cwd=ROOT, timeout=600, env=env1)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -559,8 +565,12 @@ def test_bench_two_ranks_on_one_device():
     assert line2["n_gpus"] == 2 and line2["config"]["global_batch"] == 6 and line1["config"]["global_batch"] == 6
     assert line2["mpjpe_vs_synthetic_gt"] == line1["mpjpe_vs_synthetic_gt"]
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                "data", "config", "roofline"):
+                "data", "config", "roofline", "headline_under", "ranks"):
         assert key in line2
+    rk = line2["ranks"]          # per-rank spread and the event-timed exchange step (what the first real SCALE record will carry)
+    assert rk["ms_per_step_min_over_ranks"] <= rk["ms_per_step_max_over_ranks"] == line2["ms_per_step"]
+    assert rk["allgather_ms_per_step_max_over_ranks"] > 0 and rk["allgather_bytes_per_rank"] == 3 * 27 * 17 * 3 * 4
+    assert line1["headline_under"] == "2-stream" and "ranks" not in line1 and "timed_in" in line1["roofline"]
 
 
 def test_bench_rccl_collectives_on_a_one_rank_group():
@@ -602,9 +612,10 @@ def test_bench_graph_flag_times_the_main_leg_under_replay():
         lines.append(json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1]))
     eager, graph = lines
     assert graph["graph_replay"] and "graph_replay" not in eager
+    assert graph["headline_under"] == "2-stream+graph" and eager["headline_under"] == "2-stream"
     assert graph["mpjpe_vs_synthetic_gt"] == eager["mpjpe_vs_synthetic_gt"]
     assert graph["selfcheck_batch_vs_pair_bit_identical"] and graph["roofline"]["frac"] > 0
-    assert graph["roofline"]["kernel"].startswith("whole path")
+    assert graph["roofline"]["kernel"] == eager["roofline"]["kernel"]     # the roofline comes from the separate profiled pass in both
 
 
 def test_c_abi_allgather_on_a_one_rank_rccl_communicator():
