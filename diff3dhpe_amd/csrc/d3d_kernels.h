@@ -53,8 +53,8 @@ __host__ __device__ __forceinline__ size_t pair_col_acc(int c) {
 }
 
 // ---- F16X3 range guard -------------------------------------------------------------------------------------------------
-// An fp16 plane holds 8*x (activations; the q third of a qkv output 1*x) or 4096*w (weights), clamped to +-65504: |x| > 8188
-// or |w| > 15.99 saturates silently.  Every device-side plane writer therefore tracks max |scaled value| per lane and ORs
+// An fp16 plane holds 8*x (activations; the q third of a qkv output 1*x) or 2^k*w (weights; k per matrix, 12 unless a weight
+// exceeds 15.99), clamped to +-65504: |x| > 8188 saturates silently.  Every device-side plane writer therefore tracks max |scaled value| per lane and ORs
 // bit 0 into its translation unit's sticky per-device word when a clamp fired (one atomic per lane that saw one: none in a
 // healthy run).  range_flags_*: read (and optionally clear) the word of the current device; the caller synchronises first.
 constexpr float X3_HALF_MAX = 65504.0f;
@@ -70,11 +70,12 @@ hipError_t launch_linear_f32(const float* A, const float* W, const float* bias, 
 
 // ---- kernels_gemm_f16x3.hip --------------------------------------------------------------------------------------
 // Same contract, fp32-accurate product from 3 fp16 MFMAs; A split on the fly, W in the pair layout made by
-// split_weight_f16x3() ([rows][2*cols] fp16 of 4096*w).
+// split_weight_f16x3() ([rows][2*cols] fp16 of 4096*w: this form takes k = 12 only).
 hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* bias, const float* R, float* C, int M, int N,
                                int K, int epi, hipStream_t s);
-// returns false when a weight left the fp16 range of 4096*w (|w| > 15.99) and was clamped
-bool split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order = false);
+// Planes of 2^k * w, k chosen per matrix: 12 whenever |w| <= 15.99 everywhere, smaller for larger weights (LayerNorm-folded
+// weights of checkpoints with big gains).  Returns k (the GEMM's w_exp argument); *clamped is set when an entry is not finite.
+int split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order = false, bool* clamped = nullptr);
 
 // ---- kernels_gemm_x3p.hip ---------------------------------------------------------------------------------------
 // F16X3 with pre-split operands in the pair layout: A (>= ceil(M/256)*256 rows allocated), W (>= ceil(N/256)*256 rows).
@@ -106,9 +107,10 @@ struct X3Fold {
   X3PostNorm pn;
 };
 bool x3q_postnorm_ok(int N, int K);   // shapes the post-norm form exists for
+// w_exp: the exponent k of the weight planes (split_weight_f16x3): the accumulators are un-scaled by 2^-(3 + w_exp)
 hipError_t launch_linear_x3p(const void* Apair, const void* Wpair, const float* bias, const float* R, float* C, void* Ch,
                              void* Cl, int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s,
-                             const X3Fold* fold = nullptr);
+                             const X3Fold* fold = nullptr, int w_exp = 12);
 int x3q_ntiles(int M, int N);   // statistics partials per row an st_out launch writes
 hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
 hipError_t launch_unsplit_x3(const void* pair, float* x, size_t rows, int cols, const float* part, int np, float* stats,

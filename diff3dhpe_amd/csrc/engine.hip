@@ -51,6 +51,8 @@ struct BlockW {
   // b'[n] = b[n] + sum_k W[n,k] beta[k], for norm1 -> qkv and norm2 -> fc1
   const uint16_t *qkv_f3 = nullptr, *fc1_f3 = nullptr;
   const float *qkv_cs = nullptr, *qkv_fb = nullptr, *fc1_cs = nullptr, *fc1_fb = nullptr;
+  // exponent k of each weight's planes (2^k w; 12 unless a weight exceeds 15.99: split_weight_f16x3)
+  int qkv_e = 12, proj_e = 12, fc1_e = 12, fc2_e = 12, qkv_fe = 12, fc1_fe = 12;
 };
 
 }  // namespace
@@ -63,7 +65,7 @@ struct d3d_engine {
   std::vector<float> freqs_host;
   bool freqs_set = false;
   bool committed = false;
-  bool weights_clamped = false;   // F16X3: a GEMM weight left the fp16 range of 4096*w at commit (range guard)
+  bool weights_clamped = false;   // F16X3: a GEMM weight was not finite at commit (range guard; finite weights get a per-matrix scale)
   // d3d_engine_set_option: the F16X3 block flow with the post-norm inside the fc2 epilogue / with norm1, norm2 folded into
   // the consuming GEMMs (both on by default; experiments/ and the A/B tests switch them off)
   bool opt_fused_postnorm = true, opt_fold_layernorm = true;
@@ -340,16 +342,16 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
-    auto gemm = [&](const uint16_t* A, const uint16_t* W, const float* bias, float* C, uint16_t* Ch, uint16_t* Cl, int outsplit,
+    auto gemm = [&](const uint16_t* A, const uint16_t* W, int wexp, const float* bias, float* C, uint16_t* Ch, uint16_t* Cl, int outsplit,
                     int N, int K, int epi, int qcols, const X3Fold& f) -> hipError_t {
       const int sub = f.st_in ? (epi == EPI_GELU ? D3D_KC_LINEAR_FC1 : D3D_KC_LINEAR_QKV) : (K == D ? D3D_KC_LINEAR_PROJ : D3D_KC_LINEAR_FC2);
       Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s, sub);
-      return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f);
+      return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f, wexp);
     };
     {  // q, k, v planes = norm1(x) Wqkv^T + b   (LayerNorm folded; q third pre-scaled by dh^-0.5)
       X3Fold f{};
       f.st_in = w.ST1; f.st_np = np1; f.csum = bw.qkv_cs; f.eps = 1e-6f;
-      HIP_TRY(gemm(XP, bw.qkv_f3, bw.qkv_fb, nullptr, QKVh, QKVl, 1, 3 * D, D, EPI_NONE, D, f));
+      HIP_TRY(gemm(XP, bw.qkv_f3, bw.qkv_fe, bw.qkv_fb, nullptr, QKVh, QKVl, 1, 3 * D, D, EPI_NONE, D, f));
     }
     TRACE(k, 2, 0, QKVh, 3 * MDb);
     {
@@ -362,14 +364,14 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     {  // x += attn Wproj^T + b, plane to plane in place; row statistics of the new x for the folded norm2
       X3Fold f{};
       f.Rp = XP; f.st_out = w.ST2;
-      HIP_TRY(gemm(AOx, bw.proj_x3, bw.projb, nullptr, XP, nullptr, 2, D, D, EPI_RESIDUAL, 0, f));
+      HIP_TRY(gemm(AOx, bw.proj_x3, bw.proj_e, bw.projb, nullptr, XP, nullptr, 2, D, D, EPI_RESIDUAL, 0, f));
     }
     TRACE(k, 4, 0, XP, MDb);
     TRACE(k, 4, 1, w.ST2, (size_t)M * 8 * np2);
     {  // hidden = gelu(norm2(x) W1^T + b1), LayerNorm folded
       X3Fold f{};
       f.st_in = w.ST2; f.st_np = np2; f.csum = bw.fc1_cs; f.eps = 1e-6f;
-      HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
+      HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fe, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
     }
     TRACE(k, 5, 0, HIDx, (size_t)M * e->Dm * 4);
     const float* pn_g = temporal ? e->tn_g : e->sn_g;
@@ -383,11 +385,11 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       if (!last && tvec) { f.pn.tvec = tvec + (size_t)(k + 1) * D; f.pn.tvec_stride = tvec_stride; }
       if (!last) {
         f.st_out = w.ST1;
-        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, nullptr, XP, nullptr, 2, D, e->Dm, EPI_RESIDUAL, 0, f));
+        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2_e, bw.fc2b, nullptr, XP, nullptr, 2, D, e->Dm, EPI_RESIDUAL, 0, f));
         np1 = np2;
         TRACE(k, 6, 1, w.ST1, (size_t)M * 8 * np2);
       } else {
-        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
+        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2_e, bw.fc2b, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
       }
       TRACE(k, 6, 0, w.X, MDb);
       continue;
@@ -395,7 +397,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     {  // x + hidden W2^T + b2 -> fp32 (w.HN) for the post-norm
       X3Fold f{};
       f.Rp = XP;
-      HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2b, w.HN, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
+      HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2_e, bw.fc2b, w.HN, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
     }
     TRACE(k, 6, 0, w.HN, MDb);
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector] -> planes + statistics (or fp32 at the end)
@@ -442,10 +444,10 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   // A: fp32 activation (FP32 mode) or its pair buffer (F16X3 mode).  outsplit (F16X3 only): 1 = C as hi/lo planes
   // Ch/Cl (qkv -> temporal attention), 2 = C in the pair layout at Ch (fc1 -> fc2 hand-off)
   int qcols_ = 0;
-  auto linear = [&](const float* A, const uint16_t* Ax, const float* W, const uint16_t* Wx, const float* bias, const float* R,
+  auto linear = [&](const float* A, const uint16_t* Ax, const float* W, const uint16_t* Wx, int wexp, const float* bias, const float* R,
                     float* C, uint16_t* Ch_, uint16_t* Cl_, int outsplit, int N, int K, int epi) -> hipError_t {
     Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), s);
-    if (x3) return launch_linear_x3p(Ax, Wx, bias, R, C, Ch_, Cl_, M, N, K, epi, outsplit, qcols_, 0, s);
+    if (x3) return launch_linear_x3p(Ax, Wx, bias, R, C, Ch_, Cl_, M, N, K, epi, outsplit, qcols_, 0, s, nullptr, wexp);
     return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
   };
   auto lnorm = [&](LnArgs a) -> hipError_t {
@@ -468,7 +470,7 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
     uint16_t* QKVh = reinterpret_cast<uint16_t*>(w.QKV);
     uint16_t* QKVl = QKVh + (size_t)M * 3 * D;
     qcols_ = attn_x3 ? D : 0;
-    HIP_TRY(linear(w.HN, HNx, bw.qkvw, bw.qkv_x3, bw.qkvb, nullptr, w.QKV, attn_x3 ? QKVh : nullptr, attn_x3 ? QKVl : nullptr,
+    HIP_TRY(linear(w.HN, HNx, bw.qkvw, bw.qkv_x3, bw.qkv_e, bw.qkvb, nullptr, w.QKV, attn_x3 ? QKVh : nullptr, attn_x3 ? QKVl : nullptr,
                    attn_x3 ? 1 : 0, 3 * D, D, EPI_NONE));
     qcols_ = 0;
     {
@@ -482,16 +484,16 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
         if (rc) return rc;
       }
     }
-    HIP_TRY(linear(w.HN, HNx, bw.projw, bw.proj_x3, bw.projb, w.X, w.X, nullptr, nullptr, 0, D, D, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HN, HNx, bw.projw, bw.proj_x3, bw.proj_e, bw.projb, w.X, w.X, nullptr, nullptr, 0, D, D, EPI_RESIDUAL));
     {  // h = norm2(x)
       LnArgs a{};
       a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       HIP_TRY(lnorm(a));
     }
-    HIP_TRY(linear(w.HN, HNx, bw.fc1w, bw.fc1_x3, bw.fc1b, nullptr, w.HID, x3 ? HIDx : nullptr, nullptr, x3 ? 2 : 0, e->Dm, D,
+    HIP_TRY(linear(w.HN, HNx, bw.fc1w, bw.fc1_x3, bw.fc1_e, bw.fc1b, nullptr, w.HID, x3 ? HIDx : nullptr, nullptr, x3 ? 2 : 0, e->Dm, D,
                    EPI_GELU));
-    HIP_TRY(linear(w.HID, HIDx, bw.fc2w, bw.fc2_x3, bw.fc2b, w.X, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL));
+    HIP_TRY(linear(w.HID, HIDx, bw.fc2w, bw.fc2_x3, bw.fc2_e, bw.fc2b, w.X, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL));
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = next.norm1(x)
       LnArgs a{};
       a.x = w.X; a.y = w.X;
@@ -683,20 +685,20 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     size_t o = 0;
     for (int k = 0; k < e->nblk; ++k) {
       const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2);
-      auto pair = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& dst, bool acc_order = false) {
+      auto pair = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& dst, int& wexp, bool acc_order = false) {
         const WeightSlot& ws = e->slots[e->index[name]];
-        if (!split_weight_f16x3(ws.host.data(), rows, cols, host.data() + o, acc_order)) e->weights_clamped = true;
+        wexp = split_weight_f16x3(ws.host.data(), rows, cols, host.data() + o, acc_order, &e->weights_clamped);
         dst = e->arena16 + o;
         o += 2 * pad256(rows) * cols;
       };
       BlockW& b = e->blk[k];
-      pair(p + ".attn.qkv.weight", 3 * D, D, b.qkv_x3);
-      pair(p + ".attn.proj.weight", D, D, b.proj_x3);
-      pair(p + ".mlp.fc1.weight", Dm, D, b.fc1_x3);
-      pair(p + ".mlp.fc2.weight", D, Dm, b.fc2_x3, true);   // its A operand (the hidden activation) is in accumulator order
+      pair(p + ".attn.qkv.weight", 3 * D, D, b.qkv_x3, b.qkv_e);
+      pair(p + ".attn.proj.weight", D, D, b.proj_x3, b.proj_e);
+      pair(p + ".mlp.fc1.weight", Dm, D, b.fc1_x3, b.fc1_e);
+      pair(p + ".mlp.fc2.weight", D, Dm, b.fc2_x3, b.fc2_e, true);   // its A operand (the hidden activation) is in accumulator order
       // LayerNorm folded into the consuming GEMM: LN(x) W^T + b = rstd (x (W diag g)^T) - rstd mean csum + (b + W beta)
       auto folded = [&](const std::string& wname, const std::string& bname, const std::string& norm, size_t rows, size_t cols,
-                        const uint16_t*& w3, const float*& cs, const float*& fb) {
+                        const uint16_t*& w3, const float*& cs, const float*& fb, int& wexp) {
         const std::vector<float>& W = e->slots[e->index[wname]].host;
         const std::vector<float>& bb = e->slots[e->index[bname]].host;
         const std::vector<float>& g = e->slots[e->index[norm + ".weight"]].host;
@@ -713,15 +715,15 @@ int d3d_engine_commit_weights(d3d_engine* e) {
           fold[fo + r] = (float)c;
           fold[fo + rows + r] = (float)bsum;
         }
-        if (!split_weight_f16x3(wg.data(), rows, cols, host.data() + o)) e->weights_clamped = true;
+        wexp = split_weight_f16x3(wg.data(), rows, cols, host.data() + o, false, &e->weights_clamped);
         w3 = e->arena16 + o;
         o += 2 * pad256(rows) * cols;
         cs = e->arena_fold + fo;
         fb = e->arena_fold + fo + rows;
         fo += 2 * rows;
       };
-      folded(p + ".attn.qkv.weight", p + ".attn.qkv.bias", p + ".norm1", 3 * D, D, b.qkv_f3, b.qkv_cs, b.qkv_fb);
-      folded(p + ".mlp.fc1.weight", p + ".mlp.fc1.bias", p + ".norm2", Dm, D, b.fc1_f3, b.fc1_cs, b.fc1_fb);
+      folded(p + ".attn.qkv.weight", p + ".attn.qkv.bias", p + ".norm1", 3 * D, D, b.qkv_f3, b.qkv_cs, b.qkv_fb, b.qkv_fe);
+      folded(p + ".mlp.fc1.weight", p + ".mlp.fc1.bias", p + ".norm2", Dm, D, b.fc1_f3, b.fc1_cs, b.fc1_fb, b.fc1_fe);
     }
     HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->arena_fold, fold.data(), fold.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1201,6 +1203,7 @@ namespace {
 // the host with the same routine the engine uses at commit; activations on the device with the producers' split.
 struct TmpPair {
   uint16_t* dev = nullptr;
+  int wexp = 12;
   ~TmpPair() { (void)hipFree(dev); }
 };
 int make_pair(TmpPair& t, const float* src_dev, int rows, int cols, bool weight, hipStream_t s) {
@@ -1213,7 +1216,7 @@ int make_pair(TmpPair& t, const float* src_dev, int rows, int cols, bool weight,
     std::vector<uint16_t> pr(2 * h.size());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpy(h.data(), src_dev, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-    split_weight_f16x3(h.data(), rows, cols, pr.data());
+    t.wexp = split_weight_f16x3(h.data(), rows, cols, pr.data());
     HIP_TRY(hipMemcpy(t.dev, pr.data(), pr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else {
     HIP_TRY(launch_split_x3(src_dev, t.dev, (size_t)rows, cols, s));
@@ -1245,8 +1248,8 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
   }
   auto once = [&]() -> hipError_t {
     if (precision == D3D_PREC_FP32) return launch_linear_f32(A, W, bias, R, C, M, N, K, epi, s);
-    if (variant == 9) return launch_linear_f16x3(A, wp.dev, bias, R, C, M, N, K, epi, s);   // on-the-fly A split
-    return launch_linear_x3p(ap.dev, wp.dev, bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s);
+    if (variant == 9) return wp.wexp == 12 ? launch_linear_f16x3(A, wp.dev, bias, R, C, M, N, K, epi, s) : hipErrorInvalidValue;   // on-the-fly A split
+    return launch_linear_x3p(ap.dev, wp.dev, bias, R, C, nullptr, nullptr, M, N, K, epi, 0, 0, variant, s, nullptr, wp.wexp);
   };
   HIP_TRY(once());
   if (g_opt_gemm_diag && precision == D3D_PREC_F16X3 && (variant == 13)) {
@@ -1357,8 +1360,8 @@ int d3d_op_linear_postnorm(const float* A, const float* W, const float* bias, co
   f.pn.tvec = tvec; f.pn.tvec_stride = tvec_stride; f.pn.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
   f.st_out = part;
   auto once = [&]() -> hipError_t {
-    if (stats) return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, nullptr, yp.dev, nullptr, M, N, K, EPI_RESIDUAL, 2, 0, 0, s, &f);
-    return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, Y, nullptr, nullptr, M, N, K, EPI_RESIDUAL, 0, 0, 0, s, &f);
+    if (stats) return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, nullptr, yp.dev, nullptr, M, N, K, EPI_RESIDUAL, 2, 0, 0, s, &f, wp.wexp);
+    return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, Y, nullptr, nullptr, M, N, K, EPI_RESIDUAL, 0, 0, 0, s, &f, wp.wexp);
   };
   hipError_t le = once();
   if (le == hipSuccess && avg_ms) {

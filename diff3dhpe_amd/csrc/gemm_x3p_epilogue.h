@@ -97,7 +97,8 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-struct X3Tail {            // per-launch extras of the folded forms (device copy of X3Fold + derived)
+struct X3Tail {            // per-launch extras (device copy of X3Fold + derived)
+  float out_scale;         // 2^-(3 + k): un-scales the accumulators (A planes hold 8 a, W planes 2^k w; k = 12 unless |w| > 15.99)
   const float* st_in; int st_np; const float* csum; float eps;
   const _Float16* Rp;
   float* st_out;
@@ -109,7 +110,7 @@ template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
                                              const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
                                              const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
-                                             int M, int N, int qcols, int gl, int gh) {
+                                             int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE) {
   // [gl, gh): the wave's m-tiles that are computed (all of them except in a split tail tile, x3q_tile)
   // patch: two wave-private 16 rows x 64 floats (alternating, so the LDS round trip of one m-tile overlaps the stores
   // of the previous one), 16-byte chunks XOR-swizzled by (row & 7)
@@ -243,7 +244,7 @@ template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
                                               float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
                                               const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
-                                              int M, int N, int qcols, int gl, int gh) {
+                                              int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE) {
   static_assert(EPI != EPI_RESIDUAL || (FX & FX_RP), "the 8-column epilogue takes its residual from planes");
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
@@ -372,7 +373,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
 template <int TM, int WM, int WN, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned char* lds_x, const float* __restrict__ bias,
                                                  _Float16* Cht, const float* __restrict__ csum, int mt0, int nt0, int rbase, int lane,
-                                                 int M, int N, int gl, int gh) {
+                                                 int M, int N, int gl, int gh, const float P_OUT_SCALE) {
   const int m16 = lane & 15, q4 = lane >> 4;
   f2 bb[4][2], cs[4][2];
 #pragma unroll
@@ -446,6 +447,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
                                                 float* Ct, _Float16* Cht, const _Float16* Rpt, const X3Tail& fx, int mt0, int nt0,
                                                 int wn, int lane, int M, int N, int gl, int gh) {
   static_assert(WN == 8, "row partials are read back as four float4");
+  const float P_OUT_SCALE = fx.out_scale;
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
   const int n = nt0 + 8 * rc8;

@@ -15,6 +15,7 @@
 // (A_hi, A_lo, W_hi, W_lo), 128 rows x 64 B each, 16-byte chunks XOR-swizzled by (row>>2)&3 so that every
 // ds_read_b128 16-lane group touches 16 distinct 4-bank slots.  A is split hi/lo on the fly while it is staged
 // (fp32 global -> registers -> fp16 LDS); the staging loads of k-tile t+1 are issued before the MFMAs of k-tile t.
+#include <math.h>
 #include "d3d_kernels.h"
 
 namespace d3d {
@@ -212,11 +213,26 @@ hipError_t launch_linear_f16x3(const float* A, const void* Wpair, const float* b
 // (round-to-nearest-even both times).
 // acc_order: the k index of every 32-column group is stored in the order pair_slot_acc() gives it (the layout of the
 // hidden activation that the fc1 epilogue writes straight from its accumulators, kernels_gemm_x3p.hip)
-bool split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order) {
-  bool in_range = true;
+int split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair, bool acc_order, bool* clamped) {
+  // per-matrix scale 2^k: 2^12 whenever the matrix fits (|w| <= 15.99: every matrix of a sane checkpoint -- then the planes are
+  // bit for bit what a fixed 4096 gives), smaller when a weight is larger -- LayerNorm-FOLDED weights W diag(gamma) of a
+  // checkpoint with big gains get there (gamma 6 x |w| 8 = 48).  The GEMM un-scales by 2^-(3+k) (X3Tail::out_scale); powers of
+  // two, so nothing rounds differently.  Small entries whose lo half then falls into fp16 denormals lose bits below
+  // 2^-24 2^-k: < 1e-9 absolute at k >= 5.
+  float amax = 0.0f;
+  bool finite = true;
+  for (size_t i = 0; i < rows * cols; ++i) {
+    const float a = fabsf(w[i]);
+    if (!(a <= 3.0e38f)) finite = false;
+    else if (a > amax) amax = a;
+  }
+  int k = 12;
+  while (k > -14 && ldexpf(amax, k) > 65504.0f) --k;
+  const float scale = ldexpf(1.0f, k);
+  bool in_range = finite;
   for (size_t r = 0; r < rows; ++r)
     for (size_t c = 0; c < cols; ++c) {
-      float s = w[r * cols + c] * 4096.0f;
+      float s = w[r * cols + c] * scale;
       if (!(s <= 65504.0f && s >= -65504.0f)) in_range = false;
       if (s > 65504.0f) s = 65504.0f;
       if (s < -65504.0f) s = -65504.0f;
@@ -226,7 +242,8 @@ bool split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair
       __builtin_memcpy(o, &h, 2);
       __builtin_memcpy(o + PAIR_LO, &l, 2);
     }
-  return in_range;
+  if (clamped && !in_range) *clamped = true;
+  return k;
 }
 
 }  // namespace d3d

@@ -37,7 +37,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int PBK = 32;                          // k-tile depth (fp16 elements)
-constexpr float P_OUT_SCALE = 1.0f / 32768.0f;   // 2^-(3+12)
 constexpr float P_A_SCALE = 8.0f;
 
 // F16X3 range guard (d3d_kernels.h): every plane writer tracks max |scaled value| per lane; a lane whose value left the fp16
@@ -501,37 +500,37 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   } else if constexpr (EPI == EPI_GELU && OUTSPLIT == 2) {   // hidden activation, accumulator order: no transpose
     static_assert(!(FX & (FX_RP | FX_SO)), "fc1 form");
     if constexpr (FULL)
-      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
+      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale);
     else if (full)
-      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
+      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale);
     else
-      x3q_epilogue_acc<TM, WM, WN, FX, true>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh);
+      x3q_epilogue_acc<TM, WM, WN, FX, true>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale);
     done = true;
   } else if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
     if ((N & 7) == 0) {
       // (the row-statistics form keeps one copy per instantiation: with two copies under the branch its accumulators spill)
       if constexpr (FULL)
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                           mt0 - m0, lane, M, N, qcols, gl, gh);
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
       else if (full && !(FX & FX_SO))
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                           mt0 - m0, lane, M, N, qcols, gl, gh);
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
       else
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                          mt0 - m0, lane, M, N, qcols, gl, gh);
+                                                          mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
       done = true;
     }
   }
   if (!done) {
     if constexpr (FULL)
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh);
+                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
     else if (full)
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh);
+                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
     else
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                       nt0, mt0 - m0, lane, M, N, qcols, gl, gh);
+                                                       nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
   }
   if (diag) {
     __builtin_amdgcn_s_waitcnt(0);   // the wave's own stores issued and acknowledged
@@ -680,12 +679,13 @@ static X3Walk x3q_walk(int tiles, int grid) {
 template <int TM, int WM, int WN>
 static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
                              _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
-                             unsigned long long* diag = nullptr, const X3Fold* fold = nullptr) {
+                             unsigned long long* diag = nullptr, const X3Fold* fold = nullptr, int w_exp = 12) {
   constexpr int BM = 16 * TM * WM, BN = 64 * WN;
   const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
   size_t lds_bytes = 2 * (size_t)((BM + BN) * 128);
   X3Tail tail{};
+  tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
   int fx = 0;
   if (fold) {
     if (fold->st_in) fx |= FX_LNF;
@@ -732,7 +732,7 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
 // landed.  D3D_QKTILE now states the wait itself.
 static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C,
                                      _Float16* Ch, _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols,
-                                     hipStream_t s, const X3Fold* fold) {
+                                     hipStream_t s, const X3Fold* fold, int w_exp) {
   const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
   const int tiles = mtiles * ntiles;
   int n_cu = device_cu_count() / 8 * 8;   // (per device)
@@ -742,6 +742,7 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
   const X3Walk wk = x3q_walk(tiles, grid);
   size_t lds_bytes = 2 * (size_t)(512 * 128);
   X3Tail tail{};
+  tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
   int fx = 0;
   if (fold) {
     if (fold->st_in) fx |= FX_LNF;
@@ -783,7 +784,7 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
 bool x3q_postnorm_ok(int N, int K) { return N == 512 && K % PBK == 0; }
 
 static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const float* bias, float* C, _Float16* Ch, int M, int N,
-                                int K, int outsplit, hipStream_t s, const X3Fold* fold) {
+                                int K, int outsplit, hipStream_t s, const X3Fold* fold, int w_exp) {
   if (!x3q_postnorm_ok(N, K) || !fold->Rp || !fold->pn.b || !bias || (outsplit == 2 ? (!Ch || !fold->st_out) : !C))
     return hipErrorInvalidValue;
   if (outsplit != 0 && outsplit != 2) return hipErrorInvalidValue;
@@ -800,6 +801,7 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
   const int mtiles64 = (M + 63) / 64, vtiles64 = ((mtiles64 + 7) / 8) * 8;
   const size_t lds_small = 2 * (size_t)((64 + 512) * 128);
   X3Tail tail{};
+  tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
   tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out; tail.pn = fold->pn;
   const int qcols = 0;
   unsigned long long* diag = nullptr;
@@ -841,11 +843,11 @@ int x3q_ntiles(int M, int N) { (void)M; return (N + 63) / 64; }   // statistics 
 
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
                                   _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols,
-                                  hipStream_t s, const X3Fold* fold) {
+                                  hipStream_t s, const X3Fold* fold, int w_exp) {
   if (x3q_big(M, N) && (K / PBK) % 2 == 0)
-    return launch_x3q_persist(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold);
-  if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold);
-  return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold);
+    return launch_x3q_persist(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold, w_exp);
+  if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
+  return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
 }
 
 void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }
@@ -861,7 +863,8 @@ hipError_t range_flags_gemm(unsigned* flags, bool clear) {
 // 13 = 256x256 (with the per-wave diagnostic stamps when set_linear_x3_diag() armed them), 4 = 256x128
 hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias, const float* R, float* C, void* Ch, void* Cl,
                              int M, int N, int K, int epi, int outsplit, int qcols, int variant, hipStream_t s,
-                             const X3Fold* fold) {
+                             const X3Fold* fold, int w_exp) {
+  if (w_exp < -14 || w_exp > 12) return hipErrorInvalidValue;
   if (M <= 0 || N <= 0 || K <= 0 || (K % PBK) != 0 || (N % 4) != 0) return hipErrorInvalidValue;
   if (epi == EPI_RESIDUAL && R == nullptr && !(fold && fold->Rp)) return hipErrorInvalidValue;
   if (fold && variant != 0) return hipErrorInvalidValue;
@@ -870,12 +873,12 @@ hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias
   _Float16 *ch = (_Float16*)Ch, *cl = (_Float16*)Cl;
   if (fold && fold->pn.g) {
     if (epi != EPI_RESIDUAL) return hipErrorInvalidValue;
-    return launch_x3q_pn(ap, wp, bias, C, ch, M, N, K, outsplit, s, fold);
+    return launch_x3q_pn(ap, wp, bias, C, ch, M, N, K, outsplit, s, fold, w_exp);
   }
   switch (variant) {
-    case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold);
-    case 13: return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, g_x3_diag);
-    case 4: return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s);
+    case 0: return launch_x3q_auto(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold, w_exp);
+    case 13: return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, g_x3_diag, nullptr, w_exp);
+    case 4: return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, nullptr, w_exp);
     default: return hipErrorInvalidValue;
   }
 }

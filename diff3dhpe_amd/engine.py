@@ -168,10 +168,10 @@ class Engine:
         return int(f.value)
 
     def check_range(self) -> None:
-        """Raise D3DError if an F16X3 operand left the fp16 range since the last check (use precision='fp32' then)."""
+        """Raise D3DError if the F16X3 range guard fired since the last check (use precision='fp32' then)."""
         f = self.range_flags(clear=True)
         if f:
-            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a GEMM weight (|w| > 15.99)"),
+            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a non-finite GEMM weight"),
                                    (_lib.RANGE_STATS, "a LayerNorm input row with |mean| > 16 standard deviations (one-pass statistics)"))
                     if f & b]
             raise _lib.D3DError("F16X3 operand range exceeded by " + " and ".join(what) +

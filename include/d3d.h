@@ -183,11 +183,13 @@ int d3d_engine_profile_read(d3d_engine* e, int32_t kernel_class, double* total_m
 const char* d3d_kernel_class_name(int32_t kernel_class);
 
 /* ---- F16X3 range guard.  The F16X3 operand planes hold fp16 (hi, lo) pairs of 8*x (activations: residual stream, q/k/v,
- * attention output, MLP hidden) and 4096*w (GEMM weights); values beyond the fp16 range are clamped: |x| > 8188, |w| > 15.99.
+ * attention output, MLP hidden) and 2^k*w (GEMM weights; k is chosen per matrix at commit: 12 unless an entry exceeds 15.99 --
+ * LayerNorm-folded weights W diag(gamma) of checkpoints with large gains -- then smaller, nothing is clamped); activations
+ * beyond the fp16 range are clamped: |x| > 8188.
  * Every kernel that writes such planes raises a sticky per-device flag when its clamp fired (no cost in a healthy run), and
  * d3d_engine_commit_weights notes clamped weights.  d3d_engine_range_flags synchronises `stream` and returns
  *   D3D_RANGE_ACT    an activation was clamped on this device since the flag was last cleared (any engine of the process)
- *   D3D_RANGE_WEIGHT a weight of this engine was clamped at commit
+ *   D3D_RANGE_WEIGHT a GEMM weight of this engine was not finite at commit
  *   D3D_RANGE_STATS  a LayerNorm folded into a GEMM met a row with |mean| > 16 standard deviations: the folded form works from
  *                    one-pass row statistics (sum, sum of squares), whose variance loses accuracy like eps (1 + mean^2 / var)
  *                    -- beyond ~25 sigma the 1e-4 parity gate is no longer guaranteed (post-norm biases that dwarf the gains)
