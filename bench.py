@@ -145,6 +145,36 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
                             "whole_step_tflops": round(flops_per_seq_step(T) * S * v32 / 1e12, 2),
                             "frac_of_fp32_mfma_peak": round(flops_per_seq_step(T) * S * v32 / 1e12 / PEAK_TFLOPS["fp32"], 4),
                             "note": "exact-fp32 companion (D3D_PREC_FP32), whole path against the 157.3 TFLOP/s fp32 MFMA peak"}
+    if a.precision == "f16x3":
+        # bf16 operand mode (BASELINE configs[1] names it): SECOND-CLASS -- narrower than the reference's fp32, it cannot meet the
+        # 1e-4 gate and is never the headline; reported with its distance to the default precision on this very batch
+        y_ref = eng.ddim_sample(x2d, noise)
+        net.precision = "bf16"
+        eb = diff._engine(dev)
+        eb.set_option("streams", a.streams)
+        tb, yb = timed(lambda: eb.ddim_sample(x2d, noise), n=2)
+        eb.set_option("streams", 1)
+        eb.profile_reset()
+        eb.set_profiling(True)
+        eb.ddim_sample(x2d, noise)
+        torch.cuda.synchronize(dev)
+        eb.set_profiling(False)
+        pb = eb.profile_read()
+        net.precision = a.precision
+        vb = Bl / tb
+        lin = pb["linear"]
+        out["bf16_mode"] = {"value": round(vb, 3), "unit": "pose-seq/s", "ms_per_step": round(tb * 1e3, 3),
+                            "whole_step_tflops": round(flops_per_seq_step(T) * S * vb / 1e12, 2),
+                            "frac_of_bf16_mfma_peak": round(flops_per_seq_step(T) * S * vb / 1e12 / PEAK_TFLOPS["bf16"], 4),
+                            "gemm_tflops": round(lin["flops"] / (lin["ms"] * 1e-3) / 1e12, 1) if lin["ms"] else None,
+                            "by_kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in pb.items() if v["launches"] and not k.startswith("linear_")},
+                            "by_gemm_avg_launch_ms": {k[7:]: round(v["ms"] / v["launches"], 4) for k, v in pb.items() if k.startswith("linear_") and v["launches"]},
+                            "vs_default_precision_on_this_batch": {
+                                "max_abs": round(float((yb - y_ref).abs().max()), 5),
+                                "mpjpe_normalised": round(float((yb - y_ref).norm(dim=-1).mean()), 6)},
+                            "note": "D3D_PREC_BF16: bf16 operands for the block GEMMs and both attention products (one MFMA per product), "
+                                    "fp32 residual stream / LayerNorm / softmax / DDIM update; second-class precision -- gated against the "
+                                    "oracle's bf16-operand emulation (tests/test_gpu_bf16.py), NOT against the 1e-4 gate; never the headline"}
     return out
 
 
@@ -367,9 +397,13 @@ def main():
         if rank_stats:
             line["ranks"] = rank_stats
         if a.precision == "f16x3":
-            line["precision_note"] = ("f16x3 = fp32-accurate arithmetic from three fp16 MFMAs per product (same 1e-4 parity gate as fp32); "
-                                      "it also serves BASELINE configs[1], whose 'bf16' cannot meet that gate (SURVEY appendix B) "
-                                      "and is not implemented -- no number of this repository is a bf16 number")
+            line["precision_note"] = ("f16x3 = fp32-accurate arithmetic from three fp16 MFMAs per product (same 1e-4 parity gate as fp32): "
+                                      "the headline precision.  BASELINE configs[1]'s bf16 exists as a second-class mode (--precision bf16, "
+                                      "'bf16_mode' companion object): it cannot meet the 1e-4 gate (SURVEY appendix B) and is never the headline")
+        if a.precision == "bf16":
+            line["precision_note"] = ("bf16 = SECOND-CLASS precision, narrower than the reference's fp32: bf16 operands for the block GEMMs and "
+                                      "attention products; fails the 1e-4 parity gate by design (gated against the oracle's bf16-operand "
+                                      "emulation instead).  Not a headline number.")
         if a.graph:
             line["graph_replay"] = True
         if not d["ms"]:

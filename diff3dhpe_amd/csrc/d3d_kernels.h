@@ -115,6 +115,13 @@ int x3q_ntiles(int M, int N);   // statistics partials per row an st_out launch 
 hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hipStream_t s);
 hipError_t launch_unsplit_x3(const void* pair, float* x, size_t rows, int cols, const float* part, int np, float* stats,
                              hipStream_t s);   // op hooks only
+// bf16 operand mode (D3D_PREC_BF16): A / W plain bf16 rows (K % 64 == 0, rows padded as above), one bf16 MFMA per product, fp32
+// accumulate.  EPI_NONE / EPI_GELU write Cb = bf16 [M][N] (columns < qcols scaled by 2^-3), EPI_RESIDUAL writes fp32 C = R + ...
+hipError_t launch_linear_bf16(const void* A, const void* W, const float* bias, const float* R, float* C, void* Cb, int M, int N,
+                              int K, int epi, int qcols, hipStream_t s);
+hipError_t launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t s);
+hipError_t launch_bf16_to_f32(const void* x, float* y, size_t n, hipStream_t s);
+hipError_t launch_scale_cols(float* x, size_t rows, int cols, int ncols_scaled, float f, hipStream_t s);   // op hooks only
 // diagnostic launches (variant 13): per (workgroup, wave) six u64 stamps {clk, 100 MHz} x {start, k-loop end, end}
 void set_linear_x3_diag(unsigned long long* dev_buf);
 void attn_x3_diag_report();   // -DD3D_ATTN_DIAG_BUILD builds only: prints the step stamps of the last staggered temporal-attention launch
@@ -129,6 +136,7 @@ struct LnArgs {
   float* h;          // nullable
   void* h_x3;        // nullable: when set, h is written in the F16X3 pair layout (8*h, D % 32 == 0) instead of fp32
                      //           (h itself may then be nullptr)
+  void* h_bf16;      // nullable: when set, h is written as plain bf16 rows (operand of a bf16-mode GEMM) instead of fp32
   const float* g1; const float* b1; float eps1;
   const float* g2; const float* b2; float eps2;
   const float* pos;  // nullable, (pos_mod, D)
@@ -206,6 +214,11 @@ bool attn_temporal_x3_ok(int T, int D, int H);
 hipError_t launch_split_qkv(const float* x, void* hi, void* lo, size_t rows, int D, hipStream_t s);
 hipError_t launch_unsplit_pair(const void* pair, float* x, size_t rows, int cols, hipStream_t s);
 bool attn_spatial_fast_ok(int J, int D, int H);
+// ---- kernels_attn_bf16.hip: the same core on v_mfma_f32_32x32x16_bf16, one MFMA per product (D3D_PREC_BF16).  qkv: ONE bf16
+// buffer [rows][3D] (q third pre-scaled by dh^-0.5, written by launch_linear_bf16 with qcols = D); out: bf16 [rows][D].
+// Spatial blocks: call with (B * T, J, 1).  softmax - I is normalised and rounded to bf16 before the second product.
+hipError_t launch_attn_bf16(const void* qkv_bf16, void* out_bf16, int B, int T, int J, int D, int H, hipStream_t s);
+bool attn_bf16_ok(int T, int D, int H);
 bool attn_temporal_fast_ok(int T, int D, int H);
 
 }  // namespace d3d

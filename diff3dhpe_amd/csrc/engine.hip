@@ -420,6 +420,74 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   return D3D_OK;
 }
 
+// bf16 operand mode (D3D_PREC_BF16; SURVEY section 7 step 5, BASELINE configs[1]): the block GEMMs and both attention products take
+// bf16 operands (one MFMA per product); the residual stream, LayerNorm / softmax statistics, GELU, time vectors, embedding and
+// head stay fp32.  Operand roundings sit exactly where the oracle's bf16-operand emulation puts them: LN output -> bf16 (row
+// kernel), q / k / v -> bf16 (qkv epilogue), softmax - I -> bf16 (attention kernel), attention output -> bf16, GELU output ->
+// bf16 (fc1 epilogue), weights -> bf16 (commit).  Same op sequence as run_blocks (S2S:222-247, 111-135); leaves the final
+// Temporal_norm output as fp32 in w.X.  Not fused further on purpose: it is measured first.
+int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast, const float* tvec, int64_t tvec_stride, int B,
+                    const Workspace& w, hipStream_t s) {
+  const int T = e->T, J = e->J, D = e->D;
+  const int M = B * T * J;
+  const double MD4 = (double)M * D * 4.0, MD2 = (double)M * D * 2.0;
+  uint16_t* HNb = reinterpret_cast<uint16_t*>(w.HN);     // bf16 [Mp][D]: LayerNorm output, then the attention output
+  uint16_t* QKVb = reinterpret_cast<uint16_t*>(w.QKV);   // bf16 [M][3D]
+  uint16_t* HIDb = reinterpret_cast<uint16_t*>(w.HID);   // bf16 [Mp][Dm]
+  {
+    Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
+    HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.X, B, T, J, D, e->cfg.in_chans, y_bcast, s));
+  }
+  auto linear = [&](const uint16_t* A, const uint16_t* W, const float* bias, const float* R, float* C, uint16_t* Cb, int N, int K, int epi,
+                    int qcols, int sub) -> hipError_t {
+    Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 2.0 * ((double)M * K + (double)N * K) + (double)M * N * (R ? 8.0 : 2.0), s, sub);
+    return launch_linear_bf16(A, W, bias, R, C, Cb, M, N, K, epi, qcols, s);
+  };
+  auto lnorm = [&](LnArgs a) -> hipError_t {
+    Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + (a.y ? 1 : 0)) + MD2, s);
+    return launch_layernorm(a, s);
+  };
+  {  // h = bf16(norm1_0(x))
+    LnArgs a{};
+    a.x = w.X; a.h_bf16 = HNb; a.g1 = e->blk[0].n1g; a.b1 = e->blk[0].n1b; a.eps1 = 1e-6f;
+    a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+    HIP_TRY(lnorm(a));
+  }
+  for (int k = 0; k < e->nblk; ++k) {
+    const BlockW& bw = e->blk[k];
+    const bool temporal = (k & 1) != 0;
+    HIP_TRY(linear(HNb, bw.qkv_x3, bw.qkvb, nullptr, nullptr, QKVb, 3 * D, D, EPI_NONE, D, D3D_KC_LINEAR_QKV));
+    {
+      const int N = temporal ? T : J;
+      Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD2, s);
+      if (temporal) HIP_TRY(launch_attn_bf16(QKVb, HNb, B, T, J, D, e->H, s));
+      else HIP_TRY(launch_attn_bf16(QKVb, HNb, B * T, J, 1, D, e->H, s));
+    }
+    HIP_TRY(linear(HNb, bw.proj_x3, bw.projb, w.X, w.X, nullptr, D, D, EPI_RESIDUAL, 0, D3D_KC_LINEAR_PROJ));
+    {  // h = bf16(norm2(x))
+      LnArgs a{};
+      a.x = w.X; a.h_bf16 = HNb; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
+      a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+      HIP_TRY(lnorm(a));
+    }
+    HIP_TRY(linear(HNb, bw.fc1_x3, bw.fc1b, nullptr, nullptr, HIDb, e->Dm, D, EPI_GELU, 0, D3D_KC_LINEAR_FC1));
+    HIP_TRY(linear(HIDb, bw.fc2_x3, bw.fc2b, w.X, w.X, nullptr, D, e->Dm, EPI_RESIDUAL, 0, D3D_KC_LINEAR_FC2));
+    {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = bf16(next.norm1(x))
+      LnArgs a{};
+      a.x = w.X; a.y = w.X;
+      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = 1e-6f;
+      a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+      if (k == 0) { a.pos = e->tpos; a.pos_div = J; a.pos_mod = T; }
+      if (k + 1 < e->nblk) {
+        if (tvec) { a.tvec = tvec + (size_t)(k + 1) * D; a.tvec_stride = tvec_stride; }
+        a.h_bf16 = HNb; a.g2 = e->blk[k + 1].n1g; a.b2 = e->blk[k + 1].n1b; a.eps2 = 1e-6f;
+      }
+      HIP_TRY(lnorm(a));
+    }
+  }
+  return D3D_OK;
+}
+
 // One denoiser forward up to (not including) the head: leaves the final Temporal_norm output in w.X.
 // tvec: (n, nblk, D) time-embedding table slice or nullptr; tvec_stride = 0 (all rows share entry 0) or nblk*D.
 int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, const float* tvec, int64_t tvec_stride,
@@ -430,6 +498,7 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   if (e->cfg.precision == D3D_PREC_F16X3 && attn_temporal_x3_ok(T, D, e->H) && attn_temporal_x3_ok(J, D, e->H) && D % 32 == 0 &&
       e->opt_fold_layernorm)
     return run_blocks_fold(e, x2d, y, y_bcast, tvec, tvec_stride, B, w, s);
+  if (e->cfg.precision == D3D_PREC_BF16) return run_blocks_bf16(e, x2d, y, y_bcast, tvec, tvec_stride, B, w, s);
   {
     Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
     HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.X, B, T, J, D, e->cfg.in_chans,
@@ -586,8 +655,12 @@ int d3d_engine_create(const d3d_config* c, d3d_engine** out) {
     const int dh = c->embed_dim / c->num_heads;
     if (dh != 4 && dh != 8 && dh != 16 && dh != 32 && dh != 64) return fail(D3D_EUNSUP, "head_dim must be 4,8,16,32 or 64");
   }
-  if (c->precision != D3D_PREC_FP32 && c->precision != D3D_PREC_F16X3)
-    return fail(D3D_EUNSUP, "precision must be D3D_PREC_FP32 or D3D_PREC_F16X3 in this build");
+  if (c->precision != D3D_PREC_FP32 && c->precision != D3D_PREC_F16X3 && c->precision != D3D_PREC_BF16)
+    return fail(D3D_EUNSUP, "precision must be D3D_PREC_FP32, D3D_PREC_F16X3 or D3D_PREC_BF16");
+  if (c->precision == D3D_PREC_BF16 &&
+      (!attn_bf16_ok(c->num_frame, c->embed_dim, c->num_heads) || !attn_bf16_ok(c->num_joints, c->embed_dim, c->num_heads) ||
+       c->num_joints > 32 || c->embed_dim % 64 || c->mlp_hidden % 64))
+    return fail(D3D_EUNSUP, "D3D_PREC_BF16 needs head_dim 64, num_frame <= 256, num_joints <= 32 and widths that are multiples of 64");
   d3d_engine* e = new d3d_engine();
   e->cfg = *c;
   e->T = c->num_frame; e->J = c->num_joints; e->D = c->embed_dim; e->H = c->num_heads; e->Dm = c->mlp_hidden;
@@ -727,6 +800,41 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     }
     HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->arena_fold, fold.data(), fold.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (e->cfg.precision == D3D_PREC_BF16) {
+    // bf16 copies (round to nearest even, as torch's .to(bfloat16) and v_cvt_pk_bf16_f32) of the four GEMM weights of every
+    // block, [rows padded to 256][K]: the staging of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
+    const size_t D = e->D, Dm = e->Dm;
+    auto pad256 = [](size_t n) { return (n + 255) / 256 * 256; };
+    const size_t per_blk = pad256(3 * D) * D + pad256(D) * D + pad256(Dm) * D + pad256(D) * Dm;
+    std::vector<uint16_t> host(per_blk * e->nblk, 0);
+    if (e->arena16) { (void)hipFree(e->arena16); e->arena16 = nullptr; }
+    HIP_TRY(hipMalloc(&e->arena16, host.size() * sizeof(uint16_t)));
+    auto rne = [](float f) -> uint16_t {
+      uint32_t u;
+      memcpy(&u, &f, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);     // NaN stays NaN
+      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    size_t o = 0;
+    for (int k = 0; k < e->nblk; ++k) {
+      const std::string p = std::string((k & 1) ? "TTEblocks." : "STEblocks.") + std::to_string(k / 2);
+      auto conv = [&](const std::string& name, size_t rows, size_t cols, const uint16_t*& dst) {
+        const std::vector<float>& W = e->slots[e->index[name]].host;
+        for (size_t i = 0; i < rows * cols; ++i) {
+          if (!std::isfinite(W[i])) e->weights_clamped = true;
+          host[o + i] = rne(W[i]);
+        }
+        dst = e->arena16 + o;
+        o += pad256(rows) * cols;
+      };
+      BlockW& b = e->blk[k];
+      conv(p + ".attn.qkv.weight", 3 * D, D, b.qkv_x3);
+      conv(p + ".attn.proj.weight", D, D, b.proj_x3);
+      conv(p + ".mlp.fc1.weight", Dm, D, b.fc1_x3);
+      conv(p + ".mlp.fc2.weight", D, Dm, b.fc2_x3);
+    }
+    HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   e->fus_w = wptr(e, "fusion_layer.weight"); e->fus_b = wptr(e, "fusion_layer.bias");
   e->spos = wptr(e, "Spatial_pos_embed"); e->tpos = wptr(e, "Temporal_pos_embed");
@@ -1232,10 +1340,46 @@ int d3d_op_linear(const float* A, const float* W, const float* bias, const float
 
 int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M, int32_t N,
                         int32_t K, int32_t epi, int32_t precision, int32_t variant, int32_t reps, float* avg_ms, void* stream) {
-  if (precision != D3D_PREC_FP32 && precision != D3D_PREC_F16X3) return fail(D3D_EUNSUP, "precision not implemented");
+  if (precision != D3D_PREC_FP32 && precision != D3D_PREC_F16X3 && precision != D3D_PREC_BF16) return fail(D3D_EUNSUP, "precision not implemented");
   if (!A || !W || !C || reps < 1) return fail(D3D_EINVAL, "bad argument");
   if (K % 32) return fail(D3D_EUNSUP, "K must be a multiple of 32");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (precision == D3D_PREC_BF16) {
+    // test / bench hook of the bf16 operand mode: operands rounded to bf16 on the device (rows padded to 256, zero), the product
+    // through launch_linear_bf16; EPI_NONE / EPI_GELU results come back through the kernel's bf16 output (rounded once more)
+    if (K % 64 || N % 8) return fail(D3D_EUNSUP, "bf16 mode: K % 64 == 0 and N % 8 == 0");
+    if (epi == EPI_RESIDUAL && !R) return fail(D3D_EINVAL, "residual required");
+    const size_t mp = ((size_t)M + 255) / 256 * 256, np = ((size_t)N + 255) / 256 * 256;
+    uint16_t *ab = nullptr, *wb = nullptr, *cb = nullptr;
+    HIP_TRY(hipMalloc(&ab, mp * K * 2));
+    HIP_TRY(hipMalloc(&wb, np * K * 2));
+    HIP_TRY(hipMalloc(&cb, (size_t)M * N * 2));
+    hipError_t le = hipMemsetAsync(ab, 0, mp * K * 2, s);
+    if (le == hipSuccess) le = hipMemsetAsync(wb, 0, np * K * 2, s);
+    if (le == hipSuccess) le = launch_f32_to_bf16(A, ab, (size_t)M * K, s);
+    if (le == hipSuccess) le = launch_f32_to_bf16(W, wb, (size_t)N * K, s);
+    auto once = [&]() -> hipError_t { return launch_linear_bf16(ab, wb, bias, R, C, cb, M, N, K, epi, 0, s); };
+    if (le == hipSuccess) le = once();
+    if (le == hipSuccess && avg_ms) {
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      for (int i = 0; i < 3 && le == hipSuccess; ++i) le = once();          // warm clocks
+      (void)hipEventRecord(e0, s);
+      for (int i = 0; i < reps && le == hipSuccess; ++i) le = once();
+      (void)hipEventRecord(e1, s);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      *avg_ms = ms / reps;
+    }
+    if (le == hipSuccess && epi != EPI_RESIDUAL) le = launch_bf16_to_f32(cb, C, (size_t)M * N, s);
+    hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(ab); (void)hipFree(wb); (void)hipFree(cb);
+    HIP_TRY(le);
+    HIP_TRY(se);
+    return D3D_OK;
+  }
   TmpPair ap, wp;
   if (precision == D3D_PREC_F16X3 && (N % 4) != 0) variant = 9;   // the plane kernel stores 4 columns at a time
   if (precision == D3D_PREC_F16X3) {
@@ -1406,9 +1550,29 @@ int d3d_op_layernorm(const float* x, const float* gamma, const float* beta, floa
 
 int d3d_op_attention(const float* qkv, float* out, int32_t B, int32_t T, int32_t J, int32_t D, int32_t H, int32_t temporal,
                      int32_t precision, int32_t force_generic, void* stream) {
-  if (precision != D3D_PREC_FP32 && precision != D3D_PREC_F16X3) return fail(D3D_EUNSUP, "precision not implemented");
+  if (precision != D3D_PREC_FP32 && precision != D3D_PREC_F16X3 && precision != D3D_PREC_BF16) return fail(D3D_EUNSUP, "precision not implemented");
   if (!qkv || !out || B <= 0 || T <= 0 || J <= 0 || D <= 0 || H <= 0 || D % H) return fail(D3D_EINVAL, "bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (precision == D3D_PREC_BF16) {
+    // test hook: fp32 qkv -> bf16 (q third scaled by 2^-3, as the qkv GEMM epilogue writes it) -> bf16-MFMA attention -> fp32
+    const int N = temporal ? T : J;
+    if (!attn_bf16_ok(N, D, H)) return fail(D3D_EUNSUP, "bf16 attention: head_dim 64, group length <= 256");
+    const size_t rows = (size_t)B * T * J, nq = rows * 3 * D, no = rows * D;
+    float* qs = nullptr;
+    uint16_t* tmp = nullptr;
+    HIP_TRY(hipMalloc(&qs, nq * sizeof(float)));
+    HIP_TRY(hipMalloc(&tmp, (nq + no) * sizeof(uint16_t)));
+    hipError_t le = hipMemcpyAsync(qs, qkv, nq * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (le == hipSuccess) le = launch_scale_cols(qs, rows, 3 * D, D, 0.125f, s);
+    if (le == hipSuccess) le = launch_f32_to_bf16(qs, tmp, nq, s);
+    if (le == hipSuccess) le = temporal ? launch_attn_bf16(tmp, tmp + nq, B, T, J, D, H, s) : launch_attn_bf16(tmp, tmp + nq, B * T, J, 1, D, H, s);
+    if (le == hipSuccess) le = launch_bf16_to_f32(tmp + nq, out, no, s);
+    hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(qs); (void)hipFree(tmp);
+    HIP_TRY(le);
+    HIP_TRY(se);
+    return D3D_OK;
+  }
   if (precision == D3D_PREC_F16X3 && temporal && !force_generic && attn_temporal_x3_ok(T, D, H)) {
     // test hook: fp32 qkv -> planes (as the qkv GEMM epilogue writes them) -> fp16-MFMA attention -> pair layout -> fp32
     const size_t rows = (size_t)B * T * J, nq = rows * 3 * D, no = rows * D;

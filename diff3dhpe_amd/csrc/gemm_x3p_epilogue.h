@@ -87,6 +87,21 @@ constexpr int FX_LNF = 1;   // LayerNorm folded into this GEMM: per-row (rstd, -
 constexpr int FX_RP = 2;    // residual from pair-layout planes
 constexpr int FX_SO = 4;    // per-row (sum, sum of squares) of the output rows -> st_out
 constexpr int FX_PN = 8;    // the tile spans whole rows: post-norm of the new rows in the epilogue (X3PostNorm)
+constexpr int FX_BF16 = 16; // bf16 operand mode (D3D_PREC_BF16): operands are plain bf16 rows, a 128-byte line = 64 k values, ONE bf16
+                            // MFMA per product (two per line); OUTSPLIT 3 = bf16 row-major output (the next GEMM's / the attention's operand)
+
+// 8 values -> bf16 (round to nearest even: v_cvt_pk_bf16_f32) of osc * v
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint4 cvt8_bf16(const f2 (&v)[4], float osc) {
+  bf8v o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f2 sc = v[e] * osc;
+    o[2 * e] = (__bf16)sc.x;
+    o[2 * e + 1] = (__bf16)sc.y;
+  }
+  return __builtin_bit_cast(uint4, o);
+}
 
 // sum over the 16 lanes of a DPP row (all 16 lanes get the total): quad xor 1, xor 2, half-row mirror, row mirror
 __device__ __forceinline__ float row16_sum(float v) {
@@ -255,7 +270,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   for (int e = 0; e < 4; ++e) { bb[e] = splat2(0.f); cs[e] = splat2(0.f); }
   if (bias && ncol_ok) load8(bias + n, bb);
   if ((FX & FX_LNF) && ncol_ok) load8(csum + n, cs);
-  const float osc = (n < qcols) ? 1.0f : P_A_SCALE;
+  const float osc = (OUTSPLIT == 3) ? ((n < qcols) ? 0.125f : 1.0f) : ((n < qcols) ? 1.0f : P_A_SCALE);   // (bf16 planes are unscaled)
   const int pc = (int)pair_col(8 * rc8);
   const float2* srow = reinterpret_cast<const float2*>(lds_x);
   const int npart = (N + 63) >> 6;
@@ -336,7 +351,9 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
         if (rc8 == 0 && m < M) *reinterpret_cast<float2*>(st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
         if (!ok) continue;
       }
-      if (OUTSPLIT) {
+      if constexpr (OUTSPLIT == 3) {
+        *reinterpret_cast<uint4*>(Chb + (obh + (unsigned)(2 * i + p) * rsteph)) = cvt8_bf16(v, osc);
+      } else if (OUTSPLIT) {
         h8 oh, ol;
         if constexpr ((FX & FX_SO) != 0) {   // range guard of this form: by the consumer of its row statistics (x3q_tile, FX_LNF) -- this
           split8_x3<false>(v, osc, oh, ol, amax);   // epilogue sits at the 256-register limit: one more live register costs it 60 spilled
@@ -363,7 +380,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if constexpr (OUTSPLIT != 0 && !(FX & FX_SO)) range_note(amax);
+  if constexpr (OUTSPLIT != 0 && OUTSPLIT != 3 && !(FX & FX_SO)) range_note(amax);
 }
 
 // GELU + pair output straight from the accumulators (fc1 -> hidden activation).  The hidden activation is only ever the A

@@ -146,9 +146,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
     sq = wave_sum(sq);
     if (lane == 0) *reinterpret_cast<float2*>(a.stats + 2 * (size_t)row) = make_float2(sm, sq);
   }
-  if (a.h || a.h_x3) {
+  if (a.h || a.h_x3 || a.h_bf16) {
     if (a.y || a.y_x3) ln_row<NV>(v, D, lane, a.g2, a.b2, a.eps2);
-    if (a.h_x3) {   // F16X3 pair layout: 8 lanes fill one 128-byte line (64 B of hi, 64 B of lo) of the row
+    if (a.h_bf16) {   // bf16 operand rows (round to nearest even)
+      typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+      __bf16* hp = reinterpret_cast<__bf16*>(a.h_bf16) + (size_t)row * D;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < D) {
+          bf4 o;
+          o[0] = (__bf16)v[i].x; o[1] = (__bf16)v[i].y; o[2] = (__bf16)v[i].z; o[3] = (__bf16)v[i].w;
+          *reinterpret_cast<bf4*>(hp + c) = o;
+        }
+      }
+    } else if (a.h_x3) {   // F16X3 pair layout: 8 lanes fill one 128-byte line (64 B of hi, 64 B of lo) of the row
       _Float16* hp = reinterpret_cast<_Float16*>(a.h_x3) + (size_t)row * 2 * D;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {

@@ -137,6 +137,22 @@ __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
 
 #include "gemm_x3p_epilogue.h"
 
+// The products of one (m-tile, n-tile) pair for one staged 128-byte line of each operand row.  F16X3: the line holds the 32 hi
+// and the 32 lo halves of a 32-deep k-tile -- a_lo b_hi + a_hi b_lo + a_hi b_hi, smallest terms first.  bf16 mode: the line holds
+// 64 bf16 k values -- the same two 16-byte fragment reads per operand row are k 0..31 and k 32..63, one MFMA each.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+template <int FX>
+__device__ __forceinline__ void x3_mma(f32x4& acc, const h8& bh, const h8& bl, const h8& ah, const h8& al) {
+  if constexpr ((FX & FX_BF16) != 0) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bh), __builtin_bit_cast(bf8, ah), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, bl), __builtin_bit_cast(bf8, al), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc, 0, 0, 0);
+  }
+}
+
 // Tile shapes: BM = 16*TM*WM rows, BN = 64*WN columns, WM x WN waves, each wave (16 TM) x 64 = TM x 4 MFMA tiles.
 //   <8,2,4> 256x256, 8 waves of 128x64, 128 KiB LDS  -- large problems
 //   <4,4,2> 256x128, 8 waves of  64x64,  96 KiB LDS  -- problems too small to fill the chip with 256x256 tiles
@@ -289,11 +305,32 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       }                                                                                                                  \
       if (g_act) {                                                                                                       \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                      \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
+          x3_mma<FX>(acc[g][j], bh[j], bl[j], ah[g & 1], al[g & 1]);                                                     \
         }                                                                                                                \
       }                                                                                                                  \
+      if constexpr ((FX & FX_BF16) != 0) {   /* bf16: 8 MFMAs per group -- pairs where the F16X3 pattern has triples */         \
+        if (!SUB && g == 0) {                                                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                             \
+        } else if (!SUB) {                                                                                               \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                             \
+        }                                                                                                                \
+      } else                                                                                                             \
       if (!SUB && g == 0) {   /* the k-tile opening group: A pair + first W pair, then a W pair ahead of each MFMA triple */    \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                               \
@@ -416,11 +453,32 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
         pieces_();                                                                                                        \
         if (g_act) {                                                                                                      \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
-            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                     \
-            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
-            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
+            x3_mma<FX>(acc[g][j], bh[j], bl[j], ah[g & 1], al[g & 1]);                                                    \
           }                                                                                                               \
         }                                                                                                                 \
+        if constexpr ((FX & FX_BF16) != 0) {   /* bf16: 8 MFMAs per group -- pairs where the F16X3 pattern has triples */       \
+          if (!SUB && (H) == 0 && g == G0) {                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                                            \
+          } else if (!SUB) {                                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                            \
+          }                                                                                                               \
+        } else                                                                                                            \
         if (!SUB && (H) == 0 && g == G0) {   /* the k-tile opening: fragments just ahead of their MFMAs */                \
           __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
@@ -679,7 +737,7 @@ static X3Walk x3q_walk(int tiles, int grid) {
 template <int TM, int WM, int WN>
 static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
                              _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
-                             unsigned long long* diag = nullptr, const X3Fold* fold = nullptr, int w_exp = 12) {
+                             unsigned long long* diag = nullptr, const X3Fold* fold = nullptr, int w_exp = 12, bool bf16 = false) {
   constexpr int BM = 16 * TM * WM, BN = 64 * WN;
   const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
@@ -705,7 +763,17 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
                        ntiles, qcols, diag, tail);                                                                        \
   } while (0)
 #define D3D_X3Q_LAUNCH(EPI_, OS_) D3D_X3Q_LAUNCH_FX(EPI_, OS_, 0)
-  if (fx == 0) {
+  if (bf16) {   // bf16 operand mode: the three forms its block flow uses (launch_linear_bf16)
+    tail.out_scale = 1.0f;
+    if constexpr (WM * WN == 8) {
+      if (fx == 0 && epi == EPI_NONE && outsplit == 3) D3D_X3Q_LAUNCH_FX(EPI_NONE, 3, FX_BF16);
+      else if (fx == 0 && epi == EPI_GELU && outsplit == 3) D3D_X3Q_LAUNCH_FX(EPI_GELU, 3, FX_BF16);
+      else if (fx == 0 && epi == EPI_RESIDUAL && outsplit == 0) D3D_X3Q_LAUNCH_FX(EPI_RESIDUAL, 0, FX_BF16);
+      else return hipErrorInvalidValue;
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if (fx == 0) {
     D3D_X3_DISPATCH(D3D_X3Q_LAUNCH);
   } else if constexpr (WM * WN == 8) {   // folded forms exist for the production (8-wave) shapes only
     // the four folded forms of the engine's plane-resident block (engine.hip run_blocks)
@@ -732,7 +800,7 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
 // landed.  D3D_QKTILE now states the wait itself.
 static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C,
                                      _Float16* Ch, _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols,
-                                     hipStream_t s, const X3Fold* fold, int w_exp) {
+                                     hipStream_t s, const X3Fold* fold, int w_exp, bool bf16 = false) {
   const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
   const int tiles = mtiles * ntiles;
   int n_cu = device_cu_count() / 8 * 8;   // (per device)
@@ -762,7 +830,13 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
                        qcols, wk, tail);                                                                                  \
   } while (0)
 #define D3D_X3P_LAUNCH(EPI_, OS_) D3D_X3P_LAUNCH_FX(EPI_, OS_, 0)
-  if (fx == 0) {
+  if (bf16) {
+    tail.out_scale = 1.0f;
+    if (fx == 0 && epi == EPI_NONE && outsplit == 3) D3D_X3P_LAUNCH_FX(EPI_NONE, 3, FX_BF16);
+    else if (fx == 0 && epi == EPI_GELU && outsplit == 3) D3D_X3P_LAUNCH_FX(EPI_GELU, 3, FX_BF16);
+    else if (fx == 0 && epi == EPI_RESIDUAL && outsplit == 0) D3D_X3P_LAUNCH_FX(EPI_RESIDUAL, 0, FX_BF16);
+    else return hipErrorInvalidValue;
+  } else if (fx == 0) {
     D3D_X3_DISPATCH(D3D_X3P_LAUNCH);
   } else {
     if (fx == FX_LNF && epi == EPI_NONE && outsplit == 1) D3D_X3P_LAUNCH_FX(EPI_NONE, 1, FX_LNF);
@@ -848,6 +922,59 @@ static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const 
     return launch_x3q_persist(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold, w_exp);
   if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
   return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
+}
+
+// ---- bf16 operand mode (D3D_PREC_BF16) ---------------------------------------------------------------------------------
+// C = epi(A W^T + bias) with A [>= ceil(M/256)*256 rows][K] and W [>= ceil(N/256)*256 rows][K] as plain bf16 rows (K % 64 == 0;
+// weights rounded once at commit, activations by their producer), ONE v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate.
+// The tile machinery is the F16X3 one: a 128-byte line of a row is now 64 bf16 k values instead of 32 (hi, lo) pairs, so the
+// kernel is launched with "K / 2 pair columns" and differs only in x3_mma and in the output form:
+//   EPI_NONE / EPI_GELU -> Cb, bf16 [M][N] (columns < qcols multiplied by 2^-3: the q third of a qkv GEMM, dh = 64)
+//   EPI_RESIDUAL        -> C fp32 = R + ... (the fp32 residual stream; R may alias C)
+// Same 256x256 persistent walk / 256x128 choice as launch_x3q_auto; values are tile-shape independent.
+hipError_t launch_linear_bf16(const void* A, const void* W, const float* bias, const float* R, float* C, void* Cb, int M, int N,
+                              int K, int epi, int qcols, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0 || !A || !W) return hipErrorInvalidValue;
+  if (epi == EPI_RESIDUAL ? (!R || !C) : !Cb) return hipErrorInvalidValue;
+  const _Float16 *ap = (const _Float16*)A, *wp = (const _Float16*)W;
+  _Float16* cb = (_Float16*)Cb;
+  const int outsplit = epi == EPI_RESIDUAL ? 0 : 3;
+  const int K2 = K / 2;                     // pair columns: 4 K2 bytes per row, K2 / 32 staged lines per row
+  if (x3q_big(M, N) && (K2 / PBK) % 2 == 0)
+    return launch_x3q_persist(ap, wp, bias, R, C, cb, nullptr, M, N, K2, epi, outsplit, qcols, s, nullptr, 12, true);
+  if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, cb, nullptr, M, N, K2, epi, outsplit, qcols, s, nullptr, nullptr, 12, true);
+  return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, cb, nullptr, M, N, K2, epi, outsplit, qcols, s, nullptr, nullptr, 12, true);
+}
+
+// fp32 [rows, cols] -> bf16 (round to nearest even), and back: weight commit on the device side of the op hooks, tests
+__global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ x, __bf16* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = (__bf16)x[i];
+}
+__global__ __launch_bounds__(256) void k_bf16_to_f32(const __bf16* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = (float)x[i];
+}
+// x[r][c] *= f for c < ncols_scaled (test hook: the q third of a packed qkv buffer)
+__global__ __launch_bounds__(256) void k_scale_cols(float* __restrict__ x, size_t n, int cols, int ncols_scaled, float f) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && (int)(i % cols) < ncols_scaled) x[i] *= f;
+}
+hipError_t launch_scale_cols(float* x, size_t rows, int cols, int ncols_scaled, float f, hipStream_t s) {
+  const size_t n = rows * cols;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, cols, ncols_scaled, f);
+  return hipGetLastError();
+}
+hipError_t launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (__bf16*)y, n);
+  return hipGetLastError();
+}
+hipError_t launch_bf16_to_f32(const void* x, float* y, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const __bf16*)x, y, n);
+  return hipGetLastError();
 }
 
 void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }

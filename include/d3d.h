@@ -40,7 +40,12 @@ extern "C" {
 #define D3D_PREC_F16X3 1    /* fp32-accurate GEMMs and attention from 3 fp16 MFMAs per product on hi/lo operand splits; the
                              * residual stream lives in the GEMM operand layout and norm1/norm2 are folded into the qkv/fc1
                              * GEMMs.  Same 1e-4 parity gate as FP32; the default of the Python layer. */
-#define D3D_PREC_BF16 2     /* reserved (bf16 MFMA operands): d3d_engine_create returns D3D_EUNSUP                    */
+#define D3D_PREC_BF16 2     /* SECOND-CLASS precision (BASELINE configs[1]): bf16 operands for the block GEMMs
+                             * and both attention products (one MFMA per product), everything else fp32 (residual stream, LayerNorm /
+                             * softmax statistics, GELU, time vectors, embedding, head, DDIM update).  It CANNOT meet the 1e-4 parity
+                             * gate (bf16 operands cost ~5e-2 max-abs at random init); it is gated against the CPU
+                             * oracle's bf16-operand emulation instead (same rounding points).  Needs head_dim 64, num_frame <= 256,
+                             * num_joints <= 32, widths % 64 == 0; never the default of the Python layer or of bench.py. */
 
 typedef struct d3d_engine d3d_engine;
 
