@@ -69,8 +69,9 @@ struct d3d_engine {
   // d3d_engine_set_option: the F16X3 block flow with the post-norm inside the fc2 epilogue / with norm1, norm2 folded into
   // the consuming GEMMs (both on by default; experiments/ and the A/B tests switch them off)
   bool opt_fused_postnorm = true, opt_fold_layernorm = true;
-  // "streams" = 2: d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by events)
-  int opt_streams = 1;
+  // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
+  // events); 1: the whole batch on the caller's stream
+  int opt_streams = 2;
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int device = -1;                // ordinal of the device the weights were committed on

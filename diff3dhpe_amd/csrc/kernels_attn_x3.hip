@@ -44,6 +44,25 @@ typedef unsigned u32x4_alias __attribute__((ext_vector_type(4), may_alias));
 // F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = an output clamp fired
 __device__ unsigned g_range_attn;
 
+// Output patch, write side.  Lane (row r, half h) of the O^T accumulator layout holds 4 columns of a 16-byte chunk -- hi and lo
+// halves (oh, ol: 8 bytes each) of columns 8 g + 4 h .. + 3.  Written as two ds_write_b64 per lane, rows r and r + 1 of a
+// 16-lane group share a 16-byte slot (a lane's 8-byte position inside its chunk is fixed by h, the same for the whole group):
+// a 2-way bank conflict on every write -- 0.33 (spatial) / 0.13 (temporal) of all LDS cycles of these kernels (rocprofv3
+// SQ_LDS_BANK_CONFLICT, round 2).  v_permlane32_swap trades the halves between lanes l and l + 32 instead: lanes < 32 then own
+// the WHOLE hi chunk of their row, lanes >= 32 the whole lo chunk, one ds_write_b128 each, 16-byte slots XOR-swizzled by
+// (row & 7) -- conflict-free on the write (8 consecutive rows per lane group) and on the ds_read_b128 read-back (patch_rd).
+__device__ __forceinline__ void patch_wr(unsigned char* patch, int r, int h, int g, h4 oh, h4 ol) {
+  const uint2 a = __builtin_bit_cast(uint2, oh), b = __builtin_bit_cast(uint2, ol);
+  const auto s0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);   // new a[l + 32] = b[l], new b[l] = a[l + 32]
+  const auto s1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+  u32x4_alias v;
+  v[0] = s0[0]; v[1] = s1[0]; v[2] = s0[1]; v[3] = s1[1];
+  *reinterpret_cast<u32x4_alias*>(patch + r * 128 + ((((h << 2) + g) ^ (r & 7)) << 4)) = v;
+}
+__device__ __forceinline__ u32x4 patch_rd(const unsigned char* patch, int row, int chunk) {
+  return *reinterpret_cast<const u32x4_alias*>(patch + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
 // MU > 1 (only with NKT == 1, i.e. groups of <= 32 tokens: the spatial blocks): one workgroup carries MU independent
 // (group, head) units, one per wave, each in its own LDS slice -- a 64-thread workgroup per unit is bound by the
 // workgroup launch rate (124k launches per call at T=243, B=64), not by HBM.
@@ -266,7 +285,9 @@ __device__ __forceinline__ const char* sgpr_ptr_x(const char* p) {
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
-template <int NKT, int MU>
+// WIT (wave-private form): 8-row passes of the output patch that carry rows < T -- 3 for groups of <= 24 tokens (the spatial
+// blocks: 17 joints), 4 up to 32 (temporal blocks of the T = 27 configuration).
+template <int NKT, int MU, int WIT = 3>
 __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
                                                                      _Float16* __restrict__ out_x3, int T, int J, int H, int D,
                                                                      int units) {
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   // !WAVEP (T = 81: three workgroups per CU, LDS is what limits them): a 1 KiB patch per wave (8 rows), four passes per line
   unsigned char* const patch1 = lds_all + 4 * PLANE + (int)(threadIdx.x >> 6) * 1024;
   u32x4 pq[8];                  // [dt * 4 + p]: row 32 wave + 8 p + (lane >> 3), chunk lane & 7 of line dt
-  u32x4 pw[6];                  // [dt * 3 + it]: row 8 it + (lane >> 3), chunk lane & 7 of line dt
+  u32x4 pw[2 * WIT];            // [dt * WIT + it]: row 8 it + (lane >> 3), chunk lane & 7 of line dt
   _Float16* pw_ptr = out_x3;    // row (lane >> 3), this lane's chunk of line 0 (row 8 it: + it * pw_stride)
   const size_t pw_stride = (size_t)8 * J * 2 * D;
   int tq = 32 * wave + r;
@@ -392,10 +413,10 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
     if (WAVEP) {
       if (po_valid) {
 #pragma unroll
-        for (int it = 0; it < 3; ++it)
+        for (int it = 0; it < WIT; ++it)
           if (8 * it + (lane >> 3) < T) {
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * 3 + it];
+            for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * WIT + it];
           }
       }
     } else if (po_valid) {
@@ -527,16 +548,11 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
             ol[e] = (_Float16)(sc - (float)oh[e]);
           }
           if (WAVEP) {   // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout)
-            const int sw = (r >> 1) & 7;
-            *reinterpret_cast<h4_alias*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
-            *reinterpret_cast<h4_alias*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
+            patch_wr(patch, r, h, g4, oh, ol);
             if (g4 == 3) {
               asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
 #pragma unroll
-              for (int it = 0; it < 3; ++it) {
-                const int row = 8 * it + (lane >> 3);
-                pw[dt * 3 + it] = *reinterpret_cast<const u32x4_alias*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
-              }
+              for (int it = 0; it < WIT; ++it) pw[dt * WIT + it] = patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
             }
           } else {
             po_h[g4] = oh;       // (this line's four column groups, transposed below)
@@ -579,10 +595,10 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   // outputs of the last unit
   if (WAVEP) {
 #pragma unroll
-    for (int it = 0; it < 3; ++it)
+    for (int it = 0; it < WIT; ++it)
       if (8 * it + (lane >> 3) < T) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * 3 + it];
+        for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pw_ptr + it * pw_stride + dt * 64) = pw[dt * WIT + it];
       }
   } else {
 #pragma unroll
@@ -917,17 +933,12 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
             oh[e] = (_Float16)sc;
             ol[e] = (_Float16)(sc - (float)oh[e]);
           }
-          // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout), 8 h bytes in
-          const int sw = (r >> 1) & 7;
-          *reinterpret_cast<h4_alias*>(patch + r * 128 + ((g4 ^ sw) << 4) + 8 * h) = oh;
-          *reinterpret_cast<h4_alias*>(patch + r * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = ol;
+          // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout)
+          patch_wr(patch, r, h, g4, oh, ol);
         }
         asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = 8 * it + (lane >> 3);
-          po[dt * 4 + it] = *reinterpret_cast<const u32x4_alias*>(patch + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
-        }
+        for (int it = 0; it < 4; ++it) po[dt * 4 + it] = patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
       }
       if (tq < T && amax > X3_HALF_MAX) atomicOr(&g_range_attn, 1u);
       po_ptr = out_x3 + (tok0 + (size_t)(32 * wave + (lane >> 3)) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
@@ -997,13 +1008,13 @@ static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16
   return hipGetLastError();
 }
 
-template <int NKT, int MU = 1>
+template <int NKT, int MU = 1, int WIT = 3>
 static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H,
                                  hipStream_t s) {
   // wave-private units (MU > 1, NKT == 1): 6 planes of T rows per wave (V double-buffered) + one zeroed pad behind the last
   const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 + (size_t)MU * 4096 : (size_t)4 * 32 * NKT * 128 + (size_t)NKT * 1024;
   static std::atomic<unsigned long long> attr_set{0};   // one bit per device
-  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU>), MU > 1 ? (size_t)160 * 1024 : lds_bytes,
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU, WIT>), MU > 1 ? (size_t)160 * 1024 : lds_bytes,
                                attr_set))
     return e;
   const int n_cu = device_cu_count();
@@ -1013,7 +1024,7 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
   const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;   // resident workgroups per CU
   const long long wgs = (units + MU - 1) / MU;
   const long long grid = wgs < (long long)n_cu * per_cu ? wgs : (long long)n_cu * per_cu;
-  hipLaunchKernelGGL((k_attn_temporal_x3p<NKT, MU>), dim3((unsigned)grid), dim3(64 * NKT * MU), lds_bytes, s, ph, pl, ox, T, J, H,
+  hipLaunchKernelGGL((k_attn_temporal_x3p<NKT, MU, WIT>), dim3((unsigned)grid), dim3(64 * NKT * MU), lds_bytes, s, ph, pl, ox, T, J, H,
                      D, (int)units);
   return hipGetLastError();
 }
@@ -1079,8 +1090,12 @@ hipError_t launch_attn_temporal_x3(const void* qkv_hi, const void* qkv_lo, void*
     case 1:   // groups of <= 32 tokens (spatial blocks: the 17 joints of a frame).  8 units per workgroup = the 8 heads of one
               // frame at H = 8, so a workgroup reads whole token rows; measured 0.61 ms per launch at T=243, B=64 against
               // 0.82 / 0.68 / 0.69 ms with 1 / 2 / 4 units per workgroup.
-      if ((long long)B * J * H >= 4096 && (size_t)8 * 6 * T * 128 + (size_t)(32 - T) * 128 + 8 * 4096 <= 160 * 1024)
+      if ((long long)B * J * H >= 4096 && T <= 24 && (size_t)8 * 6 * T * 128 + (size_t)(32 - T) * 128 + 8 * 4096 <= 160 * 1024)
         return launch_x3p_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
+      // groups of 25 .. 32 tokens (the temporal blocks of the T = 27 configuration): six wave-private units fit the 160 KiB, and
+      // the output patch takes four 8-row passes
+      if ((long long)B * J * H >= 4096 && (size_t)6 * 6 * T * 128 + (size_t)(32 - T) * 128 + 6 * 4096 <= 160 * 1024)
+        return launch_x3p_nkt<1, 6, 4>(ph, pl, ox, B, T, J, D, H, s);
       if ((long long)B * J * H >= 4096) return launch_x3_nkt<1, 8>(ph, pl, ox, B, T, J, D, H, s);
       return launch_x3_nkt<1, 1>(ph, pl, ox, B, T, J, D, H, s);
     case 2: return launch_x3_nkt<2>(ph, pl, ox, B, T, J, D, H, s);

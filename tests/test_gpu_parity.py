@@ -228,6 +228,18 @@ def test_large_batch_kernels_match_the_small_batch_path():
     for lo in (0, 5, 10):
         hi = min(lo + 5, 12)
         assert torch.equal(eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous()), big[lo:hi])
+    # T = 27 (BASELINE configs[4]): temporal groups of 27 tokens run the wave-private persistent kernel with six units per workgroup
+    # and four patch passes (>= 4096 units), spatial groups the eight-unit form; chunks of 13 run the one-unit-per-workgroup kernel
+    cfg = cfg_full(27)
+    _, diff = build_product(cfg, 8, sampling=2, precision="f16x3")
+    eng = diff._engine(dev)
+    inp = inputs(40, 27, 7)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    big = eng.ddim_sample(x2d, nz).clone()
+    assert torch.equal(big, eng.ddim_sample(x2d, nz))
+    for lo in (0, 13, 26, 39):
+        hi = min(lo + 13, 40)
+        assert torch.equal(eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous()), big[lo:hi])
 
 
 @pytest.mark.parametrize("prec", PRECS)
