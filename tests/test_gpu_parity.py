@@ -591,6 +591,26 @@ def test_bench_two_ranks_on_one_device():
     assert line1["headline_under"] == "2-stream" and "ranks" not in line1 and "timed_in" in line1["roofline"]
 
 
+@pytest.mark.skipif(not __import__("os").environ.get("D3D_SLOW_TESTS"),
+                    reason="~3 min of GPU: set D3D_SLOW_TESTS=1 -- the many-iteration form of test_bench_two_ranks_on_one_device")
+def test_two_ranks_on_one_device_many_iterations():
+    """Opt-in.  The deviation a second process on the GPU once caused in the head kernel showed in about 1 launch of 60: one
+    two-rank run (3 samplings x 3 steps) barely sees such an event, twenty of them at T = 243 (9 steps each) would have shown it
+    with probability > 0.99.  Every run must report the same MPJPE, bit for bit (experiments/two_rank_repeat.sh as a test)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo")
+    seen = set()
+    for i in range(20):
+        run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(29700 + i), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "2",
+                              "--warmup", "0", "--frames", "243", "--sampling", "9", "--no-cpu-baseline", "--no-extras", "--no-selfcheck",
+                              "--profile-steps", "0"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+        assert run.returncode == 0, run.stderr[-2000:]
+        seen.add(json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])["mpjpe_vs_synthetic_gt"])
+    assert len(seen) == 1, seen
+
+
 def test_bench_rccl_collectives_on_a_one_rank_group():
     """bench.py's N > 1 communication path on RCCL itself, on a one-GPU box: `torchrun --nproc-per-node 1 bench.py --gpus 1`
     with D3D_FORCE_DIST=1 executes init_process_group("nccl", device_id=...), barrier, all_gather_into_tensor and
