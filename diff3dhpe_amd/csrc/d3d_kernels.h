@@ -99,6 +99,9 @@ struct X3PostNorm {
   const float* g; const float* b; float eps;
   const float* pos; int pos_div, pos_mod;                          // nullable, as LnArgs
   const float* tvec; long long tvec_stride; int rows_per_batch;   // nullable, as LnArgs
+  // bf16 mode only (launch_linear_bf16_rows): a SECOND LayerNorm of the rows just formed, written as bf16 operand rows -- the
+  // norm2 behind proj (then g == nullptr: no post-norm, the rows are x + a W^T + b), the next block's norm1 behind fc2
+  const float* g2; const float* b2; float eps2;
 };
 struct X3Fold {
   const float* st_in; int st_np; const float* csum; float eps;
@@ -119,6 +122,13 @@ hipError_t launch_unsplit_x3(const void* pair, float* x, size_t rows, int cols, 
 // accumulate.  EPI_NONE / EPI_GELU write Cb = bf16 [M][N] (columns < qcols scaled by 2^-3), EPI_RESIDUAL writes fp32 C = R + ...
 hipError_t launch_linear_bf16(const void* A, const void* W, const float* bias, const float* R, float* C, void* Cb, int M, int N,
                               int K, int epi, int qcols, hipStream_t s);
+// Whole-row form (N == 512, 128-row tiles): X[M,N] fp32 is the residual stream, updated IN PLACE,
+//   y = X + A W^T + bias;   if pn.g: y = LN(y; pn.g, pn.b, pn.eps) [+ pos] [+ tvec];   X = y;
+//   if pn.g2: Hb = bf16(LN(y; pn.g2, pn.b2, pn.eps2))   (bf16 [M][N], the next GEMM's operand)
+// -- proj + norm2 (pn.g == nullptr) and fc2 + post-norm + next norm1 of a bf16-mode block without any row kernel.
+bool bf16_rows_ok(int N, int K);
+hipError_t launch_linear_bf16_rows(const void* A, const void* W, const float* bias, float* X, void* Hb, int M, int N, int K,
+                                   const X3PostNorm& pn, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* x, float* y, size_t n, hipStream_t s);
 hipError_t launch_scale_cols(float* x, size_t rows, int cols, int ncols_scaled, float f, hipStream_t s);   // op hooks only

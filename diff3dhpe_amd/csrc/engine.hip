@@ -454,6 +454,14 @@ int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
     HIP_TRY(lnorm(a));
   }
+  // Whole-row tiles for proj and fc2 (launch_linear_bf16_rows; "fused_postnorm" option, D == 512): the LayerNorm behind each of
+  // them -- norm2, resp. post-norm + next norm1 -- runs in the GEMM epilogue and the three row kernels per block are gone
+  // (measured first un-fused, as planned: 59 of 323 ms per sampling were LayerNorm kernels at 5 TB/s).
+  const bool rows = e->opt_fused_postnorm && bf16_rows_ok(D, D) && bf16_rows_ok(D, e->Dm);
+  auto linear_rows = [&](const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* Hb, int K, const X3PostNorm& pn, int sub) -> hipError_t {
+    Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)D * K, 2.0 * ((double)M * K + (double)D * K) + (double)M * D * (Hb ? 10.0 : 8.0), s, sub);
+    return launch_linear_bf16_rows(A, W, bias, w.X, Hb, M, D, K, pn, s);
+  };
   for (int k = 0; k < e->nblk; ++k) {
     const BlockW& bw = e->blk[k];
     const bool temporal = (k & 1) != 0;
@@ -463,6 +471,27 @@ int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       Prof p(e, temporal ? D3D_KC_ATTN_TEMPORAL : D3D_KC_ATTN_SPATIAL, 4.0 * M * (double)N * D, 4.0 * MD2, s);
       if (temporal) HIP_TRY(launch_attn_bf16(QKVb, HNb, B, T, J, D, e->H, s));
       else HIP_TRY(launch_attn_bf16(QKVb, HNb, B * T, J, 1, D, e->H, s));
+    }
+    if (rows) {
+      {  // x += attn Wproj^T + b (fp32 stream in place); h = bf16(norm2(x)) over the attention output's rows (same tile rows: in place)
+        X3PostNorm pn{};
+        pn.g2 = bw.n2g; pn.b2 = bw.n2b; pn.eps2 = 1e-6f; pn.pos_div = 1; pn.pos_mod = 1; pn.rows_per_batch = T * J;
+        HIP_TRY(linear_rows(HNb, bw.proj_x3, bw.projb, HNb, D, pn, D3D_KC_LINEAR_PROJ));
+      }
+      HIP_TRY(linear(HNb, bw.fc1_x3, bw.fc1b, nullptr, nullptr, HIDb, e->Dm, D, EPI_GELU, 0, D3D_KC_LINEAR_FC1));
+      {  // x = post_norm(x + hidden W2^T + b2) [+ Temporal_pos_embed] [+ next block's time vector]; h = bf16(next.norm1(x))
+        X3PostNorm pn{};
+        pn.g = temporal ? e->tn_g : e->sn_g; pn.b = temporal ? e->tn_b : e->sn_b; pn.eps = 1e-6f;
+        pn.pos_div = 1; pn.pos_mod = 1; pn.rows_per_batch = T * J;
+        if (k == 0) { pn.pos = e->tpos; pn.pos_div = J; pn.pos_mod = T; }
+        const bool last = k + 1 == e->nblk;
+        if (!last) {
+          if (tvec) { pn.tvec = tvec + (size_t)(k + 1) * D; pn.tvec_stride = tvec_stride; }
+          pn.g2 = e->blk[k + 1].n1g; pn.b2 = e->blk[k + 1].n1b; pn.eps2 = 1e-6f;
+        }
+        HIP_TRY(linear_rows(HIDb, bw.fc2_x3, bw.fc2b, last ? nullptr : HNb, e->Dm, pn, D3D_KC_LINEAR_FC2));
+      }
+      continue;
     }
     HIP_TRY(linear(HNb, bw.proj_x3, bw.projb, w.X, w.X, nullptr, D, D, EPI_RESIDUAL, 0, D3D_KC_LINEAR_PROJ));
     {  // h = bf16(norm2(x))

@@ -603,3 +603,165 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   if (OUTSPLIT == 2) range_note(amax);
 }
 
+// Whole-row epilogue of the bf16 operand mode (FX_PN | FX_BF16; x3q_epilogue_pn's structure with an fp32 residual stream):
+//   sweep 1  v = R + acc + bias (R = the fp32 stream, read through a 3-m-tile register window), per-wave (sum, M2) -> xch
+//   sweep 2  y = pn.g ? LN(v) [+ pos] [+ tvec] : v;  y -> C (= R: in place);  if pn.g and pn.g2: (sum, M2) of y -> xch2
+//   sweep 3  if pn.g2: bf16(LN(y; g2, b2)) -> Cb      (statistics from xch2, or from xch when there was no first norm)
+// Rows stay in the 128 registers the accumulators vacate; the un-normalised sum never makes a second trip through HBM.
+template <int TM, int WN, bool CHECK>
+__device__ __forceinline__ void x3q_epilogue_rows_bf16(f32x4 (&acc)[TM][4], float* patch, float* xch, float* xch2,
+                                                       const float* __restrict__ bias, float* Ct, _Float16* Cbt, const X3Tail& fx,
+                                                       int mt0, int nt0, int wn, int lane, int M, int N, int gl, int gh) {
+  static_assert(WN == 8, "row partials are read back as four float4");
+  const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
+  const int rrow = lane >> 3, rc8 = lane & 7;          // read side
+  const int n = nt0 + 8 * rc8;
+  f2 bb[4];
+  load8(bias + n, bb);
+  constexpr int PF = TM < 3 ? TM : 3;
+  const unsigned ob = (unsigned)(rrow * N + 8 * rc8) * 4u;            // this lane's 8 floats in row rrow (fp32 buffer)
+  const unsigned obh = (unsigned)(rrow * N + 8 * rc8) * 2u;           // ... in the bf16 buffer
+  const unsigned rstep = (unsigned)N * 32u, rsteph = (unsigned)N * 16u;   // 8 rows
+  char* Cb = reinterpret_cast<char*>(Ct);
+  char* Hb = reinterpret_cast<char*>(Cbt);
+  float4 r0[TM][2], r1[TM][2];
+  auto load_res = [&](int i) {
+    if (i < gl || i >= gh) return;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      r0[i][p] = make_float4(0, 0, 0, 0);
+      r1[i][p] = make_float4(0, 0, 0, 0);
+      if (!CHECK || mt0 + 16 * i + rrow + 8 * p < M) {
+        r0[i][p] = *reinterpret_cast<const float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep));
+        r1[i][p] = *reinterpret_cast<const float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u);
+      }
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) load_res(i);
+  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+  f2 vv[TM][2][4];
+  auto partial = [&](const f2 (&v)[4], float* dst, int r) {   // this wave's 64 columns of row r: (sum, M2 about their own mean)
+    const f2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
+    const float sm = row8_sum(s2.x + s2.y);
+    const f2 lm = splat2(sm * (1.0f / 64.0f));
+    f2 d[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = v[e] - lm;
+    const f2 q2 = fma2(d[0], d[0], d[1] * d[1]) + fma2(d[2], d[2], d[3] * d[3]);
+    const float sq = row8_sum(q2.x + q2.y);
+    if (rc8 == 0) *reinterpret_cast<float2*>(dst + 2 * (r * WN + wn)) = make_float2(sm, sq);
+  };
+  auto stats = [&](const float* src, int r, float invn, float eps, f2& mean2, f2& rstd2) {   // pairwise combination of the 8 partials
+    const float4* xr = reinterpret_cast<const float4*>(src + 2 * r * WN);
+    const float4 p0 = xr[0], p1 = xr[1], p2 = xr[2], p3 = xr[3];
+    const float mean = (((p0.x + p0.z) + (p1.x + p1.z)) + ((p2.x + p2.z) + (p3.x + p3.z))) * invn;
+    const float e0 = p0.x * (1.0f / 64.0f) - mean, e1 = p0.z * (1.0f / 64.0f) - mean, e2 = p1.x * (1.0f / 64.0f) - mean,
+                e3 = p1.z * (1.0f / 64.0f) - mean, e4 = p2.x * (1.0f / 64.0f) - mean, e5 = p2.z * (1.0f / 64.0f) - mean,
+                e6 = p3.x * (1.0f / 64.0f) - mean, e7 = p3.z * (1.0f / 64.0f) - mean;
+    const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
+                     64.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
+    mean2 = splat2(mean);
+    rstd2 = splat2(1.0f / sqrtf(m2 * invn + eps));
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+   if (i >= gl && i < gh) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(patch + (i & 1) * 1024 + m16 * 64 + (((4 * j + q4) ^ (m16 & 7)) << 2)) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    D3D_PATCH_FENCE();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = rrow + 8 * p;
+      const float* prow = patch + (i & 1) * 1024 + row * 64;
+      const float4 a0 = *reinterpret_cast<const float4*>(prow + (((2 * rc8) ^ (row & 7)) << 2));
+      const float4 a1 = *reinterpret_cast<const float4*>(prow + (((2 * rc8 + 1) ^ (row & 7)) << 2));
+      const bool ok = !CHECK || mt0 + 16 * i + row < M;
+      f2 (&v)[4] = vv[i][p];
+      v[0].x = r0[i][p].x + (a0.x + bb[0].x); v[0].y = r0[i][p].y + (a0.y + bb[0].y);
+      v[1].x = r0[i][p].z + (a0.z + bb[1].x); v[1].y = r0[i][p].w + (a0.w + bb[1].y);
+      v[2].x = r1[i][p].x + (a1.x + bb[2].x); v[2].y = r1[i][p].y + (a1.y + bb[2].y);
+      v[3].x = r1[i][p].z + (a1.z + bb[3].x); v[3].y = r1[i][p].w + (a1.w + bb[3].y);
+      if (CHECK && !ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = splat2(0.0f);
+      }
+      partial(v, xch, 16 * i + row);
+    }
+   }
+    if (i + PF < TM) load_res(i + PF);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float invn = 1.0f / (float)N;
+  const bool ln1 = fx.pn.g != nullptr, ln2 = fx.pn.g2 != nullptr;
+  f2 gg[4], be[4], tv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { gg[e] = splat2(1.0f); be[e] = splat2(0.0f); tv[e] = splat2(0.0f); }
+  if (ln1) { load8(fx.pn.g + n, gg); load8(fx.pn.b + n, be); }
+  const bool tv_uniform = ln1 && fx.pn.tvec != nullptr && fx.pn.tvec_stride == 0;
+  const bool tv_rows = ln1 && fx.pn.tvec != nullptr && fx.pn.tvec_stride != 0;
+  if (tv_uniform) load8(fx.pn.tvec + n, tv);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i < gl || i >= gh) continue;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 16 * i + rrow + 8 * p;
+      const int m = mt0 + r;
+      f2 (&v)[4] = vv[i][p];
+      if (ln1) {
+        f2 mean2, rstd2;
+        stats(xch, r, invn, fx.pn.eps, mean2, rstd2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fma2((v[e] - mean2) * rstd2, gg[e], be[e]);
+        if (fx.pn.pos && (!CHECK || m < M)) {
+          f2 t[4];
+          load8(fx.pn.pos + (size_t)((m / fx.pn.pos_div) % fx.pn.pos_mod) * N + n, t);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += t[e];
+        }
+        if (tv_rows && (!CHECK || m < M)) {
+          f2 t[4];
+          load8(fx.pn.tvec + (size_t)(m / fx.pn.rows_per_batch) * fx.pn.tvec_stride + n, t);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += t[e];
+        } else if (tv_uniform) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += tv[e];
+        }
+        if (ln2) partial(v, xch2, r);
+      }
+      if (!CHECK || m < M) {
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep)) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+        *reinterpret_cast<float4*>(Cb + (ob + (unsigned)(2 * i + p) * rstep) + 16u) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!ln2) return;   // (uniform)
+  f2 g2[4], b2[4];
+  load8(fx.pn.g2 + n, g2);
+  load8(fx.pn.b2 + n, b2);
+  if (ln1) __syncthreads();
+  const float* src = ln1 ? xch2 : xch;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i < gl || i >= gh) continue;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 16 * i + rrow + 8 * p;
+      if (CHECK && mt0 + r >= M) continue;
+      f2 mean2, rstd2;
+      stats(src, r, invn, fx.pn.eps2, mean2, rstd2);
+      f2 h[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = fma2((vv[i][p][e] - mean2) * rstd2, g2[e], b2[e]);
+      *reinterpret_cast<uint4*>(Hb + (obh + (unsigned)(2 * i + p) * rsteph)) = cvt8_bf16(h, 1.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}

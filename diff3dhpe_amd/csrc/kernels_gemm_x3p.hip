@@ -549,11 +549,14 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   const bool full = FULL || (m0 + BM <= M && n0 + BN <= N);
   bool done = false;
   if constexpr ((FX & FX_PN) != 0) {   // whole rows in the tile: post-norm here (the launcher guarantees N == BN)
-    static_assert(WM == 1 && EPI == EPI_RESIDUAL && (FX & FX_RP) && OUTSPLIT != 1, "post-norm form");
-    static_assert(STAGE >= 65536 + 2 * BM * WN * 4, "row-sum exchange beside the patches");
+    static_assert(WM == 1 && EPI == EPI_RESIDUAL && ((FX & FX_RP) || (FX & FX_BF16)) && OUTSPLIT != 1, "post-norm form");
+    static_assert(STAGE >= 65536 + ((FX & FX_BF16) ? 4 : 2) * BM * WN * 4, "row-sum exchange(s) beside the patches");
     float* xch = reinterpret_cast<float*>(lds + STAGE + 65536);
     // (one copy per instantiation: with a checked and an unchecked copy under a branch the accumulators spill)
-    x3q_epilogue_pn<TM, WN, OUTSPLIT, !FULL>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N, gl, gh);
+    if constexpr ((FX & FX_BF16) != 0)   // bf16 mode: fp32 stream in place (C), bf16 operand rows of the following LayerNorm (Ch)
+      x3q_epilogue_rows_bf16<TM, WN, !FULL>(acc, patch, xch, xch + 2 * BM * WN, bias, Ct, Cht, fx, mt0, nt0, wn, lane, M, N, gl, gh);
+    else
+      x3q_epilogue_pn<TM, WN, OUTSPLIT, !FULL>(acc, patch, xch, bias, Ct, Cht, Rpt, fx, mt0, nt0, wn, lane, M, N, gl, gh);
     done = true;
   } else if constexpr (EPI == EPI_GELU && OUTSPLIT == 2) {   // hidden activation, accumulator order: no transpose
     static_assert(!(FX & (FX_RP | FX_SO)), "fc1 form");
@@ -906,6 +909,58 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
   if (outsplit == 2) D3D_X3PN_LAUNCH(2);
   else D3D_X3PN_LAUNCH(0);
 #undef D3D_X3PN_LAUNCH
+  return hipGetLastError();
+}
+
+// bf16 mode, whole-row form (d3d_kernels.h launch_linear_bf16_rows): the 128 x 512 tile shape of the post-norm form, bf16 MFMAs,
+// x3q_epilogue_rows_bf16.  "K / 2 pair columns" as in launch_linear_bf16.
+bool bf16_rows_ok(int N, int K) { return N == 512 && K % 64 == 0; }
+
+hipError_t launch_linear_bf16_rows(const void* A, const void* W, const float* bias, float* X, void* Hb, int M, int N, int K,
+                                   const X3PostNorm& pn, hipStream_t s) {
+  if (!bf16_rows_ok(N, K) || M <= 0 || !A || !W || !bias || !X) return hipErrorInvalidValue;
+  if (pn.g2 ? (!Hb || !pn.b2) : false) return hipErrorInvalidValue;
+  if (pn.g && !pn.b) return hipErrorInvalidValue;
+  if (pn.pos && (pn.pos_div < 1 || pn.pos_mod < 1)) return hipErrorInvalidValue;
+  if (pn.tvec && pn.tvec_stride != 0 && pn.rows_per_batch < 1) return hipErrorInvalidValue;
+  const _Float16 *Ap = (const _Float16*)A, *Wp = (const _Float16*)W;
+  _Float16* Ch = (_Float16*)Hb;
+  _Float16* Cl = nullptr;
+  const float* R = nullptr;
+  float* C = X;
+  const int K2 = K / 2;
+  const int mtiles = (M + 127) / 128, ntiles = 1;
+  const int vtiles = ((mtiles + 7) / 8) * 8;
+  int n_cu = device_cu_count() / 8 * 8;   // (per device)
+  if (n_cu < 8) n_cu = 8;
+  const bool persist = mtiles >= 4 * n_cu && (K2 / PBK) % 2 == 0;
+  const X3Walk wk = x3q_walk(mtiles * ntiles, n_cu);
+  const size_t lds_bytes = 2 * (size_t)((128 + 512) * 128);
+  const bool small = mtiles < n_cu;
+  const int mtiles64 = (M + 63) / 64, vtiles64 = ((mtiles64 + 7) / 8) * 8;
+  const size_t lds_small = 2 * (size_t)((64 + 512) * 128);
+  X3Tail tail{};
+  tail.out_scale = 1.0f;
+  tail.pn = pn;
+  const int qcols = 0;
+  unsigned long long* diag = nullptr;
+  constexpr int FXB = FX_PN | FX_BF16;
+  if (persist) {
+    auto kfn = k_linear_x3q_persist<8, 1, 8, EPI_RESIDUAL, 0, FXB>;
+    static std::atomic<unsigned long long> attr_done{0};   // one bit per device
+    if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;
+    hipLaunchKernelGGL(kfn, dim3(n_cu), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K2, mtiles, ntiles, qcols, wk, tail);
+  } else if (small) {   // fewer 128-row tiles than CUs: 64-row tiles (same values: rows are independent)
+    auto kfn = k_linear_x3q<4, 1, 8, EPI_RESIDUAL, 0, FXB>;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_small, attr_done)) return ae;
+    hipLaunchKernelGGL(kfn, dim3(vtiles64), dim3(512), lds_small, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K2, mtiles64, ntiles, qcols, diag, tail);
+  } else {
+    auto kfn = k_linear_x3q<8, 1, 8, EPI_RESIDUAL, 0, FXB>;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;
+    hipLaunchKernelGGL(kfn, dim3(vtiles), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K2, mtiles, ntiles, qcols, diag, tail);
+  }
   return hipGetLastError();
 }
 

@@ -137,6 +137,30 @@ def test_bf16_engine_against_the_oracles_bf16_emulation(tag, cfg, B, S):
     assert y0.abs().max().item() <= 1.0 and torch.isfinite(y0).all()
 
 
+def test_bf16_unfused_row_kernel_flow_meets_the_same_gates():
+    """"fused_postnorm" = 0 selects the bf16 flow with stand-alone LayerNorm kernels (three per block) instead of the whole-row
+    GEMM epilogues: the same rounding points, so the same gates against the emulation -- and the two flows sit within the
+    emulation's own self-distance of each other."""
+    from oracle import d3d_oracle as orc
+    cfg = cfg_full(27)
+    net, diff = build_product(cfg, 91, sampling=3, precision="bf16")
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(2, 27, 910)
+    xcat = torch.cat([inp["x2d"], inp["noise"] * 0.7], dim=-1)
+    t = torch.tensor([77, 508])
+    fused = net.forward_denoise(xcat.cuda(), t.cuda()).cpu()
+    eng.set_option("fused_postnorm", 0)
+    plain = net.forward_denoise(xcat.cuda(), t.cuda()).cpu()
+    eng.set_option("fused_postnorm", 1)
+    e32, e64, _ = _emulations(orc.forward_denoise, torch_sd(cfg, 91), xcat, t, depth=cfg.depth)
+    self_m = _mpjpe(e32, e64)
+    print(f"bf16 flows: fused vs emulation MPJPE {_mpjpe(fused, e32):.3e}, row-kernel flow vs emulation {_mpjpe(plain, e32):.3e}, "
+          f"fused vs row-kernel flow {_mpjpe(fused, plain):.3e}, emulation self-distance {self_m:.3e}")
+    for out in (fused, plain):
+        assert maxabs(out, e32) <= GATE_MAXABS and _mpjpe(out, e32) <= max(1.5 * self_m, GATE_MPJPE)
+    assert _mpjpe(fused, plain) <= max(1.5 * self_m, GATE_MPJPE) and not torch.equal(fused, plain)
+
+
 def test_bf16_large_batch_kernels_match_the_small_batch_path():
     """B = 32 at T = 243 runs the persistent 256x256 bf16 GEMM walk (tail slices) and eight-wave attention workgroups; every output
     element is tile-shape independent, so the large batch reproduces ragged small chunks bit for bit, twice; two streams too."""
