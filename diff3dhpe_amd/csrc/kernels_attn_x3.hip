@@ -63,6 +63,28 @@ __device__ __forceinline__ u32x4 patch_rd(const unsigned char* patch, int row, i
   return *reinterpret_cast<const u32x4_alias*>(patch + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
+// (e0, e1) -> packed fp16 pairs hi = fp16(k e), lo = fp16(k e - hi), k a power of two: v_fma_mixlo/mixhi_f16 do scale,
+// subtract (reading the fp16 hi half directly) and convert in one instruction each -- 2 VALU instructions per value where the
+// generic lowering (multiply, convert, convert back, subtract, convert, pack) takes 5.  Same values: k e and k e - hi are exact
+// in fp32, so every form rounds the same quantity once.  volatile: pins the split to the step it is written in.
+__device__ __forceinline__ void split_pair_f16(float e0, float e1, float k, unsigned& hi, unsigned& lo) {
+  asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(e0), "s"(k));
+  asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(e1), "s"(k));
+  asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(e0), "s"(k), "v"(hi));
+  asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(e1), "s"(k), "v"(hi));
+}
+// eight numerators (one 16-key k-step of a lane) -> the MFMA B fragments hi / lo of 1024 e
+__device__ __forceinline__ void split8_e(const float (&e)[8], h8& eh, h8& el) {
+  unsigned hp[4], lp[4];
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) split_pair_f16(e[2 * pr], e[2 * pr + 1], 1024.0f, hp[pr], lp[pr]);
+  u32x4 hv, lv;
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) { hv[pr] = hp[pr]; lv[pr] = lp[pr]; }
+  eh = __builtin_bit_cast(h8, hv);
+  el = __builtin_bit_cast(h8, lv);
+}
+
 // MU > 1 (only with NKT == 1, i.e. groups of <= 32 tokens: the spatial blocks): one workgroup carries MU independent
 // (group, head) units, one per wave, each in its own LDS slice -- a 64-thread workgroup per unit is bound by the
 // workgroup launch rate (124k launches per call at T=243, B=64), not by HBM.
@@ -194,13 +216,12 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
   for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      h8 eh, el;
+      h8 eh, el;                                                  // e in [0,1] -> hi/lo of 2^10 e
+      {
+        float e8[8];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const float ev = sacc[kt][8 * s + jj] * 1024.0f;          // e in [0,1] -> hi/lo of 2^10 e
-        const _Float16 hh = (_Float16)ev;
-        eh[jj] = hh;
-        el[jj] = (_Float16)(ev - (float)hh);
+        for (int jj = 0; jj < 8; ++jj) e8[jj] = sacc[kt][8 * s + jj];
+        split8_e(e8, eh, el);
       }
       const int k0 = kt * 32 + 16 * s + 4 * h;
       // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of (row k0+q, columns d0+4p..+3) and
@@ -490,12 +511,11 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         h8 eh, el;
+        {
+          float e8[8];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const float ev = sacc[kt][8 * s2 + jj] * 1024.0f;
-          const _Float16 hh = (_Float16)ev;
-          eh[jj] = hh;
-          el[jj] = (_Float16)(ev - (float)hh);
+          for (int jj = 0; jj < 8; ++jj) e8[jj] = sacc[kt][8 * s2 + jj];
+          split8_e(e8, eh, el);
         }
         const int k0 = kt * 32 + 16 * s2 + 4 * h;
         const int gi = lane & 15, tq_ = gi >> 2, tp_ = gi & 3;
@@ -646,16 +666,6 @@ __device__ __forceinline__ void lds_read_tr16_b64(s4v& dst, unsigned addr) {
 template <int N>
 __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
-// (e0, e1) -> packed fp16 pairs hi = fp16(k e), lo = fp16(k e - hi), k a power of two: v_fma_mixlo/mixhi_f16 do scale,
-// subtract (reading the fp16 hi half directly) and convert in one instruction each -- 2 VALU instructions per value where the
-// generic lowering (multiply, convert, convert back, subtract, convert, pack) takes 5.  Same values: k e and k e - hi are exact
-// in fp32, so every form rounds the same quantity once.  volatile: pins the split to the step it is written in.
-__device__ __forceinline__ void split_pair_f16(float e0, float e1, float k, unsigned& hi, unsigned& lo) {
-  asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(e0), "s"(k));
-  asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(e1), "s"(k));
-  asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(e0), "s"(k), "v"(hi));
-  asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(e1), "s"(k), "v"(hi));
-}
 
 // wave priority per phase (s_setprio): the two waves of a SIMD are in different phases; without it the OLDER wave's VALU stream
 // (softmax) wins every issue arbitration and the younger wave's MFMAs starve
