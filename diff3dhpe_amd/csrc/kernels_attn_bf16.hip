@@ -9,10 +9,12 @@
 //   O^T = V^T P^T         the accumulator tile of P is the B operand after a pairwise bf16 conversion; V^T fragments come from
 //                         row-major V through ds_read_b64_tr_b16
 // q, k, v: one bf16 buffer [rows][3 D] written by the qkv GEMM (launch_linear_bf16); output bf16 [rows][D], the proj GEMM's
-// operand.  One workgroup per (batch, joint, head) unit, NKT = ceil(T / 32) waves of 32 queries; K and V rows of the unit live
-// in LDS (128 B per row, 16-byte chunks XOR-swizzled: conflict-free fragment reads).  MU > 1 (NKT == 1): MU independent units
-// per workgroup, one per wave.  This is the plain load -> compute -> store form (no persistent walk, no LDS-DMA): the bf16
-// mode is a second-class precision and its attention is 6 % of the flops; measured numbers in DESIGN.md.
+// operand.  One workgroup per (batch, joint, head) unit; K and V rows of the unit live in LDS (128 B per row, 16-byte chunks
+// XOR-swizzled: conflict-free fragment reads); every further key tile / k-step of a fragment read is a compile-time offset of
+// four base addresses.  NKT = ceil(T / 32) key tiles; a wave owns one 32-query tile, or two in turn (QT = 2: T > 160) so that
+// the workgroup is four waves and two workgroups share a CU.  MU > 1 (NKT == 1): MU independent units per workgroup, one per
+// wave.  Plain load -> compute -> store per workgroup (no persistent walk, no LDS-DMA): overlap comes from the co-resident
+// workgroups (registers: 61 .. 250 VGPRs, no scratch).
 #include "d3d_kernels.h"
 
 #include <math.h>
@@ -32,15 +34,22 @@ __device__ __forceinline__ int vkey(int row) { return (((row >> 1) & 1) << 2) ^ 
 __device__ __forceinline__ int vswz(int row, int chunk) { return row * 128 + ((chunk ^ vkey(row)) << 4); }
 }  // namespace
 
-template <int NKT, int MU>
-__global__ __launch_bounds__(64 * NKT * MU) void k_attn_bf16(const __bf16* __restrict__ qkv, __bf16* __restrict__ out, int T, int J,
+// QT: 32-query tiles per wave (1 or 2).  QT = 2 halves the workgroup (NKT / 2 waves, each taking query tiles w and w + NKT / 2 one
+// after the other against the K / V rows staged once): a T = 243 unit is then a 4-wave workgroup with 64 KiB of LDS, and TWO of
+// them share a CU as independent instruction streams -- one's K / V loads and output stores sit under the other's MFMAs and
+// softmax (the 8-wave form has the CU to itself and serialises load -> compute -> store).
+template <int NKT, int MU, int QT = 1>
+__global__ __launch_bounds__(64 * ((NKT + QT - 1) / QT) * MU) __attribute__((amdgpu_waves_per_eu(QT)))   // (QT = 2: <= 256 VGPRs, two workgroups per CU)
+void k_attn_bf16(const __bf16* __restrict__ qkv, __bf16* __restrict__ out, int T, int J,
                                                              int H, int D, int units) {
   static_assert(MU == 1 || NKT == 1, "several units per workgroup only for single-tile groups");
+  static_assert(QT == 1 || (MU == 1 && NKT % QT == 0), "query-tile passes only for whole multiples");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   constexpr int TP = 32 * NKT;
+  constexpr int NW = (NKT + QT - 1) / QT;                          // waves of a unit
   const int lane = threadIdx.x & 63;
   const int sub = (MU > 1) ? (int)(threadIdx.x >> 6) : 0;          // unit of this workgroup
-  const int wave = (MU > 1) ? 0 : (int)(threadIdx.x >> 6);         // 32-query tile of the unit
+  const int wave = (MU > 1) ? 0 : (int)(threadIdx.x >> 6);         // first 32-query tile of this wave
   const int tid = (MU > 1) ? lane : (int)threadIdx.x;              // thread index within the unit
   unsigned char* const sK = lds_all + sub * (2 * TP * 128);        // [TP][128 B]
   unsigned char* const sV = sK + TP * 128;
@@ -56,11 +65,11 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_bf16(const __bf16* __res
   const size_t tok0 = (size_t)b * T * J + j;                       // token(t) = tok0 + t * J
 
   {  // ---- stage K and V rows of the unit (pad rows zero); all global loads are issued before the LDS writes
-    constexpr int NIT = 4;                                         // TP * 8 chunk slots / (64 * NKT threads)
+    constexpr int NIT = 4 * QT;                                    // TP * 8 chunk slots / (64 * NW threads)
     uint4 kk[NIT], vv[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + it * 64 * NKT;
+      const int idx = tid + it * 64 * NW;
       const int row = idx >> 3, c8 = idx & 7;
       kk[it] = make_uint4(0, 0, 0, 0); vv[it] = kk[it];
       if (row < T) {
@@ -71,21 +80,40 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_bf16(const __bf16* __res
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + it * 64 * NKT;
+      const int idx = tid + it * 64 * NW;
       const int row = idx >> 3, c8 = idx & 7;
       *reinterpret_cast<uint4*>(sK + kswz(row, c8)) = kk[it];
       *reinterpret_cast<uint4*>(sV + vswz(row, c8)) = vv[it];
     }
   }
+  __syncthreads();
+  // fragment addresses: four bases each for K (one per 16-deep d-step) and V^T (d-half x key-row half); every further key tile /
+  // k-step is a compile-time offset (both swizzles have period 16 in the row), i.e. the ds_read offset field, not a register
+  const unsigned char* kb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kb[ks] = sK + kswz(r, 2 * ks + h);                       // + 4096 kt
+  const unsigned char* vb[2][2];
+  {
+    const int gi = lane & 15, tq_ = gi >> 2, tp_ = gi & 3;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int d0 = dt * 32 + 16 * ((lane >> 4) & 1);
+      const int ch = (d0 >> 3) + (tp_ >> 1), sb = (tp_ & 1) * 8;
+      vb[dt][0] = sV + vswz(4 * h + tq_, ch) + sb;                                         // + 2048 (2 kt + s)
+      vb[dt][1] = sV + vswz(4 * h + 8 + tq_, ch) + sb;
+    }
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < QT; ++pass) {
   // ---- this lane's query row as MFMA B fragments: d = 16 ks + 8 h .. + 7
-  const int tq = 32 * wave + r;
+  const int tq = 32 * (wave + pass * NW) + r;
+  if (32 * (wave + pass * NW) >= T) break;                        // (wave-uniform)
   bf8 qf[4];
   {
     const size_t o = (tok0 + (size_t)(tq < T ? tq : 0) * J) * D3 + hd * BDH + 8 * h;   // rows >= T reuse row 0: never stored
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8*>(qkv + o + 16 * ks);
   }
-  __syncthreads();
 
   // ---- S^T tiles: rows = keys kt * 32 + (reg & 3) + 8 (reg >> 2) + 4 h, column = query tq
   f32x16 sacc[NKT];
@@ -95,7 +123,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_bf16(const __bf16* __res
     for (int q = 0; q < 16; ++q) sacc[kt][q] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf8 kf = *reinterpret_cast<const bf8*>(sK + kswz(kt * 32 + r, 2 * ks + h));
+      const bf8 kf = *reinterpret_cast<const bf8*>(kb[ks] + kt * 4096);
       sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
     }
   }
@@ -125,6 +153,19 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_bf16(const __bf16* __res
     }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
+  // softmax - I (S2S:82): the diagonal sits in ONE key tile (kt == this wave's query tile: wave-uniform) and, inside it, in the
+  // lanes whose half h holds key r -- ((r >> 2) & 1) == h -- at register 8 (r >> 4) + 4 ((r >> 3) & 1) + (r & 3).  Its numerator
+  // becomes e - l, so that the normalisation below yields p - 1 for it: sixteen selects in one tile instead of a compare per score.
+  {
+    const int qt = __builtin_amdgcn_readfirstlane(tq >> 5);
+    const int didx = (((r >> 2) & 1) == h) ? (8 * (r >> 4) + 4 * ((r >> 3) & 1) + (r & 3)) : -1;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+      if (kt == qt) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc[kt][q] -= (q == didx) ? l : 0.0f;
+      }
+  }
 
   // ---- O^T[d][query] = sum_key V^T[d][key] (P - I)^T[key][query].  k-step (kt, s) takes accumulator registers 8 s .. 8 s + 7:
   // element jj of lane half h is key kt * 32 + 16 s + 8 (jj >> 2) + 4 h + (jj & 3); the V^T fragment is read in that order.
@@ -137,21 +178,11 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_bf16(const __bf16* __res
     for (int s = 0; s < 2; ++s) {
       bf8 pf;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const int key = kt * 32 + 16 * s + 8 * (jj >> 2) + 4 * h + (jj & 3);
-        float p = sacc[kt][8 * s + jj] * inv;
-        if (key == tq) p -= 1.0f;                                  // softmax - I (S2S:82)
-        pf[jj] = (__bf16)p;
-      }
-      const int k0 = kt * 32 + 16 * s + 4 * h;
-      const int gi = lane & 15, tq_ = gi >> 2, tp_ = gi & 3;
+      for (int jj = 0; jj < 8; ++jj) pf[jj] = (__bf16)(sacc[kt][8 * s + jj] * inv);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const int d0 = dt * 32 + 16 * ((lane >> 4) & 1);
-        const int ch = (d0 >> 3) + (tp_ >> 1), sb = (tp_ & 1) * 8;
-        const int o0 = vswz(k0 + tq_, ch) + sb, o1 = vswz(k0 + 8 + tq_, ch) + sb;
-        const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sV + o0));
-        const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(sV + o1));
+        const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(vb[dt][0] + (2 * kt + s) * 2048));
+        const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(uintptr_t)(vb[dt][1] + (2 * kt + s) * 2048));
         bf8 vf;
         const bf4 a0b = __builtin_bit_cast(bf4, a0), a1b = __builtin_bit_cast(bf4, a1);
 #pragma unroll
@@ -174,19 +205,20 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_bf16(const __bf16* __res
         *reinterpret_cast<bf4*>(orow + dt * 32 + 8 * g4 + 4 * h) = o;
       }
   }
+  }   // pass
 }
 
 bool attn_bf16_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * BDH; }
 
-template <int NKT, int MU = 1>
+template <int NKT, int MU = 1, int QT = 1>
 static hipError_t launch_nkt(const __bf16* qkv, __bf16* out, int B, int T, int J, int D, int H, hipStream_t s) {
   const size_t lds_bytes = (size_t)MU * 2 * 32 * NKT * 128;
   static std::atomic<unsigned long long> attr_set{0};   // one bit per device
-  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_bf16<NKT, MU>), lds_bytes, attr_set)) return e;
+  if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_bf16<NKT, MU, QT>), lds_bytes, attr_set)) return e;
   const long long units = (long long)B * J * H;
   if (units > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((k_attn_bf16<NKT, MU>), dim3((unsigned)((units + MU - 1) / MU)), dim3(64 * NKT * MU), lds_bytes, s, qkv, out, T, J,
-                     H, D, (int)units);
+  hipLaunchKernelGGL((k_attn_bf16<NKT, MU, QT>), dim3((unsigned)((units + MU - 1) / MU)), dim3(64 * ((NKT + QT - 1) / QT) * MU), lds_bytes, s,
+                     qkv, out, T, J, H, D, (int)units);
   return hipGetLastError();
 }
 
@@ -201,9 +233,9 @@ hipError_t launch_attn_bf16(const void* qkv_bf16, void* out_bf16, int B, int T, 
     case 3: return launch_nkt<3>(q, o, B, T, J, D, H, s);
     case 4: return launch_nkt<4>(q, o, B, T, J, D, H, s);
     case 5: return launch_nkt<5>(q, o, B, T, J, D, H, s);
-    case 6: return launch_nkt<6>(q, o, B, T, J, D, H, s);
+    case 6: return launch_nkt<6, 1, 2>(q, o, B, T, J, D, H, s);
     case 7: return launch_nkt<7>(q, o, B, T, J, D, H, s);
-    default: return launch_nkt<8>(q, o, B, T, J, D, H, s);
+    default: return launch_nkt<8, 1, 2>(q, o, B, T, J, D, H, s);   // two 4-wave workgroups per CU
   }
 }
 
