@@ -45,7 +45,7 @@ def demangle(name: str) -> str:
 
 
 _EPI = {"0": "EPI_NONE", "1": "EPI_GELU", "2": "EPI_RESIDUAL"}
-_OUT = {"0": "fp32-out", "1": "planes-out", "2": "pair-out"}
+_OUT = {"0": "fp32-out", "1": "planes-out", "2": "pair-out", "3": "bf16-out"}
 
 
 def short(name: str) -> str:
@@ -53,7 +53,8 @@ def short(name: str) -> str:
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("d3d::", "").strip()
     _FX = {"0": "", "1": ", LN-folded", "2": ", plane residual", "6": ", plane residual + row stats",
-           "10": ", plane residual + post-norm in the epilogue"}
+           "10": ", plane residual + post-norm in the epilogue", "16": ", bf16 operands",
+           "24": ", bf16 operands, whole rows + LayerNorm(s) in the epilogue"}
     m = re.match(r"k_linear_x3q(_persist)?<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
     if m:   # <TM, WM, WN, EPI, OUTSPLIT, FX> -> tile and role
         per, tm, wm, wn, epi, osp, fx = m.groups()
@@ -62,11 +63,21 @@ def short(name: str) -> str:
                 ("1", "2"): "fc1"}.get((epi, osp), "")
         if fx == "10":
             role = "fc2 + post-norm" + (", last block" if osp == "0" else "")
+        if fx == "16":
+            role = {("0", "3"): "qkv", ("1", "3"): "fc1", ("2", "0"): "proj / fc2"}.get((epi, osp), "")
+        if fx == "24":
+            role = "proj + norm2 / fc2 + post-norm + next norm1"
         return "k_linear_x3q<{}, {}, {}{}>{}".format(tile, _EPI[epi], _OUT[osp], _FX.get(fx or "0", ", fx" + str(fx)),
                                                    " (" + role + ")" if role else "")
     m = re.match(r"k_attn_temporal_x3<(\d+), (\d+)>", name)
     if m:
         return "k_attn_temporal_x3<{} key tiles, {} units/wg>{}".format(m.group(1), m.group(2), " (spatial blocks)" if m.group(2) != "1" else " (temporal blocks)")
+    m = re.match(r"k_attn_temporal_x3p<1, (\d+), (\d+)>", name)
+    if m:   # wave-private persistent form: 8 units per workgroup = spatial blocks (17 joints), 6 = temporal blocks of T <= 32
+        return "k_attn_temporal_x3p<1, {}, {}>{}".format(m.group(1), m.group(2), " (spatial blocks)" if m.group(1) == "8" else " (temporal blocks)")
+    m = re.match(r"k_attn_bf16<(\d+), (\d+), (\d+)>", name)
+    if m:
+        return "k_attn_bf16<{} key tiles, {} units/wg, {} query tiles/wave>{}".format(m.group(1), m.group(2), m.group(3), " (spatial blocks)" if m.group(2) != "1" else " (temporal blocks)")
     return name[:70]
 
 
@@ -144,9 +155,11 @@ def traffic(pmc_json, traffic_json, T, B, prec):
     # kernel name patterns per class; the fp16-MFMA attention serves both block types from one template: <1, MU> = groups of
     # <= 32 tokens = the spatial blocks, everything else (x3s<8>, x3p<3, 1>, x3p<8, 1>, x3<NKT, 1>) the temporal blocks
     def is_spatial(n):
+        if "(temporal blocks)" in n:
+            return False
         return "k_attn_spatial" in n or "k_attn_temporal_x3p<1," in n or "k_attn_temporal_x3<1," in n or "(spatial blocks)" in n
     cls = {"linear": lambda n: "k_linear" in n, "layernorm": lambda n: "k_layernorm" in n,
-           "attn_spatial": is_spatial, "attn_temporal": lambda n: "k_attn_temporal" in n and not is_spatial(n)}
+           "attn_spatial": is_spatial, "attn_temporal": lambda n: ("k_attn_temporal" in n or "k_attn_bf16" in n) and not is_spatial(n)}
     tj = json.load(open(traffic_json)) if os.path.exists(traffic_json) else {}
     for c, pat in cls.items():
         sel = [v for n, v in k.items() if pat(n)]
