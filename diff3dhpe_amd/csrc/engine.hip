@@ -426,7 +426,8 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
 // head stay fp32.  Operand roundings sit exactly where the oracle's bf16-operand emulation puts them: LN output -> bf16 (row
 // kernel), q / k / v -> bf16 (qkv epilogue), softmax - I -> bf16 (attention kernel), attention output -> bf16, GELU output ->
 // bf16 (fc1 epilogue), weights -> bf16 (commit).  Same op sequence as run_blocks (S2S:222-247, 111-135); leaves the final
-// Temporal_norm output as fp32 in w.X.  Not fused further on purpose: it is measured first.
+// Temporal_norm output as fp32 in w.X.  Measured first with three LayerNorm row kernels per block, then
+// given the whole-row proj / fc2 forms below; the row-kernel flow stays behind "fused_postnorm" = 0.
 int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast, const float* tvec, int64_t tvec_stride, int B,
                     const Workspace& w, hipStream_t s) {
   const int T = e->T, J = e->J, D = e->D;

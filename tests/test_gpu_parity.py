@@ -282,7 +282,8 @@ def test_folded_layernorm_statistics_with_offset_rows(off):
     sum of squares) partials -- a one-pass form whose relative error grows like eps * (1 + mean^2/var).  Rows of the stream are
     LayerNorm outputs (|mean| well below the standard deviation for any sane checkpoint); this test pushes the post-norm biases
     and the position embeddings so that |mean| = 2 and 8 standard deviations and checks the gate against the oracle (two-pass
-    statistics) still holds with a wide margin.  DESIGN.md section 4.1 states the bound."""
+    statistics) still holds with a wide margin.  DESIGN.md section 2 states the bound; the guard bit that covers the rest of
+    the range is tested in tests/test_gpu_round3.py::test_range_guard_row_statistics_bit."""
     from oracle import d3d_oracle as orc
     cfg = cfg_full(9)
     sd = torch_sd(cfg, 77)
