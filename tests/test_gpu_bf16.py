@@ -180,6 +180,43 @@ def test_bf16_large_batch_kernels_match_the_small_batch_path():
     assert torch.isfinite(big).all() and big.abs().max().item() <= 1.0
 
 
+def test_bf16_side_paths_eta_repeat_plosses_graph():
+    """The section 8(f) rows through the bf16 flow: eta > 0 with supplied step noise + repeat_n, p_losses with per-row timesteps,
+    hipGraph replay == eager -- against the emulation at the gates of the main test."""
+    from oracle import d3d_oracle as orc
+    from helpers import hashed
+    cfg = cfg_full(27)
+    B, S, R = 2, 3, 2
+    sd, tabs = torch_sd(cfg, 93), orc.diffusion_tables("cosine", 1000)
+    _, diff = build_product(cfg, 93, sampling=S, eta=0.5, precision="bf16")
+    inp = inputs(B * R, 27, 930)
+    sn = torch.stack([hashed(f"bfeta/{i}", tuple(inp["noise"].shape), 9) for i in range(S)])
+    _, y0 = diff(clean_3d_pose=torch.zeros(B, 27, 17, 3).cuda(), noisy_2d_pose=inp["x2d"][:B].cuda(), output_loss=False, repeat_n=R,
+                 init_noise=inp["noise"].cuda(), step_noise=sn.cuda())
+    kw = dict(num_timesteps=1000, sampling_timesteps=S, depth=cfg.depth, eta=0.5, step_noise=list(sn))
+    e32, e64, _ = _emulations(orc.ddim_sample_loop, sd, tabs, inp["x2d"][:B].repeat(R, 1, 1, 1), inp["noise"], **kw)
+    mean = lambda t: t.view(R, B, 27, 17, 3).mean(0)
+    assert maxabs(y0, mean(e32)) <= 2.5 * GATE_MAXABS and _mpjpe(y0, mean(e32)) <= max(1.5 * _mpjpe(mean(e32), mean(e64)), GATE_MPJPE)
+    # p_losses (DIFF:392-419), per-row timesteps
+    gt = inp["gt3d"][:3] * 0.5
+    t = torch.tensor([999, 12, 500])
+    loss = diff.p_losses(gt.cuda(), inp["x2d"][:3].cuda(), noise=inp["noise"][:3].cuda(), t=t.cuda())
+    with orc.operand_rounding(torch.bfloat16):
+        ref = orc.p_losses(sd, tabs, gt, inp["x2d"][:3], t, inp["noise"][:3], depth=cfg.depth, clip_loss=True)
+    # the loss is coef * (out - x_start)^2 with coef <= 3: an output difference d moves it by 2 coef |out - x_start| d
+    assert maxabs(loss, ref) <= 6.0 * float(ref.max().sqrt()) * GATE_MAXABS + 1e-3, (maxabs(loss, ref), float(ref.max()))
+    # graph replay
+    _, d0 = build_product(cfg, 93, sampling=S, precision="bf16")
+    eng = d0._engine(torch.device("cuda", torch.cuda.current_device()))
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eager = eng.ddim_sample(x2d, nz).clone()
+    eng.set_graph_mode(True)
+    try:
+        assert torch.equal(eng.ddim_sample(x2d, nz), eager) and torch.equal(eng.ddim_sample(x2d, nz), eager)
+    finally:
+        eng.set_graph_mode(False)
+
+
 def test_bf16_mode_refuses_shapes_it_has_no_kernels_for():
     import diff3dhpe_amd as d3d
     from diff3dhpe_amd import _lib

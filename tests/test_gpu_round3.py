@@ -265,3 +265,20 @@ def test_set_option_rejects_what_it_does_not_know():
         assert maxabs(eng.ddim_sample(inp["x2d"].cuda(), inp["noise"].cuda()), ref) <= GATE, key
         if key:
             eng.set_option(key, 1)
+
+
+def test_trainedlike_family_on_the_large_batch_kernels():
+    """The per-matrix weight scale (2^k, k < 12 for the LayerNorm-folded weights of this family) in the kernels the goldens do
+    not reach: B = 32 at T = 243 runs the persistent 256x256 walk, its tail slices and the whole-row fc2 form with k = 9 .. 11;
+    the result must be bit for bit the one of ragged small chunks (256x128 tiles, one tile per workgroup), with the guard silent."""
+    cfg = cfg_full(243)
+    _, diff = _tl_product(cfg, 11, "f16x3", sampling=1)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    eng.range_flags(clear=True)
+    inp = inputs(32, 243, 500)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    big = eng.ddim_sample(x2d, nz).clone()
+    for lo in (0, 13, 26):
+        hi = min(lo + 13, 32)
+        assert torch.equal(eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous()), big[lo:hi])
+    assert eng.range_flags() == 0 and torch.isfinite(big).all() and big.abs().max().item() <= 1.0
