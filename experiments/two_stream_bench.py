@@ -2,7 +2,9 @@
 """Does running two half-batches on two HIP streams overlap the HBM-bound kernels of one with the MFMA-bound GEMMs of the
 other?  Samples are independent through the whole DDIM loop, so the split is a pure re-scheduling (bit-identical output).
 
-    python experiments/two_stream_bench.py [B] [T] [S] [reps]
+    python experiments/two_stream_bench.py [B] [T] [S] [reps]          PARTS="32,32;22,21,21;16,16,16,16" for other splits
+The engine does the 2-way equal split by itself since round 3 ("streams" = 2, the default); here every sub-call runs with
+"streams" = 1 and the script does the splitting, so that other ratios and 3- / 4-way splits can be compared.
 """
 import os
 import sys
@@ -35,9 +37,11 @@ def make():
 inp = synth_inputs(B, T, seed=42)
 x2d = torch.from_numpy(inp["x2d"]).to(dev)
 noise = torch.from_numpy(inp["noise"]).to(dev)
-keep = [make(), make()]
+keep = [make() for _ in range(4)]
 engs = [k[1] for k in keep]
-streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+for e in engs:
+    e.set_option("streams", 1)
+streams = [torch.cuda.Stream(dev) for _ in range(4)]
 
 
 def one_stream():
@@ -45,14 +49,21 @@ def one_stream():
 
 
 def two_streams(split):
+    return multi([split, B - split])
+
+
+def multi(parts):
     outs = []
     cur = torch.cuda.current_stream(dev)
-    bounds = [(0, split), (split, B)]
+    bounds, lo = [], 0
+    for p_ in parts:
+        bounds.append((lo, lo + p_))
+        lo += p_
     for i, (lo, hi) in enumerate(bounds):
         streams[i].wait_stream(cur)
         with torch.cuda.stream(streams[i]):
             outs.append(engs[i].ddim_sample(x2d[lo:hi], noise[lo:hi]))
-    for s in streams:
+    for s in streams[:len(bounds)]:
         cur.wait_stream(s)
     return torch.cat(outs, 0)
 
@@ -77,3 +88,8 @@ splits = [int(v) for v in os.environ.get("SPLITS", f"{B // 2},{B - 1},{B - 2},{B
 for split in splits:
     t2, out = timeit(two_streams, split)
     print(f"two streams {split}+{B - split}: {t2 * 1e3:8.1f} ms  {B / t2:7.2f} seq/s  bit-identical={bool((out == ref).all())}", flush=True)
+for spec in [v for v in os.environ.get("PARTS", "").split(";") if v]:
+    parts = [int(v) for v in spec.split(",")]
+    assert sum(parts) == B and len(parts) <= 4
+    t2, out = timeit(multi, parts)
+    print(f"streams {'+'.join(map(str, parts))}: {t2 * 1e3:8.1f} ms  {B / t2:7.2f} seq/s  bit-identical={bool((out == ref).all())}", flush=True)
