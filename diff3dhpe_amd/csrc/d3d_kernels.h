@@ -87,6 +87,7 @@ int split_weight_f16x3(const float* w, size_t rows, size_t cols, uint16_t* pair,
 //   st_in != null  : A holds the RAW rows x (pair layout of 8x), W holds W*diag(gamma), bias holds b + W beta, csum[n] =
 //                    sum_k W[n,k] gamma[k]; the epilogue forms  LN(x) W^T + b = rstd (x W'^T) - rstd mu csum + b'  with the
 //                    row's mean / rstd from st_in[(m * st_np + p)] = (sum, sum of squares) partials over the K columns
+//                    (the buffer spans whole 256-row tiles: the persistent walk stages a tile's block of it by LDS-DMA)
 //   Rp != null     : EPI_RESIDUAL takes the residual from a pair-layout plane buffer [M][2N] of 8r (instead of fp32 R);
 //                    with outsplit == 2 and Ch == Rp the residual stream is updated in place, plane to plane
 //   st_out != null : (with EPI_RESIDUAL) per row and 64-column block the (sum, sum of squares) of the new row values go to

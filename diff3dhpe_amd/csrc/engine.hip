@@ -270,7 +270,8 @@ Workspace carve(const d3d_engine* e, int B, void* base) {
   size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
   size_t oRED = take((size_t)B * e->J * D), oTI = take((size_t)B + 64);
   size_t oXI = take(M * e->cfg.in_chans), oNI = take(M * 3), oOB = take(M * 3);   // graph-mode staging copies
-  size_t oS1 = take(M * 2 * (size_t)((D + 63) / 64)), oS2 = take(M * 2 * (size_t)((D + 63) / 64));      // row statistics of the LN-folded GEMMs
+  // row statistics of the LN-folded GEMMs; whole 256-row tiles, the persistent walk stages a tile's block of them by LDS-DMA
+  size_t oS1 = take(Mp * 2 * (size_t)((D + 63) / 64)), oS2 = take(Mp * 2 * (size_t)((D + 63) / 64));
   w.X = b + oX; w.HN = b + oHN; w.QKV = b + oQKV; w.HID = b + oHID; w.Y0 = b + oY0; w.Y1 = b + oY1;
   w.TEMB = b + oTE; w.TSCR = b + oTS; w.RED = b + oRED; w.TIMES = b + oTI;
   w.XIN = b + oXI; w.NIN = b + oNI; w.OUTB = b + oOB; w.ST1 = b + oS1; w.ST2 = b + oS2;

@@ -194,13 +194,29 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   unsigned long long st_c0 = 0, st_r0 = 0;
   if (diag) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   unsigned char* const lds_x = lds + 2 * STAGE;   // beyond the operand stages (allocated only for the folded forms)
-  if (FX & FX_LNF) {   // row statistics of the LayerNorm folded into this GEMM; visible after the first k-tile barrier
+  const int tid = tidx;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, q = lane >> 4;
+  // Row statistics of the LayerNorm folded into this GEMM: (rstd, -mean rstd) per tile row in lds_x, from the producer's (sum, sum
+  // of squares) partials.  Persistent walk: the raw partials of the tile's rows -- one contiguous block -- are requested by LDS-DMA
+  // here, land under the k-loop and are reduced from LDS in front of the epilogue (x3_row_stats below); loaded into registers at
+  // this point they cost every tile an exposed L2 round trip before its first k-tile (measured upper bound: qkv -2.0 %, fc1 -1.7 %
+  // per launch with the loads removed).  One tile per workgroup: loaded and reduced here, visible after the first k-tile barrier.
+  constexpr bool ST_DMA_FORM = PERSIST && (FX & FX_LNF) != 0;
+  constexpr int ST_RAW_MAX = 16384;                                // bytes of lds_raw (BM rows x up to 8 partials x 8 B at BM = 256)
+  unsigned char* const lds_raw = lds_x + BM * 8;
+  const int st_bytes = (FX & FX_LNF) ? BM * fx.st_np * 8 : 0;
+  const bool st_dma = ST_DMA_FORM && st_bytes <= ST_RAW_MAX;       // (uniform)
+  int st_issued = 0;                                               // DMA pieces of the statistics this wave has in flight
+  auto x3_row_stats = [&](auto&& partial) {                        // partial(row_in_tile, p) -> float2; same order of additions either way
     if (tidx < BM) {
       const int row = m0 + tidx;
       float sm = 0.f, sq = 0.f;
       if (row < M)
         for (int p = 0; p < fx.st_np; ++p) {
-          const float2 t = *reinterpret_cast<const float2*>(fx.st_in + 2 * ((size_t)row * fx.st_np + p));
+          const float2 t = partial(tidx, p);
           sm += t.x; sq += t.y;
         }
       // range guard for the producer of these rows (the proj / fc2 epilogues write the planes of x and these statistics of the
@@ -213,13 +229,23 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       const float rstd = 1.0f / sqrtf(var + fx.eps);
       reinterpret_cast<float2*>(lds_x)[tidx] = make_float2(rstd, -mean * rstd);
     }
+  };
+  if constexpr ((FX & FX_LNF) != 0) {
+    if (st_dma) {   // pieces of 1 KiB: wave w takes pieces w, w + NW (the st_in buffer is padded to whole tiles of rows)
+      const char* src = reinterpret_cast<const char*>(fx.st_in + (size_t)m0 * fx.st_np * 2);
+#pragma unroll
+      for (int it = 0; it < ST_RAW_MAX / 1024 / NW; ++it) {
+        const int pc = wave + it * NW;
+        if (pc * 1024 < st_bytes) {
+          __builtin_amdgcn_global_load_lds(sgpr_ptr(src + pc * 1024) + lane * 16,
+                                           (__attribute__((address_space(3))) void*)(uintptr_t)(lds_raw + pc * 1024), 16, 0, 0);
+          ++st_issued;
+        }
+      }
+    } else {
+      x3_row_stats([&](int r, int p) { return *reinterpret_cast<const float2*>(fx.st_in + 2 * ((size_t)(m0 + r) * fx.st_np + p)); });
+    }
   }
-
-  const int tid = tidx;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int r16 = lane & 15, q = lane >> 4;
   // (a compile-time switch: with run-time ranges in the whole-tile path too, the whole GEMM ran 3.5 % slower)
   const bool w_act = !SUB || sub_wm < 0 || wm == sub_wm;          // wave-uniform
   const int gl = SUB ? (w_act ? g_lo : 0) : 0, gh = SUB ? (w_act ? g_hi : 0) : TM;
@@ -507,8 +533,9 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       else issued_prev = (DO_W) ? B_IT : 0;                                                                               \
     } while (0)
     h8 bh[4], bl[4], ah[2], al[2];
-    // first k-tile: everything issued before this tile (stores of the previous epilogue included) has landed: vmcnt(0)
-    issued_prev = 0;
+    // first k-tile: everything issued before this tile (stores of the previous epilogue included) has landed: vmcnt(0) -- but
+    // for the statistics pieces just requested (the newest: vmcnt retires in order)
+    issued_prev = st_issued;
     D3D_PHASE(0, 0, true, true, false);
     D3D_PHASE(0, 1, false, false, nk > 2 || has_next);
     int kt = 1;
@@ -535,6 +562,13 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
 #undef D3D_QSTAGE_ONE
 #undef D3D_QSTAGE_NEXT
 
+  if constexpr (ST_DMA_FORM) {
+    if (st_dma) {   // the raw partials landed under the k-loop (every wave's second-phase wait retired its pieces -- vmcnt is in
+                    // order --, and the phase barriers since made them visible): reduce them from LDS, in the order of the direct form
+      x3_row_stats([&](int r, int p) { return reinterpret_cast<const float2*>(lds_raw)[r * fx.st_np + p]; });
+      __syncthreads();
+    }
+  }
   const int mt0 = m0 + wm * 16 * TM, nt0 = n0 + wn * 64;          // wave-uniform
   const size_t tbase = (size_t)mt0 * N + nt0;
   const float* Rt = R ? R + tbase : nullptr;
@@ -821,7 +855,7 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
     if (fold->st_out) fx |= FX_SO;
     tail.st_in = fold->st_in; tail.st_np = fold->st_np; tail.csum = fold->csum; tail.eps = fold->eps;
     tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out;
-    if (fx & FX_LNF) lds_bytes += (size_t)256 * 8;
+    if (fx & FX_LNF) lds_bytes += (size_t)256 * 8 + 16384;   // (rstd, -mean rstd) per row + the raw partials staged by LDS-DMA
     if ((fx & FX_LNF) && (!fold->csum || fold->st_np < 1)) return hipErrorInvalidValue;
   }
 #define D3D_X3P_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
