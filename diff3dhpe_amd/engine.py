@@ -119,6 +119,8 @@ class Engine:
             tdev = _f32c(time.reshape(-1), self.device)
             n_t = tdev.numel()
         out = torch.empty((B, self._out_frames(), cfg.num_joints, 3), dtype=torch.float32, device=self.device)
+        if B == 0:          # an empty shard (fewer windows than ranks): the reference returns an empty tensor, the C ABI takes B >= 1
+            return out
         ws = self._workspace(B)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().d3d_denoise(self._h, _ptr(x2d), _ptr(y), int(y.shape[1]), _ptr(tdev), n_t, _ptr(out), B, _ptr(ws),
@@ -144,6 +146,8 @@ class Engine:
         if trajectory:
             rev = torch.empty((B, Fo, cfg.num_joints, 3, S), dtype=torch.float32, device=self.device)
             x0s = torch.empty_like(rev)
+        if B == 0:          # (as in denoise)
+            return (out, rev, x0s) if trajectory else out
         ws = self._workspace(B)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().d3d_ddim_sample(self._h, _ptr(x2d), _ptr(init_noise), _ptr(step_noise), _ptr(out),

@@ -53,10 +53,14 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
         torch.cuda.synchronize(dev)
         t0 = time.time()
         shape = gt[sl].shape
-        _, pred = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d[sl].to(dev), output_loss=False,
-                                  init_noise=None if batch.get("init_noise") is None else batch["init_noise"][sl])
         pred_f = None
-        if test_time_augmentation:
+        if hi == lo:        # fewer windows than ranks: nothing to sample on this rank (forward() cannot take an empty batch)
+            pred = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+            pred_f = pred.clone() if test_time_augmentation else None
+        else:
+            _, pred = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d[sl].to(dev), output_loss=False,
+                                      init_noise=None if batch.get("init_noise") is None else batch["init_noise"][sl])
+        if test_time_augmentation and hi > lo:
             _, pred_f = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d_f[sl].to(dev), output_loss=False,
                                         init_noise=None if batch.get("init_noise_flip") is None else batch["init_noise_flip"][sl])
         gsl = sl

@@ -82,8 +82,14 @@ def short(name: str) -> str:
 
 
 def find(dirpath, pattern):
+    """Files of ONE profiled process: rocprofv3 names its outputs <pid>_*.csv, and gpurun merges the directories of
+    successive calls, so an older run's files can sit next to the newest -- keep the newest pid's only."""
     hits = glob.glob(os.path.join(dirpath, "**", pattern), recursive=True)
-    return sorted(hits)
+    if not hits:
+        return []
+    newest = max(hits, key=os.path.getmtime)
+    pid = os.path.basename(newest).split("_")[0]
+    return sorted(h for h in hits if os.path.basename(h).split("_")[0] == pid)
 
 
 def stats(dirpath, out):

@@ -175,6 +175,15 @@ def test_batch_independence_sharding_and_determinism(prec):
         parts.append(p)
     assert torch.equal(torch.cat(parts), full)
     assert full.abs().max().item() <= 1.0 and torch.isfinite(full).all()
+    # fewer windows than ranks: an empty shard comes back empty from the sampling loop (the reference's forward() cannot take
+    # one -- its view(repeat_n, 0, f, p, -1) is ambiguous --, so evaluate() does not call it for such a rank)
+    parts = []
+    for r in range(8):
+        lo, hi = parallel.shard_bounds(6, r, 8)
+        p = diff.ddim_sample_loop(x2d[lo:hi], [hi - lo, 243, 17, 3], init_noise=nz[lo:hi])
+        assert tuple(p.shape) == (hi - lo, 243, 17, 3)
+        parts.append(p)
+    assert parts[-1].shape[0] == 0 and torch.equal(torch.cat(parts), full)
 
 
 @pytest.mark.parametrize("prec", PRECS)

@@ -282,3 +282,48 @@ def test_trainedlike_family_on_the_large_batch_kernels():
         hi = min(lo + 13, 32)
         assert torch.equal(eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous()), big[lo:hi])
     assert eng.range_flags() == 0 and torch.isfinite(big).all() and big.abs().max().item() <= 1.0
+
+
+EVAL_WORKER = """
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["D3D_ROOT"]); sys.path.insert(0, os.path.join(os.environ["D3D_ROOT"], "tests"))
+from helpers import cfg_small, build_product, inputs, hashed
+from diff3dhpe_amd.evaluate import evaluate
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world)
+_, diff = build_product(cfg_small(27), 12, sampling=3, precision="f16x3")
+batches = []
+for B, seed in ((3, 5), (1, 6)):            # ragged over two ranks (2 + 1), then fewer windows than ranks (1 + 0)
+    inp = inputs(B, 27, seed)
+    mask = torch.ones(B, 27, dtype=torch.bool); mask[-1, 20:] = False
+    batches.append({"inputs_2d": inp["x2d"], "inputs_3d": inp["gt3d"], "target_mask": mask, "init_noise": inp["noise"],
+                    "init_noise_flip": hashed("flipnoise", tuple(inp["noise"].shape), seed)})
+res = evaluate(diff, batches, scale=1.3, verbose=False)
+print("RESULT " + json.dumps({"mpjpe_mm": res["mpjpe_mm"], "frames": res["frames"]}))
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_evaluate_two_ranks_with_fewer_windows_than_ranks(tmp_path):
+    """evaluate() as two torch.distributed ranks sharing cuda:0 (gloo): shards 2 + 1, then 1 + 0 -- the rank without a window
+    skips the sampling call (the reference's forward() cannot take an empty batch) and still joins the all-gather; every rank
+    reports the one-process MPJPE and frame count, bit for bit."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    script = tmp_path / "eval_worker.py"
+    script.write_text(EVAL_WORKER)
+    env = dict(os.environ, D3D_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", OMP_NUM_THREADS="1")
+
+    def result(out):
+        return json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+    one = subprocess.run([sys.executable, str(script)], env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, WORLD_SIZE="2", RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+        assert result(o) == result(one.stdout), (result(o), result(one.stdout))
+    assert result(one.stdout)["frames"] == 4 * 27 - 2 * 7
