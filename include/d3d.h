@@ -100,6 +100,8 @@ int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* o
 size_t d3d_workspace_bytes(const d3d_engine* e, int32_t B);
 
 /* ---- compute: all asynchronous on `stream` ------------------------------------------------------------------------ */
+/* B >= 1 (D3D_EINVAL otherwise): a rank whose shard of a batch is empty skips the call, as the host layer does
+ * (diff3dhpe_amd/engine.py returns the empty tensor the reference's torch ops would, evaluate.py does not call). */
 
 /* forward_denoise (S2S:249-257 / S2F:253-266) on cat([x2d, y], -1) (DIFF:255).  times_dev: n_times fp32 timesteps on
  * the device, n_times == 1 (broadcast, the sampling case DIFF:254) or == B (per-row, the p_losses case DIFF:392-408).
