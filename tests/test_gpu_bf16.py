@@ -88,8 +88,9 @@ def test_bf16_attention_matches_rounded_operand_math(B, T, J, temporal):
     assert err <= 3e-2 * max(1.0, ref.abs().max().item() / 4) and exact >= 0.998
 
 
-CASES = [("T27", cfg_full(27), 2, 9), ("T81", cfg_full(81), 2, 5), ("T243", cfg_full(243), 1, 3),
-         ("s2f_T27", cfg_full(27, seq2frame=True), 2, 5), ("notemb_T27", cfg_full(27, with_time_emb=False), 2, 5)]
+# (sized by the CPU emulation, which runs three times per case -- fp32, bf16 operands with fp32 and with fp64 accumulation)
+CASES = [("T27", cfg_full(27), 2, 9), ("T81", cfg_full(81), 1, 3), ("T243", cfg_full(243), 1, 2),
+         ("s2f_T27", cfg_full(27, seq2frame=True), 2, 3), ("notemb_T27", cfg_full(27, with_time_emb=False), 2, 3)]
 
 
 def _emulations(fn, sd, *args, **kw):
