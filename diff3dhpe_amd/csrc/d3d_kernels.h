@@ -35,6 +35,14 @@ inline int device_cu_count() {
   return n;
 }
 
+// Launch context of the calling thread (launches are issued synchronously by the thread that calls the C ABI).  tail_slices:
+// whether a persistent GEMM walk cuts the tiles of its partly filled last round into row slices (kernels_gemm_x3p.hip, X3Walk).
+// On one stream that fills CUs which would idle for a tile time (+1.3 %); with two half-batches on two streams the other half's
+// kernel takes those CUs, and slices -- 4x the workgroups for 0.7-1.0 of a tile time each -- only cost CU time (-0.6 %), so the
+// two-stream loop turns them off.  Values do not depend on it.
+struct LaunchCtx { bool tail_slices = true; };
+extern thread_local LaunchCtx tl_launch_ctx;
+
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 
 // ---- F16X3 operand ("pair") layout ---------------------------------------------------------------------------------

@@ -1058,6 +1058,11 @@ int ddim_loop_split(d3d_engine* e, const float* x2d0, const float* x2d1, const f
   const size_t rows0 = (size_t)head_rows(e, sw.B0) * 3, rows_all = (size_t)head_rows(e, B) * 3;
   HIP_TRY(hipEventRecord(e->ev_fork, s));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+  struct NoSlices {   // (d3d_kernels.h, LaunchCtx: the other half fills the partly filled rounds)
+    bool saved = tl_launch_ctx.tail_slices;
+    NoSlices() { tl_launch_ctx.tail_slices = false; }
+    ~NoSlices() { tl_launch_ctx.tail_slices = saved; }
+  } no_slices;
   int rc = ddim_loop(e, x2d0, noise0, step_noise, out0, traj_rev, traj_x0, sw.B0, sw.w0, s, rows_all);
   if (!rc)
     rc = ddim_loop(e, x2d1, noise1, step_noise ? step_noise + rows0 : nullptr, out1, traj_rev ? traj_rev + rows0 * e->S : nullptr,

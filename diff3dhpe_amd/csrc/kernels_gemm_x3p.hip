@@ -764,10 +764,12 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
 // k-loop / epilogue stamps; the persistent walk -> start / end per workgroup.
 static unsigned long long* g_x3_diag = nullptr;
 
+thread_local LaunchCtx tl_launch_ctx;
+
 // walk of `tiles` tiles over `grid` persistent workgroups
 static X3Walk x3q_walk(int tiles, int grid) {
   X3Walk w{tiles / grid, tiles % grid, 1, g_x3_diag};
-  if (w.rem > 0) w.split = (4 * w.rem <= grid) ? 4 : ((2 * w.rem <= grid) ? 2 : 1);
+  if (w.rem > 0 && tl_launch_ctx.tail_slices) w.split = (4 * w.rem <= grid) ? 4 : ((2 * w.rem <= grid) ? 2 : 1);
   return w;
 }
 
