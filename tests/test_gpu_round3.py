@@ -284,6 +284,50 @@ def test_trainedlike_family_on_the_large_batch_kernels():
     assert eng.range_flags() == 0 and torch.isfinite(big).all() and big.abs().max().item() <= 1.0
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_frame_counts_outside_the_reference_configs(prec):
+    """num_frame is free in the reference; its configs use 27 / 81 / 243.  Other counts take other kernel instantiations:
+    T = 300 is beyond the 256-frame fp16-MFMA temporal attention (F16X3 then runs the row-kernel flow with the generic attention
+    for the temporal blocks), T = 100 / 200 take the 4- and 7-key-tile forms, T = 1 is a single-frame 'video'.  Bench width for
+    the long ones (one denoiser evaluation, B = 1), the small model for a whole sampling."""
+    from oracle import d3d_oracle as orc
+    for T in (300, 200, 100):
+        cfg = cfg_full(T)
+        net, _ = build_product(cfg, 31, sampling=2, precision=prec)
+        inp = inputs(1, T, 310 + T)
+        xcat = torch.cat([inp["x2d"], inp["noise"]], dim=-1)
+        t = torch.tensor([611])
+        out = net.forward_denoise(xcat.cuda(), t.cuda())
+        ref = orc.forward_denoise(torch_sd(cfg, 31), xcat, t, depth=cfg.depth)
+        assert maxabs(out, ref) <= GATE, (T, maxabs(out, ref))
+    for T in (1, 300):
+        cfg = cfg_small(T)
+        _, diff = build_product(cfg, 32, sampling=3, precision=prec)
+        inp = inputs(2, T, 320 + T)
+        _, y0 = diff(clean_3d_pose=torch.zeros_like(inp["noise"]).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False,
+                     init_noise=inp["noise"].cuda())
+        ref = orc.ddim_sample_loop(torch_sd(cfg, 32), orc.diffusion_tables("cosine", 1000), inp["x2d"], inp["noise"],
+                                   num_timesteps=1000, sampling_timesteps=3, depth=cfg.depth)
+        assert maxabs(y0, ref) <= GATE, (T, maxabs(y0, ref))
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_joint_counts_other_than_17(prec):
+    """num_joints is a constructor argument of the reference models (17 in every shipped config).  21 joints stay on the
+    wave-private spatial attention form (groups of <= 24 tokens), 26 take the four-pass form, 40 the two-key-tile kernel."""
+    from oracle import d3d_oracle as orc
+    from diff3dhpe_amd.synth import synth_inputs
+    for J in (21, 26, 40):
+        cfg = DenoiserConfig(num_frame=27, num_joints=J, embed_dim=512, depth=2)
+        net, diff = build_product(cfg, 33, sampling=2, precision=prec)
+        inp = {k: torch.from_numpy(v) for k, v in synth_inputs(2, 27, J, seed=330 + J).items()}
+        _, y0 = diff(clean_3d_pose=torch.zeros_like(inp["noise"]).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False,
+                     init_noise=inp["noise"].cuda())
+        ref = orc.ddim_sample_loop(torch_sd(cfg, 33), orc.diffusion_tables("cosine", 1000), inp["x2d"], inp["noise"],
+                                   num_timesteps=1000, sampling_timesteps=2, depth=cfg.depth)
+        assert tuple(y0.shape) == (2, 27, J, 3) and maxabs(y0, ref) <= GATE, (J, maxabs(y0, ref))
+
+
 EVAL_WORKER = """
 import json, os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["D3D_ROOT"]); sys.path.insert(0, os.path.join(os.environ["D3D_ROOT"], "tests"))
