@@ -417,6 +417,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
         default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
       }
     };
+    constexpr bool XPF = !SUB;   // fragment reads that cross a phase barrier (whole tiles only: slices have run-time group ranges)
     const int nA = SUB ? __builtin_popcount(amask & ((1u << A_IT) - 1u)) : A_IT;   // A pieces this wave issues per k-tile
     int issued_prev = 0;                                                            // pieces this wave issued in the previous phase
     // piece `it` (A: 0..A_IT-1, W: A_IT..N_IT-1) of k-tile KTT of this tile (KTT < nk) or of k-tile 0 of the next one (KTT == nk)
@@ -448,7 +449,9 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                 \
       constexpr int G0 = (H) * (TM / 2), G1 = G0 + TM / 2;                                                                \
       const int gf = gl > G0 ? gl : G0;                     /* first active m-tile of this phase */                       \
-      if (gf < gh && gf < G1) {                                                                                           \
+      /* (whole tiles: the odd phase's first A pair was requested by the last group of the even phase -- those rows landed   \
+         before the even phase's barrier --, so the odd phase opens on its MFMAs) */                                       \
+      if (gf < gh && gf < G1 && !(XPF && (H) == 1)) {                                                                     \
         ah[gf & 1] = *reinterpret_cast<const h8*>(sb + aoff + gf * 2048);                                                 \
         al[gf & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + gf * 2048) ^ 64));                                        \
       }                                                                                                                   \
@@ -460,7 +463,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       }                                                                                                                   \
       _Pragma("unroll") for (int g = G0; g < G1; ++g) {                                                                   \
         const bool g_act = g >= gl && g < gh;                                                                             \
-        if (g_act && g + 1 < gh && g + 1 < G1) {                                                                          \
+        if (g_act && g + 1 < gh && g + 1 < ((XPF && (H) == 0) ? TM : G1)) {                                               \
           ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                     \
           al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                            \
         }                                                                                                                 \
