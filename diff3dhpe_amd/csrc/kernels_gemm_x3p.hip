@@ -418,6 +418,9 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       }
     };
     constexpr bool XPF = !SUB;   // fragment reads that cross a phase barrier (whole tiles only: slices have run-time group ranges)
+    // W fragments of the next k-tile read a phase early (below): qkv -1.3 % per launch; proj 0; fc1 +0.6 % (its GELU form sits at
+    // 256 VGPRs and spills four more dwords) -- so only the form without an epilogue operation
+    constexpr bool WPF = XPF && !(FX & FX_BF16) && EPI == EPI_NONE;
     const int nA = SUB ? __builtin_popcount(amask & ((1u << A_IT) - 1u)) : A_IT;   // A pieces this wave issues per k-tile
     int issued_prev = 0;                                                            // pieces this wave issued in the previous phase
     // piece `it` (A: 0..A_IT-1, W: A_IT..N_IT-1) of k-tile KTT of this tile (KTT < nk) or of k-tile 0 of the next one (KTT == nk)
@@ -440,7 +443,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     // staging pieces) stated with sched_group_barrier: 2 MFMAs, a read, 2 MFMAs, a read, 2 MFMAs, a piece, 2 MFMAs, the other
     // pieces, 4 MFMAs; in the k-tile's opening group the A pair and first W pair, then a W pair ahead of each MFMA triple.  Left
     // alone the scheduler puts the reads and the pieces at the top of the group and the 12 MFMAs behind them (+2.4 % on qkv).
-#define D3D_PHASE(KT, H, DO_A, W_FULL1, DO_W)                                                                             \
+#define D3D_PHASE(KT, H, DO_A, W_FULL1, DO_W, W_AHEAD)                                                                    \
     do {                                                                                                                  \
       wait_vm(issued_prev);                                                                                               \
       __builtin_amdgcn_s_barrier();                                                                                       \
@@ -455,7 +458,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
         ah[gf & 1] = *reinterpret_cast<const h8*>(sb + aoff + gf * 2048);                                                 \
         al[gf & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + gf * 2048) ^ 64));                                        \
       }                                                                                                                   \
-      if ((H) == 0) {                                                                                                     \
+      /* W_AHEAD (WPF): the W fragments of k-tile KT+1 -- in LDS since the barrier of this odd phase -- \
+         replace those of KT pair by pair behind the last group's MFMA triples, so the next even phase opens on its A pair   \
+         alone; an even phase reads W itself only in a tile's first k-tile */                                               \
+      if ((H) == 0 && (!WPF || (W_FULL1))) {                                                                              \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                   \
           bh[j] = *reinterpret_cast<const h8*>(sb + boff + j * 2048);                                                     \
           bl[j] = *reinterpret_cast<const h8*>(sb + ((boff + j * 2048) ^ 64));                                            \
@@ -473,7 +479,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           _Pragma("unroll") for (int pp = 0; pp < PPG_; ++pp) {                                                           \
             const int sl = (g - G0) * PPG_ + pp;                                                                          \
             if ((H) == 0) {                                                                                               \
-              if (sl < A_IT) { if (DO_A) D3D_PIECE((KT) + 1, sl); }                                                       \
+              if (WPF && (W_FULL1)) {   /* W(1) ahead of A(1): the next barrier's counted wait then retires W(1) */        \
+                if (sl < B_IT) D3D_PIECE((KT) + 1, A_IT + sl);                                                            \
+                else if (sl < A_IT + B_IT) { if (DO_A) D3D_PIECE((KT) + 1, sl - B_IT); }                                  \
+              } else if (sl < A_IT) { if (DO_A) D3D_PIECE((KT) + 1, sl); }                                                \
               else if (sl < A_IT + B_IT) { if (W_FULL1) D3D_PIECE((KT) + 1, sl); }                                        \
             } else if (sl < B_IT) {                                                                                       \
               if (DO_W) D3D_PIECE((KT) + 2, A_IT + sl);                                                                   \
@@ -481,11 +490,29 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           }                                                                                                               \
         };                                                                                                                \
         pieces_();                                                                                                        \
+        const bool w_ahead_ = WPF && (H) == 1 && g == G1 - 1 && (W_AHEAD);                                                \
         if (g_act) {                                                                                                      \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                 \
             x3_mma<FX>(acc[g][j], bh[j], bl[j], ah[g & 1], al[g & 1]);                                                    \
+            if (w_ahead_) {                                                                                               \
+              const unsigned char* sbn = lds + (((KT) + 1) & 1) * STAGE;                                                  \
+              bh[j] = *reinterpret_cast<const h8*>(sbn + boff + j * 2048);                                                \
+              bl[j] = *reinterpret_cast<const h8*>(sbn + ((boff + j * 2048) ^ 64));                                       \
+            }                                                                                                             \
           }                                                                                                               \
         }                                                                                                                 \
+        if (WPF && !(FX & FX_BF16) && w_ahead_) {   /* MFMA triple, its W pair's successor, ...; the pieces in between */  \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
+        } else                                                                                                            \
         if constexpr ((FX & FX_BF16) != 0) {   /* bf16: 8 MFMAs per group -- pairs where the F16X3 pattern has triples */       \
           if (!SUB && (H) == 0 && g == G0) {                                                                              \
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
@@ -509,7 +536,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
             __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);                                                            \
           }                                                                                                               \
         } else                                                                                                            \
-        if (!SUB && (H) == 0 && g == G0) {   /* the k-tile opening: fragments just ahead of their MFMAs */                \
+        if (!SUB && (H) == 0 && g == G0 && (!WPF || (W_FULL1))) {   /* the k-tile opening: fragments just ahead of their MFMAs */ \
           __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                              \
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                              \
@@ -542,28 +569,28 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           __builtin_amdgcn_sched_barrier(0);                                                                              \
         }                                                                                                                 \
       }                                                                                                                   \
-      if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) ? B_IT : 0);                                             \
+      if ((H) == 0) issued_prev = ((DO_A) ? nA : 0) + ((W_FULL1) && !WPF ? B_IT : 0);                                     \
       else issued_prev = (DO_W) ? B_IT : 0;                                                                               \
     } while (0)
     h8 bh[4], bl[4], ah[2], al[2];
     // first k-tile: everything issued before this tile (stores of the previous epilogue included) has landed: vmcnt(0) -- but
     // for the statistics pieces just requested (the newest: vmcnt retires in order)
     issued_prev = st_issued;
-    D3D_PHASE(0, 0, true, true, false);
-    D3D_PHASE(0, 1, false, false, nk > 2 || has_next);
+    D3D_PHASE(0, 0, true, true, false, false);
+    D3D_PHASE(0, 1, false, false, nk > 2 || has_next, nk > 1);
     int kt = 1;
     for (; kt + 2 < nk; ++kt) {
-      D3D_PHASE(kt, 0, true, false, false);
-      D3D_PHASE(kt, 1, false, false, true);
+      D3D_PHASE(kt, 0, true, false, false, false);
+      D3D_PHASE(kt, 1, false, false, true, true);
     }
     if (nk > 2) {   // k-tile nk-2: A(nk-1) of this tile, then W(0) of the next tile
-      D3D_PHASE(kt, 0, true, false, false);
-      D3D_PHASE(kt, 1, false, false, has_next);
+      D3D_PHASE(kt, 0, true, false, false, false);
+      D3D_PHASE(kt, 1, false, false, has_next, true);
       ++kt;
     }
     // k-tile nk-1: A(0) of the next tile; W(1) of the next tile waits for its own phase 0 (the epilogue's patches)
-    D3D_PHASE(kt, 0, has_next, false, false);
-    D3D_PHASE(kt, 1, false, false, false);
+    D3D_PHASE(kt, 0, has_next, false, false, false);
+    D3D_PHASE(kt, 1, false, false, false, false);
 #undef D3D_PHASE
 #undef D3D_PIECE
   } else {
