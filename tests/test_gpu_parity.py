@@ -226,6 +226,11 @@ def test_large_batch_kernels_match_the_small_batch_path():
         part = eng.ddim_sample(x2d[lo:hi].contiguous(), nz[lo:hi].contiguous())
         assert torch.equal(part, big[lo:hi]), f"samples {lo}:{hi} differ by {(part - big[lo:hi]).abs().max().item():.3e}"
     assert torch.isfinite(big).all() and big.abs().max().item() <= 1.0
+    # one stream: the whole batch in one carve-up, and the persistent GEMM walks cut their partly filled last round into row slices
+    # (the two-stream default keeps those tiles whole): same bits
+    eng.set_option("streams", 1)
+    assert torch.equal(eng.ddim_sample(x2d, nz), big)
+    eng.set_option("streams", 2)
     # T = 81: three key tiles per unit -- the other instantiation of the persistent attention kernel (needs >= 1024 units)
     cfg = cfg_full(81)
     _, diff = build_product(cfg, 8, sampling=2, precision="f16x3")
