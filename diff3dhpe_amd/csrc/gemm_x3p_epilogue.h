@@ -26,38 +26,48 @@ __device__ __forceinline__ float gelu_fast(float x) {
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat2(float a) { return (f2)(a); }
+// GELU(x) = 0.5 x + |x| (0.5 - q),  q = 0.5 erfc(|x| / sqrt 2) = t (a1 + t (a2 + ... a5 t)) exp(-x^2 / 2) / 2,  t = 1 / (1 + p |x| / sqrt 2)
+// (Abramowitz-Stegun 7.1.26, coefficients halved).  Per pair of values: 2 + 2 scalar instructions that take |x| as a source
+// modifier, 9 packed ones, v_rcp and v_exp twice -- four issue slots fewer than the form max(x, 0) - (|x| / 2) (p t) e, which
+// had to materialise |x| for its packed multiplies.  Absolute error < 1e-7 |x|.
 __device__ __forceinline__ f2 gelu_fast2(f2 x) {
-  f2 ax, t, e, m;
-  ax.x = __builtin_fabsf(x.x); ax.y = __builtin_fabsf(x.y);
-  const f2 z = ax * 0.70710678118654752440f;
-  const f2 den = fma2(splat2(0.3275911f), z, splat2(1.0f));
-  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
-  f2 p = fma2(splat2(1.061405429f), t, splat2(-1.453152027f));
-  p = fma2(p, t, splat2(1.421413741f));
-  p = fma2(p, t, splat2(-0.284496736f));
-  p = fma2(p, t, splat2(0.254829592f));
-  const f2 zz = z * z * -1.44269504088896340736f;
-  e.x = __builtin_amdgcn_exp2f(zz.x); e.y = __builtin_amdgcn_exp2f(zz.y);
-  m.x = __builtin_fmaxf(x.x, 0.0f); m.y = __builtin_fmaxf(x.y, 0.0f);
-  return fma2(-(splat2(0.5f) * ax * (p * t)), e, m);
+  f2 t, e, r;
+  constexpr float KP = 0.3275911f * 0.70710678118654752440f;
+  t.x = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x.x), KP, 1.0f));
+  t.y = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x.y), KP, 1.0f));
+  f2 p = fma2(splat2(0.5f * 1.061405429f), t, splat2(0.5f * -1.453152027f));
+  p = fma2(p, t, splat2(0.5f * 1.421413741f));
+  p = fma2(p, t, splat2(0.5f * -0.284496736f));
+  p = fma2(p, t, splat2(0.5f * 0.254829592f));
+  const f2 xx = (x * x) * (-0.5f * 1.44269504088896340736f);
+  e.x = __builtin_amdgcn_exp2f(xx.x); e.y = __builtin_amdgcn_exp2f(xx.y);
+  const f2 w = fma2(-(p * t), e, splat2(0.5f));
+  const f2 hx = x * 0.5f;
+  r.x = __builtin_fmaf(__builtin_fabsf(x.x), w.x, hx.x);
+  r.y = __builtin_fmaf(__builtin_fabsf(x.y), w.y, hx.y);
+  return r;
 }
-// 8 values -> fp16 (hi, lo) of osc * v, clamped to the fp16 range
+// 8 values -> fp16 (hi, lo) of osc * v (osc a power of two).  v_fma_mixlo / mixhi_f16 scale, subtract the fp16 hi half (read
+// in place) and convert in one instruction: hi = fp16(osc v), lo = fp16(osc v - hi), both single roundings of exact fp32
+// quantities -- 2 instructions per value where multiply, clamp, convert, convert back, subtract, convert took 5.  Nothing is
+// clamped: beyond the fp16 range hi becomes inf (and lo NaN), and that is exactly where the range guard fires -- amax is the
+// largest |v| seen (UNSCALED: the caller notes amax * osc).
 template <bool GUARD = true>
 __device__ __forceinline__ void split8_x3(const f2 (&v)[4], float osc, h8& oh, h8& ol, float& amax) {
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  u32x4_ hv, lv;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    f2 sc = v[e] * osc;
-    if (GUARD) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(sc.x)), __builtin_fabsf(sc.y));
-    sc.x = __builtin_amdgcn_fmed3f(sc.x, -65504.0f, 65504.0f);
-    sc.y = __builtin_amdgcn_fmed3f(sc.y, -65504.0f, 65504.0f);
-    oh[2 * e] = (_Float16)sc.x;
-    oh[2 * e + 1] = (_Float16)sc.y;
-    f2 back;
-    back.x = (float)oh[2 * e]; back.y = (float)oh[2 * e + 1];
-    const f2 d = sc - back;
-    ol[2 * e] = (_Float16)d.x;
-    ol[2 * e + 1] = (_Float16)d.y;
+    unsigned hi, lo;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v[e].x), "v"(osc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v[e].y), "v"(osc));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(v[e].x), "v"(osc), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v[e].y), "v"(osc), "v"(hi));
+    hv[e] = hi; lv[e] = lo;
+    if (GUARD) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[e].x)), __builtin_fabsf(v[e].y));
   }
+  oh = __builtin_bit_cast(h8, hv);
+  ol = __builtin_bit_cast(h8, lv);
 }
 // (sum, sum of squares) of 8 values
 __device__ __forceinline__ void sums8(const f2 (&v)[4], float& sm, float& sq) {
@@ -380,7 +390,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if constexpr (OUTSPLIT != 0 && OUTSPLIT != 3 && !(FX & FX_SO)) range_note(amax);
+  if constexpr (OUTSPLIT != 0 && OUTSPLIT != 3 && !(FX & FX_SO)) range_note(amax * osc);
 }
 
 // GELU + pair output straight from the accumulators (fc1 -> hidden activation).  The hidden activation is only ever the A
@@ -449,7 +459,7 @@ __device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned c
     }
     if (i & 1) __builtin_amdgcn_sched_barrier(0);
   }
-  range_note(amax);
+  range_note(amax * P_A_SCALE);
 }
 
 // Post-norm epilogue (FX_PN): the workgroup's tile is BM full rows (WM == 1, N == 64 WN), so the block's post-norm
@@ -600,7 +610,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (OUTSPLIT == 2) range_note(amax);
+  if (OUTSPLIT == 2) range_note(amax * P_A_SCALE);
 }
 
 // Whole-row epilogue of the bf16 operand mode (FX_PN | FX_BF16; x3q_epilogue_pn's structure with an fp32 residual stream):
