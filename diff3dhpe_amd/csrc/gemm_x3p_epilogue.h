@@ -206,10 +206,10 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       float v[4];
       if (FX & FX_LNF) {   // LN(x) W^T + b = rstd (x W'^T) - rstd mean csum + b'
         const float2 st = srow[rbase + 16 * i + row];
-        v[0] = fmaf(st.x, a4.x * P_OUT_SCALE, fmaf(st.y, cs4.x, b4.x));
-        v[1] = fmaf(st.x, a4.y * P_OUT_SCALE, fmaf(st.y, cs4.y, b4.y));
-        v[2] = fmaf(st.x, a4.z * P_OUT_SCALE, fmaf(st.y, cs4.z, b4.z));
-        v[3] = fmaf(st.x, a4.w * P_OUT_SCALE, fmaf(st.y, cs4.w, b4.w));
+        v[0] = fmaf(st.x, a4.x, fmaf(st.y, cs4.x, b4.x));   // (st.x = rstd * out_scale: x3_row_stats)
+        v[1] = fmaf(st.x, a4.y, fmaf(st.y, cs4.y, b4.y));
+        v[2] = fmaf(st.x, a4.z, fmaf(st.y, cs4.z, b4.z));
+        v[3] = fmaf(st.x, a4.w, fmaf(st.y, cs4.w, b4.w));
       } else {
         v[0] = a4.x * P_OUT_SCALE + b4.x; v[1] = a4.y * P_OUT_SCALE + b4.y;
         v[2] = a4.z * P_OUT_SCALE + b4.z; v[3] = a4.w * P_OUT_SCALE + b4.w;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
         const float2 st = srow[rbase + 16 * i + row];
         const f2 sx = splat2(st.x), sy = splat2(st.y);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fma2(sx, a[e] * P_OUT_SCALE, fma2(sy, cs[e], bb[e]));
+        for (int e = 0; e < 4; ++e) v[e] = fma2(sx, a[e], fma2(sy, cs[e], bb[e]));   // (sx = rstd * out_scale)
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fma2(a[e], splat2(P_OUT_SCALE), bb[e]);
@@ -443,8 +443,8 @@ __device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned c
         f2 a0, a1;
         a0.x = acc[i][j][0]; a0.y = acc[i][j][1]; a1.x = acc[i][j][2]; a1.y = acc[i][j][3];
         if (FX & FX_LNF) {   // LN(x) W^T + b = rstd (x W'^T) - rstd mean csum + b'
-          v[2 * jj] = fma2(sx, a0 * P_OUT_SCALE, fma2(sy, cs[j][0], bb[j][0]));
-          v[2 * jj + 1] = fma2(sx, a1 * P_OUT_SCALE, fma2(sy, cs[j][1], bb[j][1]));
+          v[2 * jj] = fma2(sx, a0, fma2(sy, cs[j][0], bb[j][0]));   // (sx = rstd * out_scale)
+          v[2 * jj + 1] = fma2(sx, a1, fma2(sy, cs[j][1], bb[j][1]));
         } else {
           v[2 * jj] = fma2(a0, splat2(P_OUT_SCALE), bb[j][0]);
           v[2 * jj + 1] = fma2(a1, splat2(P_OUT_SCALE), bb[j][1]);

@@ -227,7 +227,8 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
       if (row < M) range_note_stats(mean, var);
       const float rstd = 1.0f / sqrtf(var + fx.eps);
-      reinterpret_cast<float2*>(lds_x)[tidx] = make_float2(rstd, -mean * rstd);
+      // (rstd carries the GEMM's power-of-two output scale: the epilogues form rstd' acc - rstd mean csum + b' in two fmas)
+      reinterpret_cast<float2*>(lds_x)[tidx] = make_float2(rstd * fx.out_scale, -mean * rstd);
     }
   };
   if constexpr ((FX & FX_LNF) != 0) {
