@@ -62,9 +62,9 @@ __host__ __device__ __forceinline__ size_t pair_col_acc(int c) {
 
 // ---- F16X3 range guard -------------------------------------------------------------------------------------------------
 // An fp16 plane holds 8*x (activations; the q third of a qkv output 1*x) or 2^k*w (weights; k per matrix, 12 unless a weight
-// exceeds 15.99), clamped to +-65504: |x| > 8188 saturates silently.  Every device-side plane writer therefore tracks max |scaled value| per lane and ORs
-// bit 0 into its translation unit's sticky per-device word when a clamp fired (one atomic per lane that saw one: none in a
-// healthy run).  range_flags_*: read (and optionally clear) the word of the current device; the caller synchronises first.
+// exceeds 15.99): |x| > 8188 does not fit (clamped to +-65504 by the row / attention kernels, inf behind the GEMM epilogues'
+// v_fma_mix split).  Every device-side plane writer therefore tracks max |value| per lane and ORs bit 0 into its translation
+// unit's sticky per-device word when one left the range (one atomic per lane that saw one: none in a healthy run).  range_flags_*: read (and optionally clear) the word of the current device; the caller synchronises first.
 constexpr float X3_HALF_MAX = 65504.0f;
 hipError_t range_flags_gemm(unsigned* flags, bool clear);     // kernels_gemm_x3p.hip
 hipError_t range_flags_elem(unsigned* flags, bool clear);     // kernels_elem.hip

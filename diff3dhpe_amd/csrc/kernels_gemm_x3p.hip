@@ -40,7 +40,7 @@ constexpr int PBK = 32;                          // k-tile depth (fp16 elements)
 constexpr float P_A_SCALE = 8.0f;
 
 // F16X3 range guard (d3d_kernels.h): every plane writer tracks max |scaled value| per lane; a lane whose value left the fp16
-// range (the clamp below fired: |x| > 8188) ORs bit 0 into this sticky per-device word once, at the end of its epilogue.
+// range (|x| > 8188) ORs bit 0 into this sticky per-device word once, at the end of its epilogue.
 __device__ unsigned g_range_x3p;
 __device__ __forceinline__ void range_note(float amax) {
 #ifndef D3D_NO_RANGE_GUARD
@@ -220,7 +220,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
           sm += t.x; sq += t.y;
         }
       // range guard for the producer of these rows (the proj / fc2 epilogues write the planes of x and these statistics of the
-      // unclamped values): a clamped element |x| > 8188 implies sum x^2 > 8188^2 -- never missed; rows of ~512 values above ~360
+      // values themselves): an element |x| > 8188 implies sum x^2 > 8188^2 -- never missed; rows of ~512 values above ~360
       // would raise it falsely, a LayerNorm-ed stream is orders of magnitude below
       if (sq >= (X3_HALF_MAX * 0.125f) * (X3_HALF_MAX * 0.125f)) range_note(2.0f * X3_HALF_MAX);
       const float mean = sm / (float)K;

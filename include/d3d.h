@@ -193,10 +193,11 @@ const char* d3d_kernel_class_name(int32_t kernel_class);
 /* ---- F16X3 range guard.  The F16X3 operand planes hold fp16 (hi, lo) pairs of 8*x (activations: residual stream, q/k/v,
  * attention output, MLP hidden) and 2^k*w (GEMM weights; k is chosen per matrix at commit: 12 unless an entry exceeds 15.99 --
  * LayerNorm-folded weights W diag(gamma) of checkpoints with large gains -- then smaller, nothing is clamped); activations
- * beyond the fp16 range are clamped: |x| > 8188.
- * Every kernel that writes such planes raises a sticky per-device flag when its clamp fired (no cost in a healthy run), and
- * d3d_engine_commit_weights notes clamped weights.  d3d_engine_range_flags synchronises `stream` and returns
- *   D3D_RANGE_ACT    an activation was clamped on this device since the flag was last cleared (any engine of the process)
+ * beyond the fp16 range, |x| > 8188, are not representable (the row and attention kernels clamp them to the range, the GEMM
+ * epilogues let them become inf): results are then meaningless.
+ * Every kernel that writes such planes raises a sticky per-device flag when a value left the range (no cost in a healthy run),
+ * and d3d_engine_commit_weights notes non-finite weights.  d3d_engine_range_flags synchronises `stream` and returns
+ *   D3D_RANGE_ACT    an activation left the range on this device since the flag was last cleared (any engine of the process)
  *   D3D_RANGE_WEIGHT a GEMM weight of this engine was not finite at commit
  *   D3D_RANGE_STATS  a LayerNorm folded into a GEMM met a row with |mean| > 16 standard deviations: the folded form works from
  *                    one-pass row statistics (sum, sum of squares), whose variance loses accuracy like eps (1 + mean^2 / var)
