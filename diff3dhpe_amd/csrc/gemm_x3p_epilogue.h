@@ -4,25 +4,8 @@
 // 113-135 (Block), 236/245 (post-norms).
 #pragma once
 
-// GELU(x) = x Phi(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), with erfc from Abramowitz & Stegun 7.1.26
-// (erfc(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and a
-// handful of FMAs, branch-free -- the library erff costs about three times as much, and the fc1 epilogue is VALU-bound
-// (128 outputs per lane).  The absolute error of the result stays below 1e-7 |x|, the rounding level of the fp32 path.
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float ax = __builtin_fabsf(x);
-  const float z = ax * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
-  return __builtin_fmaf(-(0.5f * ax * (p * t)), e, __builtin_fmaxf(x, 0.0f));
-}
-
-// Two elements at a time: the epilogues are VALU-bound (the fc1 one: ~22 VALU instructions per output element, 13 us of a 52 us
-// tile), and gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on register pairs at the rate of the scalar forms.  Every
-// multiply-add is written as an explicit fma, in the order of the scalar code above, so that both give the same bits.
+// Two elements at a time: the epilogues are VALU-bound (the fc1 one: 128 outputs per lane), and gfx950 issues v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 on register pairs at the rate of the scalar forms.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat2(float a) { return (f2)(a); }
@@ -216,7 +199,12 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       }
       if (EPI == EPI_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+        for (int e = 0; e < 4; e += 2) {   // (the one GELU of all epilogue forms: an element has the same bits whichever it goes through)
+          f2 g;
+          g.x = v[e]; g.y = v[e + 1];
+          g = gelu_fast2(g);
+          v[e] = g.x; v[e + 1] = g.y;
+        }
       }
       if (EPI == EPI_RESIDUAL) {
         float4 r4 = rr[i][p];

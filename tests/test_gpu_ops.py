@@ -67,6 +67,14 @@ def test_linear_bit_reproducible_and_row_independent(prec):
     o1, o2 = E.op_linear(A, W, None, precision=prec), E.op_linear(A, W, None, precision=prec)
     assert torch.equal(o1, o2)
     assert torch.equal(E.op_linear(A[100:229].contiguous(), W, None, precision=prec), o1[100:229])   # tile position must not matter
+    # ... nor the epilogue form an element goes through: M = 66100 runs the persistent walk (whole tiles: 8 columns per lane; the
+    # ragged last tile and the row slices: 4 columns per lane), the 129-row excerpt the small-problem tiles -- with GELU (one
+    # implementation behind every form)
+    Ab = hashed("Arep2", (66100, 512), 3, 2.0).cuda()
+    bias = hashed("brep", (512,), 4, 0.5).cuda()
+    big = E.op_linear(Ab, W, bias, epi="gelu", precision=prec)
+    for lo in (0, 65900, 65971):
+        assert torch.equal(E.op_linear(Ab[lo:lo + 129].contiguous(), W, bias, epi="gelu", precision=prec), big[lo:lo + 129]), lo
 
 
 @pytest.mark.parametrize("M,K,mode", [(128, 2048, "plain"), (300, 512, "pos"), (4131, 2048, "tvec1"), (1000, 64, "tvecrows"),
