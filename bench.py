@@ -7,6 +7,7 @@ Default workload = the per-GPU shard of BASELINE.json configs[2]: T=243, J=17, D
 B=64 sequences per GPU (weak scaling: the 8-GPU run is the full B=512 of that config).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...            (no launcher: bench.py starts its N rank processes itself, self_launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  The timed region runs the engine exactly as a user gets
@@ -178,6 +179,49 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's JSON line.
+
+    The parent never imports torch and never touches HIP -- it only spawns `sys.executable bench.py <same argv>` N times with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (never an exec of a process that has initialised the GPU),
+    waits for all of them and returns the first non-zero exit code.  Rank 0's stdout is relayed unchanged (the ONE JSON line);
+    the other ranks' stdout goes to stderr.  The torchrun form (WORLD_SIZE already set) does not come through here."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:           # a free port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, D3D_BENCH_LAUNCHER="self")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else sys.stderr))
+        first_bad = None
+        while any([p.poll() is None for p in procs]):     # (a list: every child is polled each round)
+            for r, p in enumerate(procs):
+                if first_bad is None and p.returncode not in (None, 0):
+                    first_bad = (r, p.returncode)
+                    for q in procs:            # a dead rank leaves the others waiting in a collective: end exactly our children
+                        if q.poll() is None:
+                            q.terminate()
+            time.sleep(0.05)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode(errors="replace"))
+        sys.stdout.flush()
+    if first_bad is None:
+        first_bad = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if first_bad is not None:
+        print(f"bench.py self-launch: rank {first_bad[0]} failed with exit code {first_bad[1]}", file=sys.stderr)
+        return first_bad[1] if 0 < first_bad[1] < 256 else 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +251,26 @@ def main():
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the bitwise batch-vs-pair check (profiling passes: keeps the kernel tables to the timed workload)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (before torch or HIP are touched)
+        sys.exit(self_launch(a.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')} (run `python bench.py --gpus N` "
+                         f"plain, or torchrun with --nproc-per-node equal to --gpus)")
+    if os.environ.get("D3D_BENCH_LAUNCH_CHECK"):
+        # launcher self-test (tests/test_compat_and_dist.py, no GPU): report the rank environment and leave; the rank named by
+        # D3D_BENCH_LAUNCH_CHECK_FAIL exits non-zero instead (the launcher must propagate it and end the other ranks)
+        r = int(os.environ.get("RANK", "0"))
+        if os.environ.get("D3D_BENCH_LAUNCH_CHECK_FAIL") == str(r):
+            sys.exit(7)
+        if os.environ.get("D3D_BENCH_LAUNCH_CHECK_FAIL"):
+            time.sleep(30)                     # (a surviving rank would sit in a collective: the launcher has to end it)
+        print(json.dumps({"launch_check": True, "rank": r, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "world_size": int(os.environ.get("WORLD_SIZE", "1")), "master_addr": os.environ.get("MASTER_ADDR"),
+                          "master_port": os.environ.get("MASTER_PORT"), "launcher": os.environ.get("D3D_BENCH_LAUNCHER", "none")}),
+              file=sys.stdout if r == 0 else sys.stderr, flush=True)
+        return
+
     import torch
     import torch.distributed as dist
     import diff3dhpe_amd as d3d
@@ -235,7 +299,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -391,7 +454,7 @@ def main():
             "whole_step_tflops": round(whole, 2),
             "mpjpe_vs_synthetic_gt": round(err / max(cnt, 1), 6),
             "selfcheck_batch_vs_pair_bit_identical": selfcheck,
-            "headline_under": ("2-stream" if a.streams == 2 else "eager") + ("+graph" if a.graph else ""),
+            "headline_under": ("2-stream" if (a.streams == 2 and Bl >= 2) else "eager") + ("+graph" if a.graph else ""),
             "roofline": roof,
         }
         if rank_stats:
@@ -413,7 +476,14 @@ def main():
                          "by_kernel_ms_per_step": {}, "traffic": None})
             roof.pop("traffic_source", None)
         if use_dist:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:
+                rccl = None
             line["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_single_rank_group": force_dist,
+                            "rccl_version": rccl,
+                            "launcher": os.environ.get("D3D_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "external"),
+                            "one_process_per_gpu": not bool(os.environ.get("D3D_BENCH_ONE_DEVICE")),
                             "collectives": ["barrier", "all_gather_into_tensor", "all_reduce(MAX)"]}
     extras = None
     if world == 1 and not a.no_extras and not a.seq2frame:

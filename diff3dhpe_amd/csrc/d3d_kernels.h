@@ -40,8 +40,12 @@ inline int device_cu_count() {
 // On one stream that fills CUs which would idle for a tile time (+1.3 %); with two half-batches on two streams the other half's
 // kernel takes those CUs, and slices -- 4x the workgroups for 0.7-1.0 of a tile time each -- only cost CU time (-0.6 %), so the
 // two-stream loop turns them off.  Values do not depend on it.
-struct LaunchCtx { bool tail_slices = true; };
+// range_word: the F16X3 range-guard word (device memory, below) of the ENGINE whose call is being served -- the C ABI entry points of
+// an engine set it around their launches; launches outside an engine (the single-op hooks) write to a per-device sink nobody reads.
+struct LaunchCtx { bool tail_slices = true; unsigned* range_word = nullptr; };
 extern thread_local LaunchCtx tl_launch_ctx;
+unsigned* range_sink_word();   // engine.hip: 4 bytes of device memory per device, allocated on first use (nullptr if that failed)
+inline unsigned* launch_range_word() { return tl_launch_ctx.range_word ? tl_launch_ctx.range_word : range_sink_word(); }
 
 enum Epi { EPI_NONE = 0, EPI_GELU = 1, EPI_RESIDUAL = 2 };
 
@@ -63,13 +67,12 @@ __host__ __device__ __forceinline__ size_t pair_col_acc(int c) {
 // ---- F16X3 range guard -------------------------------------------------------------------------------------------------
 // An fp16 plane holds 8*x (activations; the q third of a qkv output 1*x) or 2^k*w (weights; k per matrix, 12 unless a weight
 // exceeds 15.99): |x| > 8188 does not fit (clamped to +-65504 by the row / attention kernels, inf behind the GEMM epilogues'
-// v_fma_mix split).  Every device-side plane writer therefore tracks max |value| per lane and ORs bit 0 into its translation
-// unit's sticky per-device word when one left the range (one atomic per lane that saw one: none in a healthy run).  range_flags_*: read (and optionally clear) the word of the current device; the caller synchronises first.
+// v_fma_mix split).  Every device-side plane writer therefore tracks max |value| per lane and ORs a bit into the sticky word its
+// launcher handed it (launch_range_word(): the launching ENGINE's word) when one left the range (one atomic per lane that saw one:
+// none in a healthy run).  Bits of the word: 1 = a plane value left the range, 2 = a folded LayerNorm met a row with |mean| > 16 sigma.
 constexpr float X3_HALF_MAX = 65504.0f;
-hipError_t range_flags_gemm(unsigned* flags, bool clear);     // kernels_gemm_x3p.hip
-hipError_t range_flags_elem(unsigned* flags, bool clear);     // kernels_elem.hip
-hipError_t range_flags_attn(unsigned* flags, bool clear);     // kernels_attn_x3.hip
-hipError_t range_flags_attn32(unsigned* flags, bool clear);   // kernels_attn.hip (fp32 kernels writing planes)
+constexpr unsigned RANGE_BIT_ACT = 1u, RANGE_BIT_STATS = 2u;
+__device__ __forceinline__ void range_raise(unsigned* rw, unsigned bit) { if (rw) atomicOr(rw, bit); }
 
 // ---- kernels_gemm.hip -------------------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]); all row-major fp32, K % 32 == 0.
@@ -167,6 +170,7 @@ struct LnArgs {
   int64_t tvec_stride;
   int rows_per_batch;
   int rows, D;
+  unsigned* range;   // filled in by launch_layernorm: the range-guard word the plane outputs report to
 };
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
 
@@ -205,6 +209,12 @@ hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 
 hipError_t launch_q_sample(const float* x_start, const float* noise, const int32_t* t, const float* sqrt_ac,
                            const float* somac, float* out, int B, int64_t n, hipStream_t s);
+
+// p_losses tail (DIFF:411-418) and the repeat_n tiling / hypothesis mean of forward() (DIFF:433-448); n = elements per batch row
+hipError_t launch_weighted_loss(const float* model_out, const float* target, const int32_t* t, const float* ac, const float* somac,
+                                float* out, int B, int64_t n, int l2, int clip, hipStream_t s);
+hipError_t launch_repeat_rows(const float* x, float* out, int B, int64_t n, int R, hipStream_t s);
+hipError_t launch_hypothesis_mean(const float* pred, float* out, int B, int64_t n, int R, hipStream_t s);
 
 // joint permutation of the horizontal flip, passed by value as a kernel argument (no device allocation, no copy, no sync)
 struct JointPerm { static constexpr int MAXJ = 64; int32_t p[MAXJ]; };

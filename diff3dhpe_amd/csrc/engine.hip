@@ -75,6 +75,8 @@ struct d3d_engine {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int device = -1;                // ordinal of the device the weights were committed on
+  unsigned* range_dev = nullptr;  // F16X3 range guard: THIS engine's sticky word (device memory; every plane-writing kernel launched
+                                  // for this engine ORs into it -- d3d_kernels.h LaunchCtx::range_word)
 
   float* arena = nullptr;  // all weights, device
   size_t arena_floats = 0;
@@ -100,9 +102,12 @@ struct d3d_engine {
   bool has_sqrt_ac = false;
 
   // hipGraph replay of the whole S-step loop (d3d_engine_set_graph_mode): one captured graph per (B, workspace)
-  struct GraphEntry { int B; void* ws; hipGraph_t graph; hipGraphExec_t exec; };
+  struct GraphEntry { int B; void* ws; hipGraph_t graph; hipGraphExec_t exec; unsigned long long used; };
+  static constexpr size_t MAX_GRAPHS = 4;   // least recently used entry is destroyed beyond that (a caller that re-allocates its
+                                            // workspace per batch would otherwise grow the cache without bound)
   bool graph_mode = false;
   std::vector<GraphEntry> graphs;
+  unsigned long long graph_clock = 0, graphs_captured = 0;
   hipStream_t cap_stream = nullptr;
   void drop_graphs() {
     for (auto& g : graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -126,6 +131,7 @@ struct d3d_engine {
   ~d3d_engine() {
     drop_graphs();
     (void)hipFree(trace_dev);
+    (void)hipFree(range_dev);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     if (side_stream) (void)hipStreamDestroy(side_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -138,6 +144,13 @@ struct d3d_engine {
 };
 
 namespace {
+
+// Launches issued while one of these is alive report to the engine's range-guard word (d3d_kernels.h).
+struct RangeScope {
+  unsigned* saved;
+  explicit RangeScope(const d3d_engine* e) : saved(tl_launch_ctx.range_word) { tl_launch_ctx.range_word = e->range_dev; }
+  ~RangeScope() { tl_launch_ctx.range_word = saved; }
+};
 
 void add_slot(d3d_engine* e, const std::string& name, int64_t numel) {
   WeightSlot s;
@@ -646,11 +659,25 @@ int check_ready(const d3d_engine* e, int B, const void* ws, size_t ws_bytes) {
 
 }  // namespace
 
+// Range-guard sink of launches that belong to no engine (the single-op hooks): one word per device, written, never read.
+unsigned* d3d::range_sink_word() {
+  static std::atomic<unsigned*> words[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  unsigned* w = words[dev & 63].load(std::memory_order_acquire);
+  if (w) return w;
+  if (hipMalloc(&w, 256) != hipSuccess) return nullptr;
+  (void)hipMemset(w, 0, 256);
+  unsigned* expect = nullptr;
+  if (!words[dev & 63].compare_exchange_strong(expect, w, std::memory_order_acq_rel)) { (void)hipFree(w); w = expect; }
+  return w;
+}
+
 // ================================================================================================== C ABI
 extern "C" {
 
 const char* d3d_last_error(void) { return g_err.c_str(); }
-int d3d_version(void) { return 110; }
+int d3d_version(void) { return 120; }
 
 int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out) {
   // torch.linspace(-1, N-1, S+1) in fp32 (two-sided evaluation around the midpoint), .int() truncation, reversed
@@ -772,6 +799,10 @@ int d3d_engine_commit_weights(d3d_engine* e) {
   }
   e->weights_clamped = false;
   HIP_TRY(hipGetDevice(&e->device));
+  if (!e->range_dev) {
+    HIP_TRY(hipMalloc(&e->range_dev, 256));
+    HIP_TRY(hipMemset(e->range_dev, 0, 256));
+  }
   if (e->cfg.precision == D3D_PREC_F16X3) {
     // fp16 hi/lo pair layout of the four GEMM weights of every block, rows padded to a multiple of 256 (zero rows) so
     // the LDS-DMA of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
@@ -918,6 +949,7 @@ int d3d_engine_set_schedule(d3d_engine* e, int32_t num_timesteps, const float* a
   if (num_timesteps < 1 || sampling_timesteps < 1) return fail(D3D_EINVAL, "timesteps must be positive");
   if (sampling_timesteps > num_timesteps) return fail(D3D_EINVAL, "sampling_timesteps <= timesteps required (DIFF:145)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RangeScope range_scope(e);
   e->drop_graphs();
   e->num_timesteps = num_timesteps; e->S = sampling_timesteps; e->eta = eta; e->clip = clip_denoised ? 1 : 0;
   e->ac.assign(ac_host, ac_host + num_timesteps);
@@ -966,6 +998,7 @@ int d3d_denoise(d3d_engine* e, const float* x2d, const float* y, int32_t y_frame
   if (!x2d || !y || !x0) return fail(D3D_EINVAL, "null tensor");
   if (y_frames != 1 && y_frames != e->T) return fail(D3D_EINVAL, "y_frames must be 1 or num_frame");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RangeScope range_scope(e);
   Workspace w = carve(e, B, ws);
   const float* tvec = nullptr;
   int64_t stride = 0;
@@ -1085,6 +1118,7 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
   if (!x2d || !init_noise || !out) return fail(D3D_EINVAL, "null tensor");
   if (e->eta != 0.0f && !step_noise) return fail(D3D_EINVAL, "step_noise required when eta != 0");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  RangeScope range_scope(e);
   Workspace w = carve(e, B, ws);
   const bool use_graph = e->graph_mode && !traj_rev && !traj_x0 && e->eta == 0.0f && !e->profiling && !e->tracing;
   const bool split = e->opt_streams == 2 && B >= 2 && !e->profiling && !e->tracing;
@@ -1102,9 +1136,20 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
   // inside the workspace, so one instantiated graph serves every call with the same (B, workspace).
   const size_t xin_bytes = (size_t)B * e->T * e->J * e->cfg.in_chans * sizeof(float);
   const size_t y_bytes = (size_t)head_rows(e, B) * 3 * sizeof(float);
+  // the inputs go to the staging buffers FIRST: the eager warm-up pass below then computes the real result from real inputs
+  // (staged behind it, it read uninitialised workspace memory -- large finite garbage could set the sticky range words)
+  if (split) {
+    HIP_TRY(hipMemcpyAsync(sw.w0.XIN, x2d, xin0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sw.w1.XIN, x2d + xin0, xin_bytes - xin0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sw.w0.NIN, init_noise, y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sw.w1.NIN, init_noise + y0, y_bytes - y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  } else {
+    HIP_TRY(hipMemcpyAsync(w.XIN, x2d, xin_bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.NIN, init_noise, y_bytes, hipMemcpyDeviceToDevice, s));
+  }
   hipGraphExec_t exec = nullptr;
   for (auto& g : e->graphs)
-    if (g.B == B && g.ws == ws) exec = g.exec;
+    if (g.B == B && g.ws == ws) { exec = g.exec; g.used = ++e->graph_clock; }
   if (!exec) {
     if (!e->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     auto run = [&](hipStream_t st) {   // (split: each half stages in its own carve-up -- the whole-batch one overlays them)
@@ -1125,21 +1170,24 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d, const float* init_noise, co
     HIP_TRY(ce);
     hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (ie != hipSuccess) { (void)hipGraphDestroy(graph); HIP_TRY(ie); }
-    e->graphs.push_back({B, ws, graph, exec});
+    if (e->graphs.size() >= d3d_engine::MAX_GRAPHS) {   // evict the least recently used (its last replay is complete: the warm-up
+      size_t lru = 0;                                    // pass above synchronised the stream)
+      for (size_t i = 1; i < e->graphs.size(); ++i)
+        if (e->graphs[i].used < e->graphs[lru].used) lru = i;
+      (void)hipDeviceSynchronize();   // (a replay of it on another stream of the caller's must be over too; evictions are rare)
+      (void)hipGraphExecDestroy(e->graphs[lru].exec);
+      (void)hipGraphDestroy(e->graphs[lru].graph);
+      e->graphs.erase(e->graphs.begin() + (long)lru);
+    }
+    e->graphs.push_back({B, ws, graph, exec, ++e->graph_clock});
+    ++e->graphs_captured;
   }
+  HIP_TRY(hipGraphLaunch(exec, s));
   if (split) {
-    HIP_TRY(hipMemcpyAsync(sw.w0.XIN, x2d, xin0 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(sw.w1.XIN, x2d + xin0, xin_bytes - xin0 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(sw.w0.NIN, init_noise, y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(sw.w1.NIN, init_noise + y0, y_bytes - y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipGraphLaunch(exec, s));
     HIP_TRY(hipMemcpyAsync(out, sw.w0.OUTB, y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(out + y0, sw.w1.OUTB, y_bytes - y0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return D3D_OK;
   }
-  HIP_TRY(hipMemcpyAsync(w.XIN, x2d, xin_bytes, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemcpyAsync(w.NIN, init_noise, y_bytes, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipGraphLaunch(exec, s));
   HIP_TRY(hipMemcpyAsync(out, w.OUTB, y_bytes, hipMemcpyDeviceToDevice, s));
   return D3D_OK;
 }
@@ -1174,6 +1222,39 @@ int d3d_q_sample(d3d_engine* e, const float* x_start, const float* noise, const 
   if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set");
   if (!e->has_sqrt_ac) return fail(D3D_ESTATE, "sqrt_alphas_cumprod not supplied (d3d_engine_set_sqrt_alphas_cumprod)");
   HIP_TRY(launch_q_sample(x_start, noise, t_dev, e->sqrt_ac_dev, e->somac_dev, out, B, n, reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
+int d3d_weighted_loss(d3d_engine* e, const float* model_out, const float* target, const int32_t* t_dev, float* out, int32_t B,
+                      int64_t n, int32_t loss_type, int32_t clip_loss, void* stream) {
+  if (!e || !model_out || !target || !t_dev || !out || B < 1 || n < 1) return fail(D3D_EINVAL, "bad argument");
+  if (loss_type != 1 && loss_type != 2) return fail(D3D_EINVAL, "loss_type: 1 = l1, 2 = l2 (DIFF:368-375)");
+  if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set");
+  HIP_TRY(launch_weighted_loss(model_out, target, t_dev, e->ac_dev, e->somac_dev, out, B, n, loss_type == 2, clip_loss != 0,
+                               reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
+int d3d_repeat_batch(const float* x, float* out, int32_t B, int64_t n, int32_t repeat_n, void* stream) {
+  if (!x || !out || B < 1 || n < 1 || repeat_n < 1) return fail(D3D_EINVAL, "bad argument");
+  HIP_TRY(launch_repeat_rows(x, out, B, n, repeat_n, reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
+int d3d_hypothesis_mean(const float* pred, float* out, int32_t B, int64_t n, int32_t repeat_n, void* stream) {
+  if (!pred || !out || B < 1 || n < 1 || repeat_n < 1) return fail(D3D_EINVAL, "bad argument");
+  HIP_TRY(launch_hypothesis_mean(pred, out, B, n, repeat_n, reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
+int d3d_engine_get_info(const d3d_engine* e, const char* key, int64_t* value) {
+  if (!e || !key || !value) return fail(D3D_EINVAL, "null argument");
+  const std::string k(key);
+  if (k == "graphs_cached") *value = (int64_t)e->graphs.size();
+  else if (k == "graphs_captured") *value = (int64_t)e->graphs_captured;
+  else if (k == "streams") *value = e->opt_streams;
+  else if (k == "device") *value = e->device;
+  else return fail(D3D_EINVAL, "unknown info key: " + k);
   return D3D_OK;
 }
 
@@ -1252,13 +1333,11 @@ int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* 
   if (!e || !flags) return fail(D3D_EINVAL, "null argument");
   if (!e->committed) return fail(D3D_ESTATE, "weights not committed");
   HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
-  unsigned a = 0, b = 0, c = 0, d = 0;
-  HIP_TRY(range_flags_gemm(&a, clear != 0));
-  HIP_TRY(range_flags_elem(&b, clear != 0));
-  HIP_TRY(range_flags_attn(&c, clear != 0));
-  HIP_TRY(range_flags_attn32(&d, clear != 0));
-  *flags = ((((a & 1u) | b | c | d) ? D3D_RANGE_ACT : 0u)) | (e->weights_clamped ? D3D_RANGE_WEIGHT : 0u) |
-           ((a & 2u) ? D3D_RANGE_STATS : 0u);
+  unsigned w = 0;
+  HIP_TRY(hipMemcpy(&w, e->range_dev, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (clear && w) HIP_TRY(hipMemset(e->range_dev, 0, sizeof(unsigned)));
+  *flags = ((w & RANGE_BIT_ACT) ? D3D_RANGE_ACT : 0u) | (e->weights_clamped ? D3D_RANGE_WEIGHT : 0u) |
+           ((w & RANGE_BIT_STATS) ? D3D_RANGE_STATS : 0u);
   return D3D_OK;
 }
 
@@ -1340,6 +1419,7 @@ int d3d_op_time_embedding(d3d_engine* e, const float* times_dev, int32_t n, floa
   if (!e || !times_dev || !out || !scratch || n <= 0) return fail(D3D_EINVAL, "bad argument");
   if (!e->committed) return fail(D3D_ESTATE, "weights not committed");
   if (!e->Dt) return fail(D3D_ESTATE, "engine was built with with_time_emb = 0");
+  RangeScope range_scope(e);
   return compute_temb(e, times_dev, n, out, scratch, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1387,10 +1467,14 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
     if (K % 64 || N % 8) return fail(D3D_EUNSUP, "bf16 mode: K % 64 == 0 and N % 8 == 0");
     if (epi == EPI_RESIDUAL && !R) return fail(D3D_EINVAL, "residual required");
     const size_t mp = ((size_t)M + 255) / 256 * 256, np = ((size_t)N + 255) / 256 * 256;
-    uint16_t *ab = nullptr, *wb = nullptr, *cb = nullptr;
-    HIP_TRY(hipMalloc(&ab, mp * K * 2));
-    HIP_TRY(hipMalloc(&wb, np * K * 2));
-    HIP_TRY(hipMalloc(&cb, (size_t)M * N * 2));
+    struct DevBuf {   // (freed on every return path: HIP_TRY leaves early)
+      uint16_t* p = nullptr;
+      ~DevBuf() { (void)hipFree(p); }
+    } ab_, wb_, cb_;
+    HIP_TRY(hipMalloc(&ab_.p, mp * K * 2));
+    HIP_TRY(hipMalloc(&wb_.p, np * K * 2));
+    HIP_TRY(hipMalloc(&cb_.p, (size_t)M * N * 2));
+    uint16_t *ab = ab_.p, *wb = wb_.p, *cb = cb_.p;
     hipError_t le = hipMemsetAsync(ab, 0, mp * K * 2, s);
     if (le == hipSuccess) le = hipMemsetAsync(wb, 0, np * K * 2, s);
     if (le == hipSuccess) le = launch_f32_to_bf16(A, ab, (size_t)M * K, s);
@@ -1412,7 +1496,6 @@ int d3d_op_linear_bench(const float* A, const float* W, const float* bias, const
     }
     if (le == hipSuccess && epi != EPI_RESIDUAL) le = launch_bf16_to_f32(cb, C, (size_t)M * N, s);
     hipError_t se = hipStreamSynchronize(s);
-    (void)hipFree(ab); (void)hipFree(wb); (void)hipFree(cb);
     HIP_TRY(le);
     HIP_TRY(se);
     return D3D_OK;

@@ -111,6 +111,7 @@ struct X3Tail {            // per-launch extras (device copy of X3Fold + derived
   const _Float16* Rp;
   float* st_out;
   X3PostNorm pn;
+  unsigned* range;         // the launching engine's range-guard word (d3d_kernels.h)
 };
 
 // lds_x: the workgroup's LDS beyond the operand stages: [BM] float2 row statistics (FX_LNF)
@@ -118,7 +119,7 @@ template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
                                              const float* Rt, float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
                                              const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
-                                             int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE) {
+                                             int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE, unsigned* rw) {
   // [gl, gh): the wave's m-tiles that are computed (all of them except in a split tail tile, x3q_tile)
   // patch: two wave-private 16 rows x 64 floats (alternating, so the LDS round trip of one m-tile overlaps the stores
   // of the previous one), 16-byte chunks XOR-swizzled by (row & 7)
@@ -240,7 +241,7 @@ __device__ __forceinline__ void x3q_epilogue(f32x4 (&acc)[TM][4], float* patch, 
       __builtin_amdgcn_sched_barrier(0);   // two m-tiles (two patches) in flight at a time
     }
   }
-  if constexpr (OUTSPLIT != 0 && !(FX & FX_SO)) range_note(amax);
+  if constexpr (OUTSPLIT != 0 && !(FX & FX_SO)) range_note(rw, amax);
 }
 
 // The same epilogue for the forms that touch fp16 planes (plane / pair outputs, plane residual): the read-back side gives a
@@ -257,7 +258,7 @@ template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
                                               float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
                                               const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
-                                              int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE) {
+                                              int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE, unsigned* rw) {
   static_assert(EPI != EPI_RESIDUAL || (FX & FX_RP), "the 8-column epilogue takes its residual from planes");
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
@@ -378,7 +379,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if constexpr (OUTSPLIT != 0 && OUTSPLIT != 3 && !(FX & FX_SO)) range_note(amax * osc);
+  if constexpr (OUTSPLIT != 0 && OUTSPLIT != 3 && !(FX & FX_SO)) range_note(rw, amax * osc);
 }
 
 // GELU + pair output straight from the accumulators (fc1 -> hidden activation).  The hidden activation is only ever the A
@@ -388,7 +389,7 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
 template <int TM, int WM, int WN, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned char* lds_x, const float* __restrict__ bias,
                                                  _Float16* Cht, const float* __restrict__ csum, int mt0, int nt0, int rbase, int lane,
-                                                 int M, int N, int gl, int gh, const float P_OUT_SCALE) {
+                                                 int M, int N, int gl, int gh, const float P_OUT_SCALE, unsigned* rw) {
   const int m16 = lane & 15, q4 = lane >> 4;
   f2 bb[4][2], cs[4][2];
 #pragma unroll
@@ -447,7 +448,7 @@ __device__ __forceinline__ void x3q_epilogue_acc(f32x4 (&acc)[TM][4], unsigned c
     }
     if (i & 1) __builtin_amdgcn_sched_barrier(0);
   }
-  range_note(amax * P_A_SCALE);
+  range_note(rw, amax * P_A_SCALE);
 }
 
 // Post-norm epilogue (FX_PN): the workgroup's tile is BM full rows (WM == 1, N == 64 WN), so the block's post-norm
@@ -598,7 +599,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (OUTSPLIT == 2) range_note(amax * P_A_SCALE);
+  if (OUTSPLIT == 2) range_note(fx.range, amax * P_A_SCALE);
 }
 
 // Whole-row epilogue of the bf16 operand mode (FX_PN | FX_BF16; x3q_epilogue_pn's structure with an fp32 residual stream):

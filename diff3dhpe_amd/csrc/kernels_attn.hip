@@ -20,23 +20,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h4a __attribute__((ext_vector_type(4)));
 typedef _Float16 h8a __attribute__((ext_vector_type(8)));
 
-// F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = a clamp fired
-__device__ unsigned g_range_attn32;
-
 // fp32 -> (hi, lo) fp16 pair of 8*x: the operand format of the F16X3 GEMM (kernels_gemm_x3p.hip)
-__device__ __forceinline__ void split1_x3(float x, _Float16& hi, _Float16& lo) {
-  if (fabsf(x) > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn32, 1u);   // (fp32-mode kernels feeding an F16X3 GEMM: not the hot path)
+__device__ __forceinline__ void split1_x3(float x, _Float16& hi, _Float16& lo, unsigned* rw) {
+  if (fabsf(x) > X3_HALF_MAX * 0.125f) range_raise(rw, RANGE_BIT_ACT);   // (fp32-mode kernels feeding an F16X3 GEMM: not the hot path)
   const float s = __builtin_amdgcn_fmed3f(x * 8.0f, -65504.0f, 65504.0f);
   hi = (_Float16)s;
   lo = (_Float16)(s - (float)hi);
 }
-__device__ __forceinline__ void store4_x3(_Float16* hp, _Float16* lp, float a, float b, float c, float d) {
+__device__ __forceinline__ void store4_x3(_Float16* hp, _Float16* lp, float a, float b, float c, float d, unsigned* rw) {
   const float f[4] = {a, b, c, d};
   h4a hi, lo;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     _Float16 x, y;
-    split1_x3(f[j], x, y);
+    split1_x3(f[j], x, y, rw);
     hi[j] = x;
     lo[j] = y;
   }
@@ -50,7 +47,7 @@ constexpr int SP_DH = 64;
 template <int NJ>
 __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restrict__ qkv, float* __restrict__ out,
                                                           _Float16* __restrict__ out_x3,
-                                                          int units, int H, int D) {
+                                                          int units, int H, int D, unsigned* rw) {
   constexpr int UPW = 64 / NJ;                   // (group, head) units per wave
   constexpr int UNIT_LD = NJ * SP_DH + 4;        // +16 B so the UPW broadcast addresses fall in different banks
   constexpr int ROWS4 = NJ * (SP_DH / 4);        // float4 per unit
@@ -157,7 +154,7 @@ __global__ __launch_bounds__(256) void k_attn_spatial_f32(const float* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           _Float16 x, y;
-          split1_x3(o[c + e], x, y);
+          split1_x3(o[c + e], x, y, rw);
           hi[e] = x;
           lo[e] = y;
         }
@@ -181,7 +178,7 @@ hipError_t launch_attn_spatial_f32(const float* qkv, float* out, void* out_x3, i
   constexpr int UPB = 4 * (64 / 17);
   const long long grid = (units + UPB - 1) / UPB;
   if (units > 0x7fffffffLL || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_attn_spatial_f32<17>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_x3, (int)units, H, D);
+  hipLaunchKernelGGL(k_attn_spatial_f32<17>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_x3, (int)units, H, D, launch_range_word());
   return hipGetLastError();
 }
 
@@ -191,7 +188,7 @@ constexpr int TP_DH = 64, K_LD = 68, V_LD = 64;
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __restrict__ qkv, float* __restrict__ out,
                                                                 _Float16* __restrict__ out_x3,
-                                                                int T, int J, int H, int D) {
+                                                                int T, int J, int H, int D, unsigned* rw) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TP = 32 * NKT;
   float* Ks = lds;                 // [TP][K_LD]  (272-B rows: ds_read_b128 of 16 consecutive keys is conflict-free)
@@ -303,19 +300,12 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_f32(const float* __r
         const size_t o = oo + dt * 32 + 8 * g4 + 4 * hh;
         if (out_x3)   // pair layout: oo % 32 == 0, the 32-column tile dt is one 128-byte line
           store4_x3(out_x3 + 2 * oo + dt * 64 + 8 * g4 + 4 * hh, out_x3 + 2 * oo + dt * 64 + 8 * g4 + 4 * hh + PAIR_LO,
-                    oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
+                    oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3], rw);
         else
           *reinterpret_cast<float4*>(out + o) =
               make_float4(oacc[dt][4 * g4], oacc[dt][4 * g4 + 1], oacc[dt][4 * g4 + 2], oacc[dt][4 * g4 + 3]);
       }
   }
-}
-
-hipError_t range_flags_attn32(unsigned* flags, bool clear) {
-  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_attn32), sizeof(unsigned));
-  const unsigned zero = 0;
-  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_attn32), &zero, sizeof(unsigned));
-  return e;
 }
 
 bool attn_temporal_fast_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * TP_DH; }
@@ -329,7 +319,7 @@ static hipError_t launch_temporal_nkt(const float* qkv, float* out, void* out_x3
   const long long grid = (long long)B * J * H;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_attn_temporal_f32<NKT>, dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, qkv, out,
-                     (_Float16*)out_x3, T, J, H, D);
+                     (_Float16*)out_x3, T, J, H, D, launch_range_word());
   return hipGetLastError();
 }
 
@@ -352,7 +342,7 @@ hipError_t launch_attn_temporal_f32(const float* qkv, float* out, void* out_x3, 
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_generic(const float* __restrict__ qkv, float* __restrict__ out,
                                                       _Float16* __restrict__ out_x3,
-                                                      long long rows, int N, int H, int D, int temporal, int T, int J) {
+                                                      long long rows, int N, int H, int D, int temporal, int T, int J, unsigned* rw) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= rows) return;
   const int i = (int)(gid % N);
@@ -398,7 +388,7 @@ __global__ __launch_bounds__(256) void k_attn_generic(const float* __restrict__ 
   for (int c = 0; c < DH; ++c) {
     if (out_x3) {
       _Float16* op = out_x3 + token(i) * 2 * D + pair_col(h * DH + c);
-      split1_x3(o[c], op[0], op[PAIR_LO]);
+      split1_x3(o[c], op[0], op[PAIR_LO], rw);
     }
     else out[oo + c] = o[c];
   }
@@ -416,7 +406,7 @@ hipError_t launch_attn_generic(const float* qkv, float* out, void* out_x3, int B
 #define D3D_GEN(DH)                                                                                                    \
   case DH:                                                                                                             \
     hipLaunchKernelGGL(k_attn_generic<DH>, dim3((unsigned)grid), dim3(256), 0, s, qkv, out, (_Float16*)out_x3, rows, N, \
-                       H, D, temporal, T, J);                                                                          \
+                       H, D, temporal, T, J, launch_range_word());                                                   \
     break;
   switch (dh) {
     D3D_GEN(4) D3D_GEN(8) D3D_GEN(16) D3D_GEN(32) D3D_GEN(64)

@@ -41,9 +41,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4_alias __attribute__((ext_vector_type(4), may_alias));
 typedef unsigned u32x4_alias __attribute__((ext_vector_type(4), may_alias));
 
-// F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = an output clamp fired
-__device__ unsigned g_range_attn;
-
 // Output patch, write side.  Lane (row r, half h) of the O^T accumulator layout holds 4 columns of a 16-byte chunk -- hi and lo
 // halves (oh, ol: 8 bytes each) of columns 8 g + 4 h .. + 3.  Written as two ds_write_b64 per lane, rows r and r + 1 of a
 // 16-lane group share a 16-byte slot (a lane's 8-byte position inside its chunk is fixed by h, the same for the whole group):
@@ -91,7 +88,7 @@ __device__ __forceinline__ void split8_e(const float (&e)[8], h8& eh, h8& el) {
 template <int NKT, int MU>
 __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
                                                                     _Float16* __restrict__ out_x3,
-                                                                    int T, int J, int H, int D, int units) {
+                                                                    int T, int J, int H, int D, int units, unsigned* rw) {
   static_assert(MU == 1 || NKT == 1, "several units per workgroup only for single-tile groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   constexpr int TP = 32 * NKT;
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3(const _Float
         *reinterpret_cast<h4*>(out_x3 + oo + pair_col(d)) = oh;
         *reinterpret_cast<h4*>(out_x3 + oo + pair_col(d) + PAIR_LO) = ol;
       }
-    if (amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
+    if (amax > X3_HALF_MAX * 0.125f) range_raise(rw, RANGE_BIT_ACT);
   }
 }
 
@@ -311,7 +308,7 @@ __device__ __forceinline__ const char* sgpr_ptr_x(const char* p) {
 template <int NKT, int MU, int WIT = 3>
 __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
                                                                      _Float16* __restrict__ out_x3, int T, int J, int H, int D,
-                                                                     int units) {
+                                                                     int units, unsigned* rw) {
   static_assert(MU == 1 || NKT == 1, "wave-private units only for single-tile groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   constexpr int TP = 32 * NKT;
@@ -598,7 +595,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
           }
         }
       }
-      if (tq < T && amax > X3_HALF_MAX * 0.125f) atomicOr(&g_range_attn, 1u);
+      if (tq < T && amax > X3_HALF_MAX * 0.125f) range_raise(rw, RANGE_BIT_ACT);
       po_off = (tok0 + (size_t)tqc * J) * 2 * D + hd * 2 * XDH;
       pw_ptr = out_x3 + (tok0 + (size_t)((WAVEP ? 0 : 32 * wave) + (lane >> 3)) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
       po_valid = true;
@@ -673,7 +670,7 @@ constexpr int ATTN_PRIO_S = 2, ATTN_PRIO_PV = 1, ATTN_PRIO_SOFT = 0;
 template <int NKT, int HALF>
 __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl, _Float16* __restrict__ out_x3,
                                               int T, int J, int H, int D, int units, unsigned char* const lds, const int wave,
-                                              unsigned long long* diag) {
+                                              unsigned long long* diag, unsigned* rw) {
   constexpr int TP = 32 * NKT;
   constexpr int PLANE = TP * 128;
   unsigned char* const sKh = lds;                 // K hi plane; lo plane at + PLANE
@@ -950,7 +947,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
 #pragma unroll
         for (int it = 0; it < 4; ++it) po[dt * 4 + it] = patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
       }
-      if (tq < T && amax > X3_HALF_MAX) atomicOr(&g_range_attn, 1u);
+      if (tq < T && amax > X3_HALF_MAX) range_raise(rw, RANGE_BIT_ACT);
       po_ptr = out_x3 + (tok0 + (size_t)(32 * wave + (lane >> 3)) * J) * 2 * D + hd * 2 * XDH + 8 * (lane & 7);
       po_valid = true;
     }
@@ -981,7 +978,7 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3s(const _Float16* __restrict__ Ph, const _Float16* __restrict__ Pl,
                                                                 _Float16* __restrict__ out_x3, int T, int J, int H, int D, int units,
-                                                                unsigned long long* diag) {
+                                                                unsigned long long* diag, unsigned* rw) {
   static_assert(NKT == 8, "two halves of four waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_s[];
   constexpr int TP = 32 * NKT;
@@ -992,15 +989,8 @@ __global__ __launch_bounds__(64 * NKT) void k_attn_temporal_x3s(const _Float16* 
     *reinterpret_cast<uint4*>(lds_s + pl * PLANE + (T + (rem >> 3)) * 128 + ((rem & 7) << 4)) = make_uint4(0, 0, 0, 0);
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // 32-query tile of the unit
-  if (wave < 4) attn_x3s_half<NKT, 0>(Ph, Pl, out_x3, T, J, H, D, units, lds_s, wave, diag);
-  else attn_x3s_half<NKT, 1>(Ph, Pl, out_x3, T, J, H, D, units, lds_s, wave, diag);
-}
-
-hipError_t range_flags_attn(unsigned* flags, bool clear) {
-  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_attn), sizeof(unsigned));
-  const unsigned zero = 0;
-  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_attn), &zero, sizeof(unsigned));
-  return e;
+  if (wave < 4) attn_x3s_half<NKT, 0>(Ph, Pl, out_x3, T, J, H, D, units, lds_s, wave, diag, rw);
+  else attn_x3s_half<NKT, 1>(Ph, Pl, out_x3, T, J, H, D, units, lds_s, wave, diag, rw);
 }
 
 bool attn_temporal_x3_ok(int T, int D, int H) { return T >= 1 && T <= 256 && H > 0 && D == H * XDH; }
@@ -1014,7 +1004,7 @@ static hipError_t launch_x3_nkt(const _Float16* ph, const _Float16* pl, _Float16
   const long long units = (long long)B * J * H;
   if (units > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL((k_attn_temporal_x3<NKT, MU>), dim3((unsigned)((units + MU - 1) / MU)), dim3(64 * NKT * MU), lds_bytes, s, ph,
-                     pl, ox, T, J, H, D, (int)units);
+                     pl, ox, T, J, H, D, (int)units, launch_range_word());
   return hipGetLastError();
 }
 
@@ -1035,7 +1025,7 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
   const long long wgs = (units + MU - 1) / MU;
   const long long grid = wgs < (long long)n_cu * per_cu ? wgs : (long long)n_cu * per_cu;
   hipLaunchKernelGGL((k_attn_temporal_x3p<NKT, MU, WIT>), dim3((unsigned)grid), dim3(64 * NKT * MU), lds_bytes, s, ph, pl, ox, T, J, H,
-                     D, (int)units);
+                     D, (int)units, launch_range_word());
   return hipGetLastError();
 }
 
@@ -1084,7 +1074,7 @@ static hipError_t launch_x3s(const _Float16* ph, const _Float16* pl, _Float16* o
   (void)hipMemsetAsync(g_attn_diag, 0, ATTN_DIAG_WORDS * 8, s);
   diag = g_attn_diag;
 #endif
-  hipLaunchKernelGGL((k_attn_temporal_x3s<NKT>), dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, ox, T, J, H, D, (int)units, diag);
+  hipLaunchKernelGGL((k_attn_temporal_x3s<NKT>), dim3((unsigned)grid), dim3(64 * NKT), lds_bytes, s, ph, pl, ox, T, J, H, D, (int)units, diag, launch_range_word());
   return hipGetLastError();
 }
 

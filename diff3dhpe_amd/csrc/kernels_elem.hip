@@ -9,9 +9,6 @@ namespace d3d {
 
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
-// F16X3 range guard (d3d_kernels.h): sticky per-device word of this translation unit, bit 0 = a plane writer's clamp fired
-__device__ unsigned g_range_elem;
-
 // fp32 -> (hi, lo) fp16 pair of 8*x: the operand format of the F16X3 GEMM (kernels_gemm_x3p.hip)
 __device__ __forceinline__ void split4_x3(const float4 v, h4v& hi, h4v& lo, float& amax) {
   const float f[4] = {v.x, v.y, v.z, v.w};
@@ -132,7 +129,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
         *reinterpret_cast<h4v*>(yp + pair_col(c) + PAIR_LO) = lo;
       }
     }
-    if (amax > X3_HALF_MAX) atomicOr(&g_range_elem, 1u);
+    if (amax > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
   }
   if (a.stats) {
     float sm = 0.f, sq = 0.f;
@@ -172,7 +169,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
           *reinterpret_cast<h4v*>(hp + pair_col(c) + PAIR_LO) = lo;
         }
       }
-      if (amax > X3_HALF_MAX) atomicOr(&g_range_elem, 1u);
+      if (amax > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
     } else {
       float* hr = a.h + (size_t)row * D;
 #pragma unroll
@@ -184,14 +181,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
   }
 }
 
-hipError_t range_flags_elem(unsigned* flags, bool clear) {
-  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_elem), sizeof(unsigned));
-  const unsigned zero = 0;
-  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_elem), &zero, sizeof(unsigned));
-  return e;
-}
-
-hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
+hipError_t launch_layernorm(const LnArgs& a_, hipStream_t s) {
+  LnArgs a = a_;
+  a.range = launch_range_word();   // F16X3 range guard: the launching engine's word (d3d_kernels.h)
   if (a.rows <= 0 || a.D <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
   const int grid = (a.rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   if (a.D <= 256)
@@ -395,7 +387,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
         // process (0 of ~900 traced samplings); the compiler's free schedule -- three loads in flight behind counted waits,
         // o[0] / o[1] in v_pk_fma_f32 pairs -- returned ONE wrong o[0] in about 1 launch of 60 there.  The mechanism below the
         // instruction stream is not identified (experiments/NOTES.md); tests/test_abi_host.py checks the built kernel's ISA
-        // for exactly these two properties, so that a toolchain change cannot silently bring the other stream back.
+        // for these two properties (the one-fragment-at-a-time waits at every width, the unpacked sums at the production width),
+        // and the default GPU suite repeats a two-process sampling (tests/test_gpu_round4.py) as the run-time cross-check.
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
@@ -470,6 +463,55 @@ hipError_t launch_q_sample(const float* x_start, const float* noise, const int32
   const int64_t total = (int64_t)B * n;
   hipLaunchKernelGGL(k_q_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x_start, noise, t, sqrt_ac,
                      somac, out, B, n);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ p_losses tail (DIFF:411-418)
+// out = loss_fn(model_out, target, reduction='none') * loss_coef,  loss_coef[b] = 1 + ac[t_b] / sqrt(1 - ac)[t_b]  [clamped to <= 3]
+// -- the host framework's operation order: fp32 division, add, clamp; difference, square (l2) or absolute value (l1); one multiply.
+__global__ __launch_bounds__(256) void k_weighted_loss(const float* __restrict__ model_out, const float* __restrict__ target,
+                                                       const int32_t* __restrict__ t, const float* __restrict__ ac,
+                                                       const float* __restrict__ somac, float* __restrict__ out, int B, int64_t n,
+                                                       int l2, int clip) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)B * n) return;
+  const int tb = t[gid / n];
+  float coef = __fadd_rn(1.0f, __fdiv_rn(ac[tb], somac[tb]));
+  if (clip) coef = fminf(coef, 3.0f);
+  const float d = __fadd_rn(model_out[gid], -target[gid]);
+  out[gid] = __fmul_rn(l2 ? __fmul_rn(d, d) : fabsf(d), coef);
+}
+
+hipError_t launch_weighted_loss(const float* model_out, const float* target, const int32_t* t, const float* ac, const float* somac,
+                                float* out, int B, int64_t n, int l2, int clip, hipStream_t s) {
+  const int64_t total = (int64_t)B * n;
+  hipLaunchKernelGGL(k_weighted_loss, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, model_out, target, t, ac, somac, out,
+                     B, n, l2, clip);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ repeat_n hypotheses (DIFF:433-448)
+// tile: out[r * B + b, :] = x[b, :] (noisy_2d_pose.repeat(repeat_n, 1, 1, 1));  mean: out[b, :] = (sum_r pred[r * B + b, :]) / R in
+// hypothesis order (torch.mean(pred.view(repeat_n, b, ...), dim=0)).  n = elements per batch row.
+__global__ __launch_bounds__(256) void k_repeat_rows(const float* __restrict__ x, float* __restrict__ out, int64_t rowsn, int64_t total) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid < total) out[gid] = x[gid % rowsn];
+}
+__global__ __launch_bounds__(256) void k_hypothesis_mean(const float* __restrict__ pred, float* __restrict__ out, int64_t rowsn, int R) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= rowsn) return;
+  float acc = pred[gid];
+  for (int r = 1; r < R; ++r) acc = __fadd_rn(acc, pred[(int64_t)r * rowsn + gid]);
+  out[gid] = __fdiv_rn(acc, (float)R);
+}
+hipError_t launch_repeat_rows(const float* x, float* out, int B, int64_t n, int R, hipStream_t s) {
+  const int64_t rowsn = (int64_t)B * n, total = rowsn * R;
+  hipLaunchKernelGGL(k_repeat_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, rowsn, total);
+  return hipGetLastError();
+}
+hipError_t launch_hypothesis_mean(const float* pred, float* out, int B, int64_t n, int R, hipStream_t s) {
+  const int64_t rowsn = (int64_t)B * n;
+  hipLaunchKernelGGL(k_hypothesis_mean, dim3((unsigned)((rowsn + 255) / 256)), dim3(256), 0, s, pred, out, rowsn, R);
   return hipGetLastError();
 }
 

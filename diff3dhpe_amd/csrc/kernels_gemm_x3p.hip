@@ -40,20 +40,19 @@ constexpr int PBK = 32;                          // k-tile depth (fp16 elements)
 constexpr float P_A_SCALE = 8.0f;
 
 // F16X3 range guard (d3d_kernels.h): every plane writer tracks max |scaled value| per lane; a lane whose value left the fp16
-// range (|x| > 8188) ORs bit 0 into this sticky per-device word once, at the end of its epilogue.
-__device__ unsigned g_range_x3p;
-__device__ __forceinline__ void range_note(float amax) {
+// range (|x| > 8188) ORs bit 0 into the launching engine's sticky word (X3Tail::range) once, at the end of its epilogue.
+__device__ __forceinline__ void range_note(unsigned* rw, float amax) {
 #ifndef D3D_NO_RANGE_GUARD
-  if (amax > X3_HALF_MAX) atomicOr(&g_range_x3p, 1u);
+  if (amax > X3_HALF_MAX) range_raise(rw, RANGE_BIT_ACT);
 #endif
 }
 // Bit 1: a LayerNorm folded into a GEMM met a row whose mean dwarfs its spread.  The folded form has the row's ONE-PASS
 // statistics (sum, sum of squares from the producer's epilogue): var = E[x^2] - mean^2 loses relative accuracy like
 // eps (1 + mean^2 / var) -- 4x the two-pass error at |mean| = 8 sigma, the 1e-4 parity gate near 25 sigma (measured:
 // test_folded_layernorm_statistics_with_offset_rows).  Raised from |mean| > 16 sigma on; remedy as for bit 0: precision fp32.
-__device__ __forceinline__ void range_note_stats(float mean, float var) {
+__device__ __forceinline__ void range_note_stats(unsigned* rw, float mean, float var) {
 #ifndef D3D_NO_RANGE_GUARD
-  if (mean * mean > 256.0f * var) atomicOr(&g_range_x3p, 2u);
+  if (mean * mean > 256.0f * var) range_raise(rw, RANGE_BIT_STATS);
 #endif
 }
 
@@ -222,10 +221,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       // range guard for the producer of these rows (the proj / fc2 epilogues write the planes of x and these statistics of the
       // values themselves): an element |x| > 8188 implies sum x^2 > 8188^2 -- never missed; rows of ~512 values above ~360
       // would raise it falsely, a LayerNorm-ed stream is orders of magnitude below
-      if (sq >= (X3_HALF_MAX * 0.125f) * (X3_HALF_MAX * 0.125f)) range_note(2.0f * X3_HALF_MAX);
+      if (sq >= (X3_HALF_MAX * 0.125f) * (X3_HALF_MAX * 0.125f)) range_note(fx.range, 2.0f * X3_HALF_MAX);
       const float mean = sm / (float)K;
       const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
-      if (row < M) range_note_stats(mean, var);
+      if (row < M) range_note_stats(fx.range, mean, var);
       const float rstd = 1.0f / sqrtf(var + fx.eps);
       // (rstd carries the GEMM's power-of-two output scale: the epilogues form rstd' acc - rstd mean csum + b' in two fmas)
       reinterpret_cast<float2*>(lds_x)[tidx] = make_float2(rstd * fx.out_scale, -mean * rstd);
@@ -636,37 +635,37 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   } else if constexpr (EPI == EPI_GELU && OUTSPLIT == 2) {   // hidden activation, accumulator order: no transpose
     static_assert(!(FX & (FX_RP | FX_SO)), "fc1 form");
     if constexpr (FULL)
-      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale);
+      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale, fx.range);
     else if (full)
-      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale);
+      x3q_epilogue_acc<TM, WM, WN, FX, false>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale, fx.range);
     else
-      x3q_epilogue_acc<TM, WM, WN, FX, true>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale);
+      x3q_epilogue_acc<TM, WM, WN, FX, true>(acc, lds_x, bias, Cht, fx.csum, mt0, nt0, mt0 - m0, lane, M, N, gl, gh, fx.out_scale, fx.range);
     done = true;
   } else if constexpr (PLANES) {   // 8 columns per lane: 16-byte plane accesses
     if ((N & 7) == 0) {
       // (the row-statistics form keeps one copy per instantiation: with two copies under the branch its accumulators spill)
       if constexpr (FULL)
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
       else if (full && !(FX & FX_SO))
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
       else
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                          mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
+                                                          mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
       done = true;
     }
   }
   if (!done) {
     if constexpr (FULL)
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
+                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
     else if (full)
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
+                                                        nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
     else
       x3q_epilogue<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Rt, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0,
-                                                       nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale);
+                                                       nt0, mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
   }
   if (diag) {
     __builtin_amdgcn_s_waitcnt(0);   // the wave's own stores issued and acknowledged
@@ -824,6 +823,7 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   size_t lds_bytes = 2 * (size_t)((BM + BN) * 128);
   X3Tail tail{};
   tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
+  tail.range = launch_range_word();
   int fx = 0;
   if (fold) {
     if (fold->st_in) fx |= FX_LNF;
@@ -891,6 +891,7 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
   size_t lds_bytes = 2 * (size_t)(512 * 128);
   X3Tail tail{};
   tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
+  tail.range = launch_range_word();
   int fx = 0;
   if (fold) {
     if (fold->st_in) fx |= FX_LNF;
@@ -956,6 +957,7 @@ static hipError_t launch_x3q_pn(const _Float16* Ap, const _Float16* Wp, const fl
   const size_t lds_small = 2 * (size_t)((64 + 512) * 128);
   X3Tail tail{};
   tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
+  tail.range = launch_range_word();
   tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out; tail.pn = fold->pn;
   const int qcols = 0;
   unsigned long long* diag = nullptr;
@@ -1018,6 +1020,7 @@ hipError_t launch_linear_bf16_rows(const void* A, const void* W, const float* bi
   const size_t lds_small = 2 * (size_t)((64 + 512) * 128);
   X3Tail tail{};
   tail.out_scale = 1.0f;
+  tail.range = launch_range_word();
   tail.pn = pn;
   const int qcols = 0;
   unsigned long long* diag = nullptr;
@@ -1111,13 +1114,6 @@ hipError_t launch_bf16_to_f32(const void* x, float* y, size_t n, hipStream_t s) 
 
 void set_linear_x3_diag(unsigned long long* dev_buf) { g_x3_diag = dev_buf; }
 
-hipError_t range_flags_gemm(unsigned* flags, bool clear) {
-  hipError_t e = hipMemcpyFromSymbol(flags, HIP_SYMBOL(g_range_x3p), sizeof(unsigned));
-  const unsigned zero = 0;
-  if (e == hipSuccess && clear && *flags) e = hipMemcpyToSymbol(HIP_SYMBOL(g_range_x3p), &zero, sizeof(unsigned));
-  return e;
-}
-
 // variant: 0 = auto (launch_x3q_auto); the two production shapes forced, one workgroup per tile (experiments/gemm_bench.py):
 // 13 = 256x256 (with the per-wave diagnostic stamps when set_linear_x3_diag() armed them), 4 = 256x128
 hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias, const float* R, float* C, void* Ch, void* Cl,
@@ -1143,7 +1139,8 @@ hipError_t launch_linear_x3p(const void* Ap_, const void* Wp_, const float* bias
 }
 
 // fp32 [rows, cols] -> pair layout of 8*x (stand-alone converter: tests, and any activation whose producer is not ours)
-__global__ __launch_bounds__(256) void k_split_x3(const float* __restrict__ x, _Float16* __restrict__ pair, size_t n4, int cols) {
+__global__ __launch_bounds__(256) void k_split_x3(const float* __restrict__ x, _Float16* __restrict__ pair, size_t n4, int cols,
+                                                  unsigned* rw) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -1159,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_split_x3(const float* __restrict__ x, _
     a[j] = (_Float16)s;
     b[j] = (_Float16)(s - (float)a[j]);
   }
-  range_note(amax);
+  range_note(rw, amax);
   _Float16* p = pair + row * 2 * cols + pair_col(c);
   *reinterpret_cast<h4*>(p) = a;
   *reinterpret_cast<h4*>(p + PAIR_LO) = b;
@@ -1169,7 +1166,7 @@ hipError_t launch_split_x3(const float* x, void* pair, size_t rows, int cols, hi
   if (cols <= 0 || cols % 32) return hipErrorInvalidValue;
   const size_t n4 = rows * cols / 4;
   if (n4 == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_split_x3, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, (_Float16*)pair, n4, cols);
+  hipLaunchKernelGGL(k_split_x3, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, (_Float16*)pair, n4, cols, launch_range_word());
   return hipGetLastError();
 }
 

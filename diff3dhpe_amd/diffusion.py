@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
+from .engine import hypothesis_mean, repeat_batch
 from .nets import _MixSTEDenoiser
 
 
@@ -193,13 +194,11 @@ class GaussianDiffusion(nn.Module):
             noise = torch.randn_like(x_start)
         x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
         dev = self.model._compute_device(pose_2d, self.betas)
-        model_out = self._engine(dev).denoise(pose_2d, x_noisy, t).to(x_start.device)   # y broadcast over T for seq2frame
-        ac = self.alphas_cumprod.to(x_start.device)
-        so = self.sqrt_one_minus_alphas_cumprod.to(x_start.device)
-        loss_coef = 1.0 + ac[t].view(-1, 1, 1, 1) / so[t].view(-1, 1, 1, 1)
-        if self.clipLoss:
-            loss_coef = torch.clamp(loss_coef, max=3.0)
-        return self.loss_fn(model_out, x_start, reduction='none') * loss_coef
+        eng = self._engine(dev)
+        model_out = eng.denoise(pose_2d, x_noisy, t)                                     # y broadcast over T for seq2frame
+        self.loss_fn                                                                     # (ValueError on an unknown loss_type, DIFF:375)
+        # the variable loss weight 1 + k_t, its clamp and the loss itself (DIFF:411-418) are one engine kernel (d3d_weighted_loss)
+        return eng.weighted_loss(model_out, x_start, t, self.loss_type, self.clipLoss).to(x_start.device)
 
     # ------------------------------------------------------------------ forward (DIFF:421-449)
     def forward(self, clean_3d_pose, noisy_2d_pose, noise=None, output_reverse_diffusion_3d=False, output_loss=True,
@@ -209,7 +208,9 @@ class GaussianDiffusion(nn.Module):
             return self.p_losses(clean_3d_pose, noisy_2d_pose, noise), None
         loss_pose = self.p_losses(clean_3d_pose, noisy_2d_pose, noise) if output_loss else None
         b, f, p, c = clean_3d_pose.shape
-        noisy_2d_pose = noisy_2d_pose.repeat(repeat_n, 1, 1, 1)
+        in_dev = noisy_2d_pose.device
+        if repeat_n != 1:   # .repeat(repeat_n, 1, 1, 1) (DIFF:433) and the mean over the hypotheses below: engine kernels
+            noisy_2d_pose = repeat_batch(noisy_2d_pose.to(self.model._compute_device(noisy_2d_pose, self.betas)), repeat_n)
         target_shape = list(clean_3d_pose.shape)
         target_shape[0] = target_shape[0] * repeat_n
         res = self.forward_estimate_pose(noisy_2d_pose, target_shape=target_shape,
@@ -217,7 +218,5 @@ class GaussianDiffusion(nn.Module):
                                          init_noise=init_noise, step_noise=step_noise)
         if output_reverse_diffusion_3d:
             pred, rev, x0s = res
-            pred = torch.mean(pred.view(repeat_n, b, f, p, -1), dim=0, keepdim=True).squeeze(0)
-            return loss_pose, pred, rev, x0s
-        pred = torch.mean(res.view(repeat_n, b, f, p, -1), dim=0, keepdim=True).squeeze(0)
-        return loss_pose, pred
+            return loss_pose, hypothesis_mean(pred, repeat_n).to(in_dev), rev.to(in_dev), x0s.to(in_dev)   # DIFF:441
+        return loss_pose, hypothesis_mean(res, repeat_n).to(in_dev)                      # DIFF:448

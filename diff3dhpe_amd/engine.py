@@ -163,9 +163,15 @@ class Engine:
         """Explicit engine switch (include/d3d.h: "fused_postnorm", "fold_layernorm", "streams"); the library reads no environment."""
         _lib.check(_lib.lib().d3d_engine_set_option(self._h, key.encode(), int(value)))
 
+    def info(self, key: str) -> int:
+        """Read-only engine facts (include/d3d.h d3d_engine_get_info): "graphs_cached", "graphs_captured", "streams", "device"."""
+        v = C.c_int64(0)
+        _lib.check(_lib.lib().d3d_engine_get_info(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def range_flags(self, clear: bool = True) -> int:
         """F16X3 range guard (include/d3d.h): _lib.RANGE_ACT | RANGE_WEIGHT | RANGE_STATS bits; synchronises the current stream.
-        The activation / statistics words are per DEVICE, cleared on read: engines (or streams) sharing a device share them."""
+        The flags belong to THIS engine (its own word of device memory), cleared on read."""
         f = C.c_uint32(0)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().d3d_engine_range_flags(self._h, C.byref(f), int(clear), self._stream()))
@@ -175,7 +181,7 @@ class Engine:
         """Raise D3DError if the F16X3 range guard fired since the last check (use precision='fp32' then)."""
         f = self.range_flags(clear=True)
         if f:
-            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a non-finite GEMM weight"),
+            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a non-finite (or beyond ~1e9: unrepresentable) GEMM weight"),
                                    (_lib.RANGE_STATS, "a LayerNorm input row with |mean| > 16 standard deviations (one-pass statistics)"))
                     if f & b]
             raise _lib.D3DError("F16X3 operand range exceeded by " + " and ".join(what) +
@@ -239,6 +245,48 @@ class Engine:
             _lib.check(_lib.lib().d3d_q_sample(self._h, _ptr(xs), _ptr(nz), _ptr(ti), _ptr(out), B, xs.numel() // B,
                                                self._stream()))
         return out
+
+
+    def weighted_loss(self, model_out: torch.Tensor, target: torch.Tensor, t: torch.Tensor, loss_type: str, clip_loss: bool) -> torch.Tensor:
+        """p_losses tail (DIFF:411-418): loss_fn(model_out, target, 'none') * min(1 + ac[t] / sqrt(1 - ac)[t], 3 if clip_loss)."""
+        B = target.shape[0]
+        mo, tg = _f32c(model_out, self.device), _f32c(target, self.device)
+        assert mo.shape == tg.shape, (mo.shape, tg.shape)
+        ti = t.detach().to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty_like(tg)
+        if B == 0:
+            return out
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_weighted_loss(self._h, _ptr(mo), _ptr(tg), _ptr(ti), _ptr(out), B, tg.numel() // B,
+                                                    {"l1": 1, "l2": 2}[loss_type], int(bool(clip_loss)), self._stream()))
+        return out
+
+
+def repeat_batch(x: torch.Tensor, repeat_n: int) -> torch.Tensor:
+    """x.repeat(repeat_n, 1, ...) on the device (DIFF:433): (B, ...) -> (repeat_n * B, ...)."""
+    if repeat_n == 1 or x.shape[0] == 0:
+        return x
+    dev = x.device
+    xs = _f32c(x, dev)
+    out = torch.empty((repeat_n * xs.shape[0],) + tuple(xs.shape[1:]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_repeat_batch(_ptr(xs), _ptr(out), xs.shape[0], xs.numel() // xs.shape[0], int(repeat_n), st))
+    return out
+
+
+def hypothesis_mean(pred: torch.Tensor, repeat_n: int) -> torch.Tensor:
+    """torch.mean(pred.view(repeat_n, b, ...), dim=0) on the device (DIFF:441/448): (repeat_n * B, ...) -> (B, ...)."""
+    if repeat_n == 1 or pred.shape[0] == 0:
+        return pred
+    dev = pred.device
+    ps = _f32c(pred, dev)
+    B = ps.shape[0] // repeat_n
+    out = torch.empty((B,) + tuple(ps.shape[1:]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_hypothesis_mean(_ptr(ps), _ptr(out), B, ps.numel() // ps.shape[0], int(repeat_n), st))
+    return out
 
 
 # ---------------------------------------------------------------------------------------- stand-alone op wrappers

@@ -64,10 +64,12 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
             _, pred_f = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d_f[sl].to(dev), output_loss=False,
                                         init_noise=None if batch.get("init_noise_flip") is None else batch["init_noise_flip"][sl])
         gsl = sl
-        if world > 1:   # the one exchange step: all-gather the predicted sequences; every rank then reduces the full batch
-            pred = parallel.all_gather_pred(pred, B)
-            if pred_f is not None:
-                pred_f = parallel.all_gather_pred(pred_f, B)
+        if world > 1:   # the ONE exchange step: all-gather the predicted sequences; every rank then reduces the full batch
+            if pred_f is not None:   # the TTA pair travels together: (b, 2, T, J, 3) shards, one collective per batch
+                both = parallel.all_gather_pred(torch.stack([pred, pred_f], dim=1), B)
+                pred, pred_f = both[:, 0], both[:, 1]
+            else:
+                pred = parallel.all_gather_pred(pred, B)
             gsl = slice(0, B)
         err, cnt = tta_mpjpe(pred, pred_f, gt[gsl].to(dev), None if mask is None else mask[gsl].to(dev), scale,
                              list(joints_left), list(joints_right))

@@ -122,11 +122,17 @@ class _MixSTEDenoiser(nn.Module):
             raise _lib.D3DError("engine_for() needs a HIP device")
         idx = device.index if device.index is not None else torch.cuda.current_device()
         if not self.allow_multi_device and self._engines and idx not in self._engines:
-            raise _lib.D3DError(
-                f"this model already runs on cuda:{next(iter(self._engines))} and is now asked to run on cuda:{idx}: diff3dhpe_amd "
-                "supports ONE device per process (launch one process per GPU: torchrun --nproc-per-node N, or pass one id to "
-                "--gpu_id); nn.DataParallel over several devices in one process is untested -- set allow_multi_device = True on "
-                "the model class to try it")
+            p = self._tensor("fusion_layer.weight")
+            moved = self._src_sig is None and p.is_cuda and p.device.index == idx
+            if moved:   # the module itself was moved (.to('cuda:1') after running on cuda:0): one device at a time -- release the
+                self._engines.clear()         # stale engine (its weights, tables and workspace live on the old device)
+                self._engine_sig.clear()
+            else:
+                raise _lib.D3DError(
+                    f"this model already runs on cuda:{next(iter(self._engines))} and is now asked to run on cuda:{idx}: diff3dhpe_amd "
+                    "supports ONE device per process (launch one process per GPU: `python bench.py --gpus N`, torchrun --nproc-per-node "
+                    "N, or pass one id to --gpu_id); nn.DataParallel over several devices in one process is untested -- set "
+                    "allow_multi_device = True on the model class to try it (moving the whole module with .to() is fine)")
         eng = self._engines.get(idx)
         if eng is None or eng.precision != self.precision:
             eng = Engine(self.cfg, precision=self.precision, device=torch.device("cuda", idx))

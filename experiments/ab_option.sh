@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of an engine option on one box:  experiments/ab_option.sh fused_postnorm=0 [reps] [bench args]
 #   -> pose-seq/s and per-class kernel ms with the default engine / with the option, alternating runs of bench.py
-opt=$1; reps=${2:-2}; shift 2
+opt=$1; shift; reps=${1:-2}; [ $# -gt 0 ] && shift
 pick='import sys,json; d=json.loads(sys.stdin.read()); k=d["roofline"]["by_kernel_ms_per_step"]; print(d["value"], k.get("linear"), k.get("attn_spatial"), k.get("attn_temporal"))'
 for r in $(seq $reps); do
   a=$(python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-selfcheck --no-extras "$@" | python -c "$pick")

@@ -121,7 +121,9 @@ int d3d_ddim_sample(d3d_engine* e, const float* x2d_dev, const float* init_noise
 
 /* hipGraph replay of d3d_ddim_sample: when enabled (and eta == 0, no trajectory capture, profiling off) the whole S-step
  * launch sequence is captured once per (B, workspace pointer) and replayed with one hipGraphLaunch per call; inputs and
- * the result go through staging buffers inside the workspace.  Weights / schedule changes drop the captured graphs. */
+ * the result go through staging buffers inside the workspace.  Weights / schedule changes drop the captured graphs.  At most
+ * FOUR captured graphs are kept per engine: a fifth (B, workspace) pair evicts the least recently used one (a caller that
+ * re-allocates its workspace per batch re-captures every time, but does not accumulate graphs). */
 int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
 
 /* Explicit switches (the library reads NO environment variables).  Engine options (results stay within the parity gate either way;
@@ -140,6 +142,22 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value);
  * n = elements per batch row. */
 int d3d_q_sample(d3d_engine* e, const float* x_start_dev, const float* noise_dev, const int32_t* t_dev, float* out_dev,
                  int32_t B, int64_t n, void* stream);
+
+/* p_losses tail (DIFF:411-418): out = loss_fn(model_out, target, reduction='none') * loss_coef[b],
+ * loss_coef[b] = 1 + alphas_cumprod[t_b] / sqrt_one_minus_alphas_cumprod[t_b], clamped to <= 3 when clip_loss (clipLoss, DIFF:111).
+ * loss_type 1 = l1, 2 = l2 (DIFF:368-375).  model_out / target / out: B rows of n fp32 values; t_dev: B int32 timesteps. */
+int d3d_weighted_loss(d3d_engine* e, const float* model_out_dev, const float* target_dev, const int32_t* t_dev, float* out_dev,
+                      int32_t B, int64_t n, int32_t loss_type, int32_t clip_loss, void* stream);
+
+/* repeat_n hypotheses of forward() (DIFF:433-448): d3d_repeat_batch writes out[r * B + b, :] = x[b, :] for r < repeat_n
+ * (noisy_2d_pose.repeat(repeat_n, 1, 1, 1)); d3d_hypothesis_mean writes out[b, :] = (pred[b, :] + pred[B + b, :] + ...) / repeat_n
+ * (torch.mean(pred.view(repeat_n, b, f, p, -1), dim=0)).  n = fp32 values per batch row. */
+int d3d_repeat_batch(const float* x_dev, float* out_dev, int32_t B, int64_t n, int32_t repeat_n, void* stream);
+int d3d_hypothesis_mean(const float* pred_dev, float* out_dev, int32_t B, int64_t n, int32_t repeat_n, void* stream);
+
+/* Read-only engine facts: "graphs_cached" (captured hipGraphs held now, <= 4), "graphs_captured" (captures since creation),
+ * "streams", "device".  Unknown key: D3D_EINVAL. */
+int d3d_engine_get_info(const d3d_engine* e, const char* key, int64_t* value);
 
 /* evaluate() tail (RUN:583-590, LOSS:15-22): un-flip + average the TTA pair, multiply by scale, and reduce the masked
  * per-joint L2 error.  sums_dev[0] += sum of joint errors over frames with mask != 0, sums_dev[1] += number of such
@@ -195,16 +213,18 @@ const char* d3d_kernel_class_name(int32_t kernel_class);
  * LayerNorm-folded weights W diag(gamma) of checkpoints with large gains -- then smaller, nothing is clamped); activations
  * beyond the fp16 range, |x| > 8188, are not representable (the row and attention kernels clamp them to the range, the GEMM
  * epilogues let them become inf): results are then meaningless.
- * Every kernel that writes such planes raises a sticky per-device flag when a value left the range (no cost in a healthy run),
- * and d3d_engine_commit_weights notes non-finite weights.  d3d_engine_range_flags synchronises `stream` and returns
- *   D3D_RANGE_ACT    an activation left the range on this device since the flag was last cleared (any engine of the process)
+ * Every kernel that writes such planes raises a sticky flag in a word of device memory that belongs to the ENGINE it was launched
+ * for when a value left the range (no cost in a healthy run), and d3d_engine_commit_weights notes non-finite weights.
+ * d3d_engine_range_flags synchronises `stream` and returns
+ *   D3D_RANGE_ACT    an activation of THIS engine left the range since its flag was last cleared
  *   D3D_RANGE_WEIGHT a GEMM weight of this engine was not finite at commit
  *   D3D_RANGE_STATS  a LayerNorm folded into a GEMM met a row with |mean| > 16 standard deviations: the folded form works from
  *                    one-pass row statistics (sum, sum of squares), whose variance loses accuracy like eps (1 + mean^2 / var)
  *                    -- beyond ~25 sigma the 1e-4 parity gate is no longer guaranteed (post-norm biases that dwarf the gains)
- * clear != 0 resets the activation and statistics flags.  The flag words are per DEVICE (one per kernel translation unit), not
- * per engine: two engines, or two streams, on one device share them -- a read with clear != 0 by one consumes what the other
- * raised.  A set flag means the F16X3 result is NOT fp32-accurate for this checkpoint / input:
+ * clear != 0 resets the activation and statistics flags of this engine.  The word is per ENGINE (ABI version 120; it used to be
+ * per device): two engines on one device, or evaluate() beside a user's own engine, do not see or consume each other's flags; the
+ * two internal streams of one d3d_ddim_sample call report to the same word, which is read behind their join.  The single-op hooks
+ * below belong to no engine and report nowhere.  A set flag means the F16X3 result is NOT fp32-accurate for this checkpoint / input:
  * run the engine with D3D_PREC_FP32 (RUN:226-235 loads arbitrary checkpoints; random-init and LayerNorm-ed streams stay far
  * inside the range). */
 #define D3D_RANGE_ACT 1u

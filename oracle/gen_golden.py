@@ -481,10 +481,48 @@ def gen_trainedlike():
          x_start_est=x0s.numpy())
 
 
+def gen_round4():
+    """The two reachable constructor combinations that had no fixture: seq2frame WITHOUT time embedding (the
+    reference's own 3DHP command lines: Experiments.sh:15-17, --model ...S2F... with_time_emb False) as raw denoiser outputs and
+    as a full 7-step sampling, and the trained-like weight family on the seq2frame model.  All through the imported reference."""
+    def denoise_case(tag, cfg, seed, family, in_seed):
+        net, _, sd = build_ref(cfg, seed, family=family)
+        inp = synth_inputs(2, cfg.num_frame, seed=in_seed)
+        x2d = torch.from_numpy(inp["x2d"])
+        y_t = torch.from_numpy(inp["noise"]) * 0.7
+        out = {}
+        for t in (999, 443, 0):
+            tv = torch.full((2,), t, dtype=torch.long)
+            with torch.no_grad():
+                r = net.forward_denoise(torch.cat([x2d, y_t], dim=-1), tv)
+            o = orc.forward_denoise(sd, torch.cat([x2d, y_t], dim=-1), tv, depth=cfg.depth, seq2frame=cfg.seq2frame)
+            check(f"denoise {tag} t={t}", o, r)
+            out[f"t{t}"] = r.numpy()
+        tv = torch.tensor([905, 17], dtype=torch.long)
+        with torch.no_grad():
+            out["tmixed"] = net.forward_denoise(torch.cat([x2d, y_t], dim=-1), tv).numpy()
+        out["tmixed_t"] = tv.numpy().astype(np.int32)
+        save("denoise_" + tag, seed=np.int32(seed), input_seed=np.int32(in_seed), B=np.int32(2), y_scale=np.float32(0.7), **out)
+
+    denoise_case("s2f_notemb_T27", cfg_full(27, seq2frame=True, with_time_emb=False), 4, "uniform", 100)
+    denoise_case("trainedlike_s2f_T27", cfg_full(27, seq2frame=True), 11, "trainedlike", 500)
+    # full sampling on the 3DHP configuration: seq2frame, no time embedding, 7 DDIM steps (Experiments.sh:17)
+    cfg = cfg_full(27, seq2frame=True, with_time_emb=False)
+    net, diff, sd = build_ref(cfg, 6, sampling=7)
+    inp = synth_inputs(3, 27, seed=700)
+    x2d, noise = torch.from_numpy(inp["x2d"]), torch.from_numpy(inp["noise"][:, :1].copy())
+    with inject_noise(noise), torch.no_grad():
+        _, y0 = diff(torch.zeros_like(noise), x2d, None, False, False)
+    o = orc.ddim_sample_loop(sd, orc.diffusion_tables("cosine", 1000), x2d, noise, num_timesteps=1000, sampling_timesteps=7, depth=8,
+                             seq2frame=True)
+    check("ddim s2f notemb T=27 S=7 y0", o, y0, 5e-6)
+    save("ddim_s2f_notemb_T27_S7", seed=np.int32(6), input_seed=np.int32(700), B=np.int32(3), S=np.int32(7), y0=y0.numpy())
+
+
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
-    "dataset": gen_dataset, "trainedlike": gen_trainedlike,
+    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4,
 }
 
 if __name__ == "__main__":

@@ -209,8 +209,12 @@ def _device_isa(obj_name):
     import shutil, subprocess, tempfile
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     src = os.path.join(ROOT, "diff3dhpe_amd", "build", obj_name)
-    if not (os.path.exists(objdump) and os.path.exists(src)):
-        pytest.skip("no llvm-objdump / object file here (the library was built elsewhere)")
+    # no skip: this image has hipcc and llvm-objdump on the build container AND on the GPU box; a missing object file is built
+    assert os.path.exists(objdump), "llvm-objdump of the ROCm toolchain not found: the ISA pins cannot be checked"
+    if not os.path.exists(src):
+        from diff3dhpe_amd.build import build
+        build(verbose=False)
+    assert os.path.exists(src), src
     with tempfile.TemporaryDirectory() as tmp:
         o = os.path.join(tmp, obj_name)
         shutil.copy(src, o)
@@ -221,30 +225,45 @@ def _device_isa(obj_name):
 
 
 def test_head_kernel_instruction_stream_is_the_one_that_is_stable_on_a_shared_gpu():
-    """k_head's 3-row dot product must be compiled as: ONE weight fragment loaded, waited for (vmcnt(0)) and consumed at a time,
-    and no packed (v_pk_*) instruction between a weight load and the next one that mixes the three sums -- the stream that never
-    deviated when two processes shared a GPU (0 of ~900 traced samplings; the compiler's free schedule deviated in 1 launch
-    of 60, mechanism unidentified: experiments/NOTES.md).  A toolchain update that re-schedules the loop fails HERE, on the
-    build box, instead of silently changing results on a shared GPU."""
+    """k_head's 3-row dot product must be compiled as the stream that never deviated when two processes shared a GPU (0 of ~900
+    traced samplings; the compiler's free schedule deviated in 1 launch of 60, mechanism unidentified: experiments/NOTES.md):
+      (a) ONE weight fragment loaded, waited for (vmcnt(0)) and consumed at a time -- never several in flight behind counted waits;
+      (b) the three running sums o[0], o[1], o[2] live in separate registers and are updated by scalar v_add_f32: between a
+          fragment's load and the next there is no v_pk_add_f32 and no v_pk_* with an op_sel / op_sel_hi modifier (the deviating
+          stream kept o[0] / o[1] in one register pair, updated by v_pk_fma_f32 with op_sel).  Packed multiplies INSIDE one sum
+          (v_pk_mul_f32 / v_pk_fma_f32 on the x,z / y,w halves of one fragment, no op_sel) are part of the kept stream.
+    A toolchain update that re-schedules the loop fails HERE, on the build box, instead of silently changing results on a shared
+    GPU; the run-time cross-check is tests/test_gpu_round4.py::test_two_ranks_on_one_device_repeat."""
     import re
     isa = _device_isa("kernels_elem.o")
     for nv in (1, 2, 4):
         m = re.search(r"<_ZN3d3d6k_headILi%dEEEvNS_8HeadArgsE>:\n(.*?)(\n\n|\Z)" % nv, isa, re.S)
         assert m, f"k_head<{nv}> not found"
-        ops = []
+        ops, text = [], []
         for line in m.group(1).splitlines():
             t = line.strip().split("//")[0].strip()
+            text.append(t)
             if t.startswith("global_load_dwordx4"):
                 ops.append("L")
             elif t.startswith("s_waitcnt") and "vmcnt(" in t:
                 ops.append("W" + re.search(r"vmcnt\((\d+)\)", t).group(1))
             elif t.startswith("global_load") or t.startswith("global_store") or t.startswith("buffer_"):
                 ops.append("M")
+            else:
+                ops.append(None)
         # The last 16-byte loads of the kernel are weight fragments: all six of them at D = 512 (NV = 2, the production width, where
         # the two-process experiments ran); at the other widths the compiler sinks some LayerNorm-vector loads between them,
-        # so only the last fragment's three are identified by position.  A vmcnt(0) wait must stand between each of them and the
-        # next load (and behind the last).
+        # so only the last fragment's three are identified by position.
         idx = [i for i, o in enumerate(ops) if o == "L"][-(6 if nv == 2 else 3):]
+        dpp = next((i for i in range(idx[-1], len(text)) if "_dpp" in text[i]), len(text))   # the wave reduction behind the dot product
         for n, i in enumerate(idx):
-            end = idx[n + 1] if n + 1 < len(idx) else len(ops)
-            assert "W0" in ops[i + 1:end], (nv, ops[max(0, i - 2): end + 1])
+            end = idx[n + 1] if n + 1 < len(idx) else dpp
+            seg_ops = [o for o in ops[i + 1:end] if o]
+            assert "W0" in seg_ops, (nv, seg_ops)                                        # (a) waited for before anything else loads
+            assert not any(o == "L" for o in seg_ops)
+            if nv != 2:      # (b) is checked at the production width: at the others LayerNorm arithmetic (packed) sits between the loads
+                continue
+            seg = text[i + 1:end]
+            packed = [t for t in seg if t.startswith("v_pk_")]
+            assert not any(t.startswith("v_pk_add_f32") or "op_sel" in t for t in packed), (nv, packed)   # (b)
+            assert any(t.startswith("v_add_f32") for t in seg), (nv, seg)                # the sum's own scalar update

@@ -58,6 +58,9 @@ WORKER = textwrap.dedent("""
         local = full[lo:hi] * 2.0            # stand-in for the per-rank sampling result
         got = parallel.all_gather_pred(local, B)
         assert got.shape == full.shape and torch.equal(got, full * 2.0), (B, rank)
+        # the flip-TTA pair in ONE collective (evaluate.py): (b, 2, T, J, 3) shards
+        both = parallel.all_gather_pred(torch.stack([local, -local], dim=1), B)
+        assert both.shape == (B, 2, 5, 17, 3) and torch.equal(both[:, 0], full * 2.0) and torch.equal(both[:, 1], full * -2.0), (B, rank)
         # frame-weighted MPJPE reduction: per-rank partial sums == global sums
         err = (local - gt[lo:hi]).norm(dim=-1)
         s, c = parallel.reduce_sums(float(err.sum()), err.numel(), torch.device("cpu"))
@@ -78,3 +81,38 @@ def test_allgather_and_reduction_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=180) for p in procs]
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, e[-2000:]
+
+
+def _bench(args, env_extra, timeout=120):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, cwd=ROOT,
+                          timeout=timeout)
+
+
+def test_bench_self_launch_starts_one_rank_process_per_gpu():
+    """`python bench.py --gpus N` with no launcher: the parent (which never imports torch) starts N rank processes with the
+    torch.distributed rendezvous environment, relays rank 0's stdout alone and returns 0 (launch-check mode: no GPU needed)."""
+    import json
+    run = _bench(["--gpus", "4"], {"D3D_BENCH_LAUNCH_CHECK": "1"})
+    assert run.returncode == 0, run.stderr
+    out = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["rank"] == 0 and out[0]["world_size"] == 4 and out[0]["launcher"] == "self"
+    err = [json.loads(l) for l in run.stderr.splitlines() if l.startswith("{")]
+    assert sorted(e["rank"] for e in err) == [1, 2, 3] and all(e["local_rank"] == e["rank"] for e in err)
+    assert {e["master_port"] for e in err} == {out[0]["master_port"]} and out[0]["master_addr"] == "127.0.0.1"
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """A rank that dies must not leave the others waiting in a collective: the launcher ends its own children and returns the
+    failing rank's exit code (here rank 2 exits 7 while the others would sleep 30 s)."""
+    import time
+    t0 = time.time()
+    run = _bench(["--gpus", "3"], {"D3D_BENCH_LAUNCH_CHECK": "1", "D3D_BENCH_LAUNCH_CHECK_FAIL": "2"})
+    assert run.returncode == 7 and "rank 2 failed" in run.stderr, (run.returncode, run.stderr)
+    assert time.time() - t0 < 20
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    run = _bench(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0", "D3D_BENCH_LAUNCH_CHECK": ""})
+    assert run.returncode != 0 and "WORLD_SIZE=3" in (run.stderr + run.stdout)

@@ -80,7 +80,8 @@ def test_attention_and_blocks():
 
 DENOISE = [("small_T81", cfg_small(81)), ("full_T27", cfg_full(27)), ("full_T81", cfg_full(81)),
            ("s2f_T27", cfg_full(27, seq2frame=True)), ("notemb_T27", cfg_full(27, with_time_emb=False)),
-           ("small_s2f_T27", cfg_small(27, seq2frame=True)), ("full_T243", cfg_full(243))]
+           ("small_s2f_T27", cfg_small(27, seq2frame=True)), ("full_T243", cfg_full(243)),
+           ("s2f_notemb_T27", cfg_full(27, seq2frame=True, with_time_emb=False))]
 
 
 @pytest.mark.parametrize("tag,cfg", DENOISE, ids=[d[0] for d in DENOISE])
@@ -102,7 +103,8 @@ def test_forward_denoise(tag, cfg):
 
 DDIM = [("small_T81_S5", cfg_small(81), True, True), ("full_T81_S9", cfg_full(81), False, True),
         ("s2f_T27_S9", cfg_full(27, seq2frame=True), True, True), ("full_T27_S7_notemb", cfg_full(27, with_time_emb=False), False, True),
-        ("small_T81_S5_noclip", cfg_small(81), True, False), ("full_T243_S9", cfg_full(243), False, True)]
+        ("small_T81_S5_noclip", cfg_small(81), True, False), ("full_T243_S9", cfg_full(243), False, True),
+        ("s2f_notemb_T27_S7", cfg_full(27, seq2frame=True, with_time_emb=False), False, True)]
 
 
 @pytest.mark.parametrize("tag,cfg,traj,clip", DDIM, ids=[d[0] for d in DDIM])
@@ -207,18 +209,18 @@ def test_sequence_window_table():
         assert float((wf.double() * torch.arange(1, 35, dtype=torch.float64).reshape(17, 2)).sum()) == float(g[tag + "/flip_checksum"])
 
 
-@pytest.mark.parametrize("T", [27, 243])
-def test_trainedlike_family_denoise(T):
+@pytest.mark.parametrize("T,s2f", [(27, False), (243, False), (27, True)])
+def test_trainedlike_family_denoise(T, s2f):
     """Second weight family (heavy-tailed weights, wide LayerNorm gains, O(1) position embeddings): the restatement reproduces the
-    imported reference's outputs there too (bit-exact on the generating host)."""
+    imported reference's outputs there too (bit-exact on the generating host); seq2seq and (round 4) seq2frame."""
     from diff3dhpe_amd.synth import synth_state_dict
-    g = gold(f"denoise_trainedlike_T{T}")
-    cfg = cfg_full(T)
+    g = gold(f"denoise_trainedlike_{'s2f_' if s2f else ''}T{T}")
+    cfg = cfg_full(T, seq2frame=s2f)
     sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, int(g["seed"]), family="trainedlike").items()}
     inp = inputs(2, T, int(g["input_seed"]))
     xcat = torch.cat([inp["x2d"], inp["noise"] * float(g["y_scale"])], dim=-1)
     for key in [k for k in g.files if k.startswith("t") and k[1:].isdigit()]:
-        o = orc.forward_denoise(sd, xcat, torch.full((2,), int(key[1:]), dtype=torch.long), depth=8)
+        o = orc.forward_denoise(sd, xcat, torch.full((2,), int(key[1:]), dtype=torch.long), depth=8, seq2frame=s2f)
         assert np.abs(o.numpy() - g[key]).max() <= TOL, key
 
 
