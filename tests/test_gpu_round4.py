@@ -293,8 +293,9 @@ def test_repeat_and_hypothesis_mean_kernels():
     ref = torch.mean(p.view(3, 5, 27, 17, -1), dim=0, keepdim=True).squeeze(0)
     got = hypothesis_mean(p, 3)
     assert got.shape == ref.shape and (got - ref).abs().max().item() <= 2.4e-7     # (sum order of a 3-term fp32 mean)
-    seq = (p[:5] + p[5:10] + p[10:]) / 3.0
-    assert torch.equal(got, seq)
+    pc = p.cpu()                     # the pinned reference is the CPU path: sum in hypothesis order, then a true division
+    seq = (pc[:5] + pc[5:10] + pc[10:]) / 3.0          # (the host framework's GPU kernels multiply by 1/R instead: 1 ulp apart)
+    assert torch.equal(got.cpu(), seq)
 
 
 def test_repeat_n_with_cpu_inputs_returns_on_the_inputs_device():
