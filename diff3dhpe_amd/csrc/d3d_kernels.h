@@ -148,6 +148,13 @@ hipError_t launch_scale_cols(float* x, size_t rows, int cols, int ncols_scaled, 
 void set_linear_x3_diag(unsigned long long* dev_buf);
 void attn_x3_diag_report();   // -DD3D_ATTN_DIAG_BUILD builds only: prints the step stamps of the last staggered temporal-attention launch
 
+// ---- kernels_qkv_sattn.hip: spatial blocks, qkv GEMM (LayerNorm-folded) + 17-key attention in one kernel --------------------
+// Apair: the residual stream planes (rows up to 255 * ceil(frames / 15) + 1 are staged); W / bias / csum HEAD-MAJOR (row 192 h +
+// 64 part + d); st_in / st_np / eps as X3Fold; out_x3: attention output in the pair layout.  M = frames * J tokens.
+bool qkv_sattn_ok(int J, int D, int H, int K);
+hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, const float* bias_hm, const float* csum_hm, const float* st_in,
+                            int st_np, float eps, int w_exp, void* out_x3, int M, int K, int J, int D, int H, hipStream_t s);
+
 // ---- kernels_elem.hip -------------------------------------------------------------------------------------------
 // Row LayerNorm; optionally also writes a second LayerNorm of the first result (post-norm -> next block's norm1).
 //   y  = LN(x; g1,b1,eps1) [+ pos[(row / pos_div) % pos_mod] ] [+ tvec[(row / rows_per_batch) * tvec_stride]]

@@ -51,6 +51,10 @@ struct BlockW {
   // b'[n] = b[n] + sum_k W[n,k] beta[k], for norm1 -> qkv and norm2 -> fc1
   const uint16_t *qkv_f3 = nullptr, *fc1_f3 = nullptr;
   const float *qkv_cs = nullptr, *qkv_fb = nullptr, *fc1_cs = nullptr, *fc1_fb = nullptr;
+  // spatial blocks, fused qkv + attention kernel (kernels_qkv_sattn.hip): the folded qkv weight / csum / bias with HEAD-MAJOR rows
+  // (row 192 h + 64 part + d = original row 512 part + 64 h + d), so that one head's q, k, v are one contiguous N-tile
+  const uint16_t* qkv_f3h = nullptr;
+  const float *qkv_csh = nullptr, *qkv_fbh = nullptr;
   // exponent k of each weight's planes (2^k w; 12 unless a weight exceeds 15.99: split_weight_f16x3)
   int qkv_e = 12, proj_e = 12, fc1_e = 12, fc2_e = 12, qkv_fe = 12, fc1_fe = 12;
 };
@@ -69,6 +73,8 @@ struct d3d_engine {
   // d3d_engine_set_option: the F16X3 block flow with the post-norm inside the fc2 epilogue / with norm1, norm2 folded into
   // the consuming GEMMs (both on by default; experiments/ and the A/B tests switch them off)
   bool opt_fused_postnorm = true, opt_fold_layernorm = true;
+  // "fused_spatial": the spatial blocks' qkv GEMM and attention as ONE kernel (q / k / v never leave the chip); bit-identical
+  bool opt_fused_spatial = true;
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
@@ -277,7 +283,10 @@ Workspace carve(const d3d_engine* e, int B, void* base) {
   };
   float* b = reinterpret_cast<float*>(base);
   Workspace w{};
-  const size_t Mp = (M + 255) / 256 * 256;   // F16X3 operand planes are read in whole 256-row tiles
+  // F16X3 operand planes are read in whole 256-row tiles; the fused spatial kernel's tiles start every 255 rows (15 frames) and
+  // stage 256, so the last one may reach 255 * ceil(frames / 15) + 1 rows
+  const size_t fr = M / (size_t)e->J, qs_rows = 255 * ((fr + 14) / 15) + 1;
+  const size_t Mp = (std::max(M, qs_rows) + 255) / 256 * 256;
   size_t oX = take(Mp * D), oHN = take(Mp * D), oQKV = take(M * 3 * D), oHID = take(Mp * e->Dm);
   size_t oY0 = take(M * 3), oY1 = take(M * 3);
   size_t oTE = take((size_t)B * e->nblk * D), oTS = take((size_t)B * (D + 2 * (size_t)e->Dt));
@@ -363,6 +372,12 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s, sub);
       return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f, wexp);
     };
+    if (!temporal && e->opt_fused_spatial && bw.qkv_f3h && qkv_sattn_ok(J, D, e->H, D)) {
+      // spatial block: q, k, v of a frame group stay in LDS and feed the 17-key attention in the same kernel (kernels_qkv_sattn.hip)
+      Prof p(e, D3D_KC_QKV_SATTN, 2.0 * M * 3.0 * D * D + 4.0 * M * (double)J * D, 2.0 * MD4 + 4.0 * 3.0 * D * D, s);
+      HIP_TRY(launch_qkv_sattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, 1e-6f, bw.qkv_fe, AOx, M, D, J, D, e->H, s));
+      TRACE(k, 3, 0, AOx, MDb);
+    } else {
     {  // q, k, v planes = norm1(x) Wqkv^T + b   (LayerNorm folded; q third pre-scaled by dh^-0.5)
       X3Fold f{};
       f.st_in = w.ST1; f.st_np = np1; f.csum = bw.qkv_cs; f.eps = 1e-6f;
@@ -376,6 +391,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       else HIP_TRY(launch_attn_temporal_x3(QKVh, QKVl, AOx, B * T, J, 1, D, e->H, s));
     }
     TRACE(k, 3, 0, AOx, MDb);
+    }
     {  // x += attn Wproj^T + b, plane to plane in place; row statistics of the new x for the folded norm2
       X3Fold f{};
       f.Rp = XP; f.st_out = w.ST2;
@@ -808,9 +824,10 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     // the LDS-DMA of edge tiles never leaves the allocation (kernels_gemm_x3p.hip contract)
     const size_t D = e->D, Dm = e->Dm;
     auto pad256 = [](size_t n) { return (n + 255) / 256 * 256; };
-    const size_t per_blk = 2 * (2 * pad256(3 * D) * D + pad256(D) * D + 2 * pad256(Dm) * D + pad256(D) * Dm);
+    const size_t per_blk = 2 * (3 * pad256(3 * D) * D + pad256(D) * D + 2 * pad256(Dm) * D + pad256(D) * Dm);
     std::vector<uint16_t> host(per_blk * e->nblk, 0);
-    const size_t fold_per_blk = 2 * (3 * D + Dm);
+    const size_t fold_per_blk = 2 * (3 * D + Dm) + 2 * 3 * D;
+    const bool head_major = qkv_sattn_ok(e->J, e->D, e->H, e->D);
     std::vector<float> fold(fold_per_blk * e->nblk, 0.f);
     if (e->arena_fold) { (void)hipFree(e->arena_fold); e->arena_fold = nullptr; }
     HIP_TRY(hipMalloc(&e->arena_fold, fold.size() * sizeof(float)));
@@ -859,6 +876,25 @@ int d3d_engine_commit_weights(d3d_engine* e) {
         fo += 2 * rows;
       };
       folded(p + ".attn.qkv.weight", p + ".attn.qkv.bias", p + ".norm1", 3 * D, D, b.qkv_f3, b.qkv_cs, b.qkv_fb, b.qkv_fe);
+      if (head_major && !(k & 1)) {   // spatial block: the same folded rows once more in head-major order (same per-matrix exponent)
+        const size_t dh = D / e->H, rows = 3 * D;
+        std::vector<float> whm(rows * D);
+        const size_t f_cs = (size_t)(b.qkv_cs - e->arena_fold), f_fb = (size_t)(b.qkv_fb - e->arena_fold);
+        for (size_t r = 0; r < rows; ++r) {
+          const size_t hd_ = r / (3 * dh), part = (r % (3 * dh)) / dh, d = r % dh, src = part * D + hd_ * dh + d;
+          memcpy(&whm[r * D], &wg[src * D], D * sizeof(float));     // wg still holds W diag(gamma) of this block's qkv
+          fold[fo + r] = fold[f_cs + src];
+          fold[fo + rows + r] = fold[f_fb + src];
+        }
+        int ke = 12;
+        ke = split_weight_f16x3(whm.data(), rows, D, host.data() + o, false, &e->weights_clamped);
+        if (ke != b.qkv_fe) return fail(D3D_EHIP, "internal: head-major qkv planes got a different exponent");
+        b.qkv_f3h = e->arena16 + o;
+        o += 2 * pad256(rows) * D;
+        b.qkv_csh = e->arena_fold + fo;
+        b.qkv_fbh = e->arena_fold + fo + rows;
+        fo += 2 * rows;
+      }
       folded(p + ".mlp.fc1.weight", p + ".mlp.fc1.bias", p + ".norm2", Dm, D, b.fc1_f3, b.fc1_cs, b.fc1_fb, b.fc1_fe);
     }
     HIP_TRY(hipMemcpy(e->arena16, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -1200,6 +1236,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   if (!e) return fail(D3D_EINVAL, "null engine");
   if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;
+  else if (k == "fused_spatial") e->opt_fused_spatial = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
     e->opt_streams = (int)value;
@@ -1410,7 +1447,7 @@ int d3d_engine_profile_read(d3d_engine* e, int32_t cls, double* total_ms, int64_
 
 const char* d3d_kernel_class_name(int32_t cls) {
   static const char* names[D3D_KC_COUNT] = {"linear", "attn_spatial", "attn_temporal", "layernorm", "embed", "head", "other",
-                                            "linear_qkv", "linear_proj", "linear_fc1", "linear_fc2"};
+                                            "linear_qkv", "linear_proj", "linear_fc1", "linear_fc2", "qkv_sattn"};
   return (cls >= 0 && cls < D3D_KC_COUNT) ? names[cls] : "?";
 }
 

@@ -130,6 +130,9 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  * used by the A/B scripts under experiments/ and by tests that exercise the alternative flows):
  *   "fused_postnorm"  1 (default) / 0: F16X3 block flow with the block's post-norm inside the fc2 GEMM epilogue / as a row kernel
  *   "fold_layernorm"  1 (default) / 0: F16X3 flow with norm1 / norm2 folded into the qkv / fc1 GEMMs / as row kernels
+ *   "fused_spatial"   1 (default) / 0: F16X3 flow, spatial blocks (17 joints of a frame, D = 512, 8 heads): the qkv GEMM of a group
+ *                     of 15 frames keeps q / k / v in LDS and runs the frames' attention in the same kernel (S2S:67 + 73-83; the
+ *                     q / k / v planes never go to HBM) / qkv GEMM and attention as two kernels.  Bit-identical either way.
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
@@ -201,7 +204,10 @@ int d3d_window_gather(const float* seq_dev, int32_t n_frames, int32_t T, int32_t
 #define D3D_KC_LINEAR_PROJ 8
 #define D3D_KC_LINEAR_FC1 9
 #define D3D_KC_LINEAR_FC2 10
-#define D3D_KC_COUNT 11
+/* spatial blocks of the F16X3 flow: the LayerNorm-folded qkv GEMM and the 17-key attention as ONE kernel ("fused_spatial"); its
+ * launches are counted here only (neither under D3D_KC_LINEAR nor D3D_KC_ATTN_SPATIAL) */
+#define D3D_KC_QKV_SATTN 11
+#define D3D_KC_COUNT 12
 int d3d_engine_set_profiling(d3d_engine* e, int32_t on);
 int d3d_engine_profile_reset(d3d_engine* e);
 int d3d_engine_profile_read(d3d_engine* e, int32_t kernel_class, double* total_ms, int64_t* launches, double* flops,

@@ -313,3 +313,43 @@ def test_repeat_n_with_cpu_inputs_returns_on_the_inputs_device():
                  repeat_n=R, init_noise=inp["noise"], step_noise=step_noise)
     assert y0.shape == (B, 27, 17, 3) and not y0.is_cuda
     assert maxabs(y0, g["y0"]) <= GATE
+
+
+# ------------------------------------------------------------------------------------------------ fused spatial blocks
+@pytest.mark.parametrize("T,B,family", [(27, 2, "uniform"), (81, 3, "uniform"), (27, 5, "trainedlike"), (243, 9, "uniform"), (9, 1, "uniform")])
+def test_fused_spatial_blocks_are_bit_identical_to_the_two_kernel_flow(T, B, family):
+    """"fused_spatial" (default): the spatial blocks' LayerNorm-folded qkv GEMM and 17-key attention as one kernel (q / k / v stay in
+    LDS: kernels_qkv_sattn.hip).  Same MFMAs in the same order per element, same epilogue and attention arithmetic: the sampling is
+    bit for bit the one of the two-kernel flow -- whose parity against the reference the golden tests establish.  Frame counts
+    that are / are not multiples of the 15-frame tile, one to many tiles per workgroup, both weight families, the range guard silent."""
+    cfg = cfg_full(T)
+    _, diff = _product(cfg, 11 if family == "trainedlike" else 5, "f16x3", sampling=2, family=family)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(B, T, 77)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eng.range_flags(clear=True)
+    eng.set_option("fused_spatial", 1)
+    fused = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_spatial", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_spatial", 1)
+    assert torch.isfinite(fused).all() and eng.range_flags() == 0
+    assert torch.equal(fused, plain)
+
+
+def test_fused_spatial_blocks_with_garbage_workspace_and_large_batch():
+    """The fused kernel stages rows beyond the matrix (its 255-row tiles over a 256-row padded stream) and must not let them
+    reach a stored value: workspace filled with NaN, B = 32 at T = 243 (30 tiles per workgroup, ragged last M-tile), two streams."""
+    cfg = cfg_full(243)
+    _, diff = _product(cfg, 5, "f16x3", sampling=1)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(32, 243, 78)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eng.set_option("fused_spatial", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_spatial", 1)
+    eng._workspace(32).view(torch.float32).fill_(float("nan"))
+    fused = eng.ddim_sample(x2d, nz)
+    assert torch.equal(fused, plain)
+    for lo in (0, 13):                                           # and batch-size independent, as every kernel of the engine
+        assert torch.equal(eng.ddim_sample(x2d[lo:lo + 13].contiguous(), nz[lo:lo + 13].contiguous()), plain[lo:lo + 13])
