@@ -152,6 +152,7 @@ void attn_x3_diag_report();   // -DD3D_ATTN_DIAG_BUILD builds only: prints the s
 // Apair: the residual stream planes (rows up to 255 * ceil(frames / 15) + 1 are staged); W / bias / csum HEAD-MAJOR (row 192 h +
 // 64 part + d); st_in / st_np / eps as X3Fold; out_x3: attention output in the pair layout.  M = frames * J tokens.
 bool qkv_sattn_ok(int J, int D, int H, int K);
+void set_qkv_sattn_diag(int on);   // "qs_diag" option: in-kernel stamp report of every 50th launch on stderr
 hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, const float* bias_hm, const float* csum_hm, const float* st_in,
                             int st_np, float eps, int w_exp, void* out_x3, int M, int K, int J, int D, int H, hipStream_t s);
 

@@ -359,6 +359,11 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   }
   TRACE(0, 1, 0, XP, MDb);
   TRACE(0, 1, 1, w.ST1, (size_t)M * 8);
+  const bool fused_sp = e->opt_fused_spatial && qkv_sattn_ok(J, D, e->H, D) && e->blk[0].qkv_f3h != nullptr;
+  if (fused_sp) {   // the fused spatial kernel stages (and multiplies) up to 255 rows beyond the matrix: finite values there
+    const size_t Mp = (size_t)((reinterpret_cast<char*>(w.HN) - reinterpret_cast<char*>(w.X)) / ((size_t)D * 4));   // rows of w.X as carved
+    if (Mp > (size_t)M) HIP_TRY(hipMemsetAsync(XP + (size_t)M * 2 * D, 0, (Mp - (size_t)M) * 2 * D * sizeof(uint16_t), s));
+  }
   const int np2 = x3q_ntiles(M, D);                     // statistics partials per row written by a GEMM epilogue
   int np1 = 1;                                          // ... per row in w.ST1 (1 after a row kernel)
   // post-norm inside the fc2 epilogue (X3PostNorm) where the tile shape for it exists; else fp32 + the row kernel
@@ -372,7 +377,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s, sub);
       return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f, wexp);
     };
-    if (!temporal && e->opt_fused_spatial && bw.qkv_f3h && qkv_sattn_ok(J, D, e->H, D)) {
+    if (!temporal && fused_sp) {
       // spatial block: q, k, v of a frame group stay in LDS and feed the 17-key attention in the same kernel (kernels_qkv_sattn.hip)
       Prof p(e, D3D_KC_QKV_SATTN, 2.0 * M * 3.0 * D * D + 4.0 * M * (double)J * D, 2.0 * MD4 + 4.0 * 3.0 * D * D, s);
       HIP_TRY(launch_qkv_sattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, 1e-6f, bw.qkv_fe, AOx, M, D, J, D, e->H, s));
@@ -1233,6 +1238,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   const std::string k(key);
   if (k == "gemm_diag") { g_opt_gemm_diag = value != 0; return D3D_OK; }     // process-wide: e may be NULL
   if (k == "attn_diag") { g_opt_attn_diag = value != 0; return D3D_OK; }
+  if (k == "qs_diag") { set_qkv_sattn_diag(value != 0); return D3D_OK; }
   if (!e) return fail(D3D_EINVAL, "null engine");
   if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;

@@ -12,15 +12,20 @@
 // block is bit-identical to the unfused flow ("fused_spatial" engine option, tests/test_gpu_round4.py).
 //
 // After the k-loop the tile's 255 x 192 values (196 KB as hi / lo fp16) do not fit the LDS at once; two passes:
-//   pass 0: rows 0..135 (frames 0-7) -> q / k / v hi / lo planes of 8 frame slots (6 x 17 rows x 128 B each, the swizzles of
-//           kernels_attn_x3.hip) -> barrier -> wave w runs frame w (scores, softmax, (P - I) V as in k_attn_temporal_x3p) and
-//           stores its 17 x 64 outputs as whole 128-byte lines of the pair layout
-//   pass 1: rows 136..254 (frames 8-14) likewise, 7 slots; the next tile's first k-tile is requested in front of its attention step
+//   pass 0: frames 0-3 and 8-11 (rows 0..67 of wave-row 0, 136..203 of wave-row 1: BOTH wave rows write half their accumulators)
+//           -> q / k / v hi / lo planes of 8 frame slots (6 x 17 rows x 128 B each, the swizzles of kernels_attn_x3.hip) -> barrier
+//           -> wave w runs one frame (scores, softmax, (P - I) V as in k_attn_temporal_x3p) and stores its 17 x 64 outputs as
+//           whole 128-byte lines of the pair layout
+//   pass 1: frames 4-7 and 12-14 likewise, 7 slots; the next tile's first k-tile is requested in front of its attention step
+// (first version: pass 0 = rows 0..135, pass 1 = the rest -- each pass written by ONE wave row while the other waited: 3.8 + 4.4 us
+// of a 40.5 us tile, in-kernel stamps; the epilogue steps are VALU-issue-bound with two waves per SIMD)
 // LDS map (160 KiB): [0, 56 K) stage 0 | [56 K, 158 K) stage 1, then the frame slots (+ the raw row-statistics block during the
 // k-loop) | 1920 zeroed bytes that the pad-row reads of the last slot's V plane run into.
 #include "d3d_kernels.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <vector>
 
 namespace d3d {
 namespace {
@@ -38,7 +43,6 @@ constexpr int QS_BM = 256, QS_BN = 192, QS_TM = 8, QS_NJ = 3;
 constexpr int QS_AREG = QS_BM * 128, QS_STAGE = (QS_BM + QS_BN) * 128;   // 57344
 constexpr int QS_AIT = 4, QS_BIT = 3;                                    // 1-KiB DMA pieces per wave per k-tile
 constexpr int QS_J = 17, QS_FPT = 15, QS_ROWS = QS_J * QS_FPT;           // 255 token rows per tile
-constexpr int QS_P0_ROWS = 8 * QS_J;                                     // 136: rows of pass 0 (frames 0-7)
 constexpr int QS_PLANE = QS_J * 128, QS_SLOT = 6 * QS_PLANE;             // 2176, 13056
 constexpr int QS_QKV = QS_STAGE;                                         // frame slots start behind stage 0
 constexpr int QS_PAD = QS_QKV + 8 * QS_SLOT;                             // 161792: zeroed tail (15 rows x 128 B)
@@ -106,6 +110,8 @@ struct QsArgs {
   _Float16* out;           // attention output, pair layout [M][2 D] of 8 o
   int M, K, F, mtiles, D;  // tokens, GEMM depth, frames (M / 17), M-tiles (ceil(F / 15)), model width (8 heads x 64)
   unsigned* range;         // the engine's range-guard word
+  unsigned long long* diag;   // diagnostic launches only ("qs_diag"): per workgroup 8 words -- cycles of wave 0 in the k-loop, the
+                              // statistics step, write 0, attention 0, write 1 (+ prefetch), attention 1, tiles, 100 MHz ticks
 };
 
 #define QS_GLDS(SRC, DSTOFF)                                                                                            \
@@ -156,22 +162,24 @@ __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Flo
     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sacc, 0, 0, 0);
     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sacc, 0, 0, 0);
   }
+  // keys of accumulator register q in lane half h: (q & 3) + 8 (q >> 2) + 4 h.  With 17 keys, registers 9..15 hold pad keys in both
+  // halves and register 8 (key 16 / 20) a real one in half 0 only: their numerators are exact zeros -- no exponentials, no sums
   float m = -INFINITY;
+  if (h != 0) sacc[8] = -INFINITY;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int key = (q & 3) + 8 * (q >> 2) + 4 * h;
-    if (key >= T) sacc[q] = -INFINITY;
-    m = fmaxf(m, sacc[q]);
-  }
+  for (int q = 0; q < 9; ++q) m = fmaxf(m, sacc[q]);
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   constexpr float C_EXP = 1.4426950408889634f / 64.0f;
   const float mb = m * C_EXP;
   float l = 0.f;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const float e = __builtin_amdgcn_exp2f(fmaf(sacc[q], C_EXP, -mb));
+    float e = 0.0f;
+    if (q < 9) {
+      e = __builtin_amdgcn_exp2f(fmaf(sacc[q], C_EXP, -mb));
+      l += e;
+    }
     sacc[q] = e;
-    l += e;
   }
   l += __shfl_xor(l, 32, 64);
   f32x16 oacc[2];
@@ -181,10 +189,18 @@ __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Flo
   for (int s2 = 0; s2 < 2; ++s2) {
     h8 eh, el;
     {
-      float e8[8];
+      if (s2 == 0) {
+        float e8[8];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) e8[jj] = sacc[8 * s2 + jj];
-      split8_e(e8, eh, el);
+        for (int jj = 0; jj < 8; ++jj) e8[jj] = sacc[jj];
+        split8_e(e8, eh, el);
+      } else {   // registers 9..15 are exact zeros: only the first pair carries a numerator
+        unsigned a, b;
+        split_pair_s(sacc[8], 0.0f, 1024.0f, a, b);
+        u32x4 hv = {a, 0u, 0u, 0u}, lv = {b, 0u, 0u, 0u};
+        eh = __builtin_bit_cast(h8, hv);
+        el = __builtin_bit_cast(h8, lv);
+      }
     }
     const int k0 = 16 * s2 + 4 * h;
     const int gi = lane & 15, tq_ = gi >> 2, tp_ = gi & 3;
@@ -220,18 +236,29 @@ __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Flo
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int vo = vswz(tqc, dt * 4 + g4) + 8 * h;
-      const h4 vqh = *reinterpret_cast<const h4*>(sVh + vo);
-      const h4 vql = *reinterpret_cast<const h4*>(sVl + vo);
-      h4 oh, ol;
+      // -v_query = -(hi + lo) / 8 by two v_fma_mix_f32 on the packed fp16 halves (exact: the pair sums to <= 22 bits), o = O^T inv - v_q
+      // in one fma (the rounding every form of this kernel makes), then hi = fp16(8 o), lo = fp16(8 o - hi) by v_fma_mixlo / mixhi:
+      // 6 VALU instructions per value where convert / add / scale / fma / clamp / convert / convert back / subtract / convert took 12
+      // (same bits whenever |8 o| is inside the fp16 range; beyond it the range guard fires either way)
+      const uint2 vqh = *reinterpret_cast<const uint2*>(sVh + vo);
+      const uint2 vql = *reinterpret_cast<const uint2*>(sVl + vo);
+      float o4[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float vq = ((float)vqh[e] + (float)vql[e]) * 0.125f;
-        const float o = __builtin_fmaf(oacc[dt][4 * g4 + e], inv, -vq);
-        amax = fmaxf(amax, fabsf(o));
-        const float sc = __builtin_amdgcn_fmed3f(o * 8.0f, -65504.0f, 65504.0f);
-        oh[e] = (_Float16)sc;
-        ol[e] = (_Float16)(sc - (float)oh[e]);
+      for (int pr = 0; pr < 2; ++pr) {
+        const unsigned ph_ = pr ? vqh.y : vqh.x, pl_ = pr ? vql.y : vql.x;
+        float n0, n1;
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(n0) : "v"(pl_), "v"(-0.125f));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(n0) : "v"(ph_), "v"(-0.125f), "v"(n0));
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(n1) : "v"(pl_), "v"(-0.125f));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(n1) : "v"(ph_), "v"(-0.125f), "v"(n1));
+        o4[2 * pr] = __builtin_fmaf(oacc[dt][4 * g4 + 2 * pr], inv, n0);
+        o4[2 * pr + 1] = __builtin_fmaf(oacc[dt][4 * g4 + 2 * pr + 1], inv, n1);
       }
+      unsigned h0, l0, h1, l1;
+      split_pair(o4[0], o4[1], 8.0f, h0, l0);
+      split_pair(o4[2], o4[3], 8.0f, h1, l1);
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
+      const h4 oh = __builtin_bit_cast(h4, make_uint2(h0, h1)), ol = __builtin_bit_cast(h4, make_uint2(l0, l1));
       patch_wr(patch, r, h, g4, oh, ol);
     }
     asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
@@ -290,7 +317,16 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
     for (int it = 0; it < QS_BIT; ++it) QS_GLDS(sgpr_ptr(ubB + it * it_stride) + lofs, QS_AREG + wave * 1024 + lane * 16 + it * 8192);
   }
   int tid_o = (int)threadIdx.x;
+  unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long dg_r0 = a.diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define QS_STAMP(I)                                                         \
+  if (a.diag) {                                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();           \
+    dg[I] += now_ - dg_t;                                                   \
+    dg_t = now_;                                                            \
+  }
   for (int item = 0; item < nitems; ++item) {
+    unsigned long long dg_t = a.diag ? __builtin_amdgcn_s_memtime() : 0ull;
     asm volatile("" : "+v"(tid_o));   // per-lane offsets are re-derived in every tile instead of being hoisted (and spilled)
     const int tid = tid_o;
     const int lane = tid & 63;
@@ -448,6 +484,7 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
 #undef QS_PHASE
 #undef QS_PIECE
     __builtin_amdgcn_s_setprio(0);
+    QS_STAMP(0);
 
     // ---- row statistics -> (rstd * out_scale, -mean rstd) per tile row, in stage 0 (free since k-tile nk - 2)
     float2* const srow = reinterpret_cast<float2*>(lds);
@@ -471,6 +508,7 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       srow[tid] = make_float2(rstd * a.out_scale, -mean * rstd);
     }
     __syncthreads();   // statistics visible; every wave is out of the k-loop: stage 1 and the LDS behind it become the frame slots
+    QS_STAMP(1);
 
     float2 st[QS_TM];
 #pragma unroll
@@ -482,37 +520,35 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       cs4[j] = *reinterpret_cast<const float4*>(a.csum + n);
       b4[j] = *reinterpret_cast<const float4*>(a.bias + n);
     }
-    float amax = 0.0f;
-    // q / k / v of the rows [r_lo, r_hi) of this tile -> frame slots (LayerNorm fold and hi / lo split of x3q_epilogue8)
+    float amaxj[QS_NJ] = {0.0f, 0.0f, 0.0f};   // max |value| per column group (its plane scale is wave-uniform: applied at the end)
+    // q / k / v of this pass's frames -> frame slots (LayerNorm fold and hi / lo split of x3q_epilogue8).  Frame fr of the tile:
+    // pass (fr >> 2) & 1, slot (fr & 3) + 4 (fr >> 3).  Rows beyond the matrix hold finite values (the engine zeroes the pad rows of
+    // the stream), so nothing non-finite can reach a slot -- the pad-row reads of a neighbour's V plane may see them.
     auto write_pass = [&](int pass) {
 #pragma unroll
       for (int i = 0; i < QS_TM; ++i) {
-        if (pass == 0 ? (wm == 1 && i > 0) : (wm == 0)) continue;         // (wave-uniform: rows 0-135 / 136-254)
+        if (pass == 0 ? (i > 4) : (i < 4 && !(wm == 1 && i == 0))) continue;   // (wave-uniform: m-tiles without rows of this pass)
         const int R = wm * 128 + 16 * i + r16;
-        const bool mine = pass == 0 ? (R < QS_P0_ROWS) : (R >= QS_P0_ROWS && R < QS_ROWS);
-        if (!mine) continue;
         const int fr = R / QS_J, jr = R - fr * QS_J;
-        unsigned char* const slot = lds + QS_QKV + (fr - 8 * pass) * QS_SLOT;
-        const bool row_ok = m0 + R < a.M;                                  // rows beyond the matrix: zeros (their frames are never stored,
-#pragma unroll                                                             // but pad-row reads of a neighbour's V plane may see them)
+        if (((fr >> 2) & 1) != pass || fr >= QS_FPT) continue;
+        unsigned char* const slot = lds + QS_QKV + ((fr & 3) + 4 * (fr >> 3)) * QS_SLOT + jr * 128;
+        const int kk = (jr >> 1) & 7, vk = vkey(jr);
+#pragma unroll
         for (int j = 0; j < QS_NJ; ++j) {
-          const int c = wn * 48 + 16 * j + 4 * q;                          // column inside the head's 192: part = q / k / v, d
-          const int part = c >> 6, d = c & 63;
+          const int c0 = wn * 48 + 16 * j;                                 // (wave-uniform) first column of this accumulator tile
+          const int part = c0 >> 6;                                        // q / k / v: the same for the tile's 16 columns
+          const int d = (c0 & 63) + 4 * q;
           const float osc = part == 0 ? 1.0f : 8.0f;
           float v[4];
           v[0] = fmaf(st[i].x, acc[i][j][0], fmaf(st[i].y, cs4[j].x, b4[j].x));
           v[1] = fmaf(st[i].x, acc[i][j][1], fmaf(st[i].y, cs4[j].y, b4[j].y));
           v[2] = fmaf(st[i].x, acc[i][j][2], fmaf(st[i].y, cs4[j].z, b4[j].z));
           v[3] = fmaf(st[i].x, acc[i][j][3], fmaf(st[i].y, cs4[j].w, b4[j].w));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (!row_ok) v[e] = 0.0f;
-            amax = fmaxf(amax, fabsf(v[e]) * osc);
-          }
+          amaxj[j] = fmaxf(fmaxf(amaxj[j], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
           unsigned h0, l0, h1, l1;
           split_pair(v[0], v[1], osc, h0, l0);
           split_pair(v[2], v[3], osc, h1, l1);
-          const int off = (part == 2 ? vswz(jr, d >> 3) : kswz(jr, d >> 3)) + ((d & 4) << 1);
+          const int off = ((((d >> 3) ^ (part == 2 ? vk : kk)) << 4)) + ((d & 4) << 1);
           unsigned char* const ph = slot + part * 2 * QS_PLANE + off;
           u32x2_alias hv, lv;
           hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
@@ -522,17 +558,24 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       }
     };
     auto attend = [&](int pass) {
-      const int fr = 8 * pass + wave;                                     // frame of the tile this wave takes
+      const int fr = (wave & 3) + 4 * pass + 8 * (wave >> 2);             // frame of the tile this wave takes: slot = wave
       const long long gf = (long long)mt * QS_FPT + fr;
       if (fr < QS_FPT && gf < a.F)
         qs_attention(lds + QS_QKV + wave * QS_SLOT, lane, a.out + ((size_t)gf * QS_J) * 2 * a.D + hd * 128, a.D, a.range);
     };
     write_pass(0);
     __syncthreads();
+    QS_STAMP(2);
     attend(0);
     __syncthreads();
+    QS_STAMP(3);
     write_pass(1);
-    if (amax > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
+    {
+      float amax = 0.0f;
+#pragma unroll
+      for (int j = 0; j < QS_NJ; ++j) amax = fmaxf(amax, amaxj[j] * (((wn * 48 + 16 * j) >> 6) == 0 ? 1.0f : 8.0f));
+      if (amax > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
+    }
     if (has_next) {   // the next tile's first k-tile into stage 0, under the second attention step
       const char* ubAn = reinterpret_cast<const char*>(a.Ap) + (size_t)(mtn * QS_ROWS + wave * 8) * K2 * 2;
       const char* ubBn = reinterpret_cast<const char*>(a.Wp) + (size_t)(hdn * QS_BN + wave * 8) * K2 * 2;
@@ -542,13 +585,24 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       for (int it = 0; it < QS_BIT; ++it) QS_GLDS(sgpr_ptr(ubBn + it * it_stride) + lofs_, dstB + it * 8192);
     }
     __syncthreads();
+    QS_STAMP(4);
     attend(1);
     mt = mtn; hd = hdn;
     __syncthreads();   // the slots are read before the next tile's statistics block and second k-tile are staged over them
+    QS_STAMP(5);
+  }
+#undef QS_STAMP
+  if (a.diag && threadIdx.x == 0) {
+    for (int i = 0; i < 6; ++i) a.diag[8 * b + i] = dg[i];
+    a.diag[8 * b + 6] = (unsigned long long)nitems;
+    a.diag[8 * b + 7] = __builtin_amdgcn_s_memrealtime() - dg_r0;
   }
 }
 
 }  // namespace
+
+static std::atomic<int> g_qs_diag{0};
+void set_qkv_sattn_diag(int on) { g_qs_diag = on; }
 
 bool qkv_sattn_ok(int J, int D, int H, int K) { return J == QS_J && H == 8 && D == 512 && K % 64 == 0 && K >= 128; }
 
@@ -569,6 +623,31 @@ hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, cons
   if (n_cu <= 0) return hipErrorUnknown;
   const int tiles = a.mtiles * 8;
   const int grid = tiles < n_cu ? tiles : n_cu;
+  if (g_qs_diag.load() > 0) {   // "qs_diag" option: every 50th launch with stamps, summarised on stderr (synchronises the stream)
+    static std::atomic<int> count{0};
+    if (count.fetch_add(1) % 50 == 10) {
+      unsigned long long* buf = nullptr;
+      if (hipMalloc(&buf, (size_t)grid * 64) != hipSuccess) return hipErrorOutOfMemory;
+      (void)hipMemsetAsync(buf, 0, (size_t)grid * 64, s);
+      a.diag = buf;
+      hipLaunchKernelGGL(k_qkv_sattn, dim3(grid), dim3(512), QS_LDS, s, a);
+      (void)hipStreamSynchronize(s);
+      std::vector<unsigned long long> h((size_t)grid * 8);
+      (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(buf);
+      double sum[6] = {0}, tiles_n = 0, cyc = 0, ticks = 0;
+      for (int g = 0; g < grid; ++g) {
+        for (int i = 0; i < 6; ++i) { sum[i] += (double)h[8 * g + i]; cyc += (double)h[8 * g + i]; }
+        tiles_n += (double)h[8 * g + 6]; ticks += (double)h[8 * g + 7];
+      }
+      const double ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;   // cycles per ns (100 MHz ticks = 10 ns)
+      fprintf(stderr, "[qs diag] M=%d tiles %d on %d workgroups, clock %.2f GHz; per tile (us, wave 0): k-loop %.2f  stats %.2f  write0 %.2f  "
+              "attn0 %.2f  write1+prefetch %.2f  attn1 %.2f  | total %.2f\n", M, tiles, grid, ghz,
+              sum[0] / tiles_n / ghz / 1e3, sum[1] / tiles_n / ghz / 1e3, sum[2] / tiles_n / ghz / 1e3, sum[3] / tiles_n / ghz / 1e3,
+              sum[4] / tiles_n / ghz / 1e3, sum[5] / tiles_n / ghz / 1e3, cyc / tiles_n / ghz / 1e3);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(k_qkv_sattn, dim3(grid), dim3(512), QS_LDS, s, a);
   return hipGetLastError();
 }

@@ -138,7 +138,8 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
  *                     +2.9 % at T=243 / B=64, neutral at T=81 / T=27).  Per-kernel profiling and the trace force one stream.
  * Process-wide diagnostics (e may be NULL): "gemm_diag", "attn_diag" 0 / 1: the op hooks print in-kernel stamp reports to stderr
- * (attn_diag needs a -DD3D_ATTN_DIAG_BUILD library).  Unknown key: D3D_EINVAL. */
+ * (attn_diag needs a -DD3D_ATTN_DIAG_BUILD library); "qs_diag" 0 / 1: every 50th launch of the fused spatial kernel runs with
+ * per-step stamps and prints their summary to stderr (that launch synchronises its stream).  Unknown key: D3D_EINVAL. */
 int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value);
 
 /* q_sample (DIFF:360-366, extract DIFF:21-24): out = sqrt_ac[t_b] * x_start + sqrt(1-ac)[t_b] * noise, per row b.
