@@ -52,7 +52,8 @@ struct BlockW {
   const uint16_t *qkv_f3 = nullptr, *fc1_f3 = nullptr;
   const float *qkv_cs = nullptr, *qkv_fb = nullptr, *fc1_cs = nullptr, *fc1_fb = nullptr;
   // spatial blocks, fused qkv + attention kernel (kernels_qkv_sattn.hip): the folded qkv weight / csum / bias with HEAD-MAJOR rows
-  // (row 192 h + 64 part + d = original row 512 part + 64 h + d), so that one head's q, k, v are one contiguous N-tile
+  // (row 192 h + 48 wn + 16 part + x = original row 512 part + 64 h + 16 wn + x), so that one head's q, k, v are one contiguous
+  // N-tile and accumulator column tile j of every wave is part j
   const uint16_t* qkv_f3h = nullptr;
   const float *qkv_csh = nullptr, *qkv_fbh = nullptr;
   // exponent k of each weight's planes (2^k w; 12 unless a weight exceeds 15.99: split_weight_f16x3)
@@ -886,7 +887,9 @@ int d3d_engine_commit_weights(d3d_engine* e) {
         std::vector<float> whm(rows * D);
         const size_t f_cs = (size_t)(b.qkv_cs - e->arena_fold), f_fb = (size_t)(b.qkv_fb - e->arena_fold);
         for (size_t r = 0; r < rows; ++r) {
-          const size_t hd_ = r / (3 * dh), part = (r % (3 * dh)) / dh, d = r % dh, src = part * D + hd_ * dh + d;
+          // tile order (kernels_qkv_sattn.hip): row 192 h + 48 wn + 16 part + x <- original row 512 part + 64 h + 16 wn + x
+          const size_t hd_ = r / (3 * dh), c = r % (3 * dh), wn_ = c / 48, part = (c % 48) / 16, x = c % 16;
+          const size_t src = part * D + hd_ * dh + 16 * wn_ + x;
           memcpy(&whm[r * D], &wg[src * D], D * sizeof(float));     // wg still holds W diag(gamma) of this block's qkv
           fold[fo + r] = fold[f_cs + src];
           fold[fo + rows + r] = fold[f_fb + src];

@@ -20,7 +20,7 @@
 // (first version: pass 0 = rows 0..135, pass 1 = the rest -- each pass written by ONE wave row while the other waited: 3.8 + 4.4 us
 // of a 40.5 us tile, in-kernel stamps; the epilogue steps are VALU-issue-bound with two waves per SIMD)
 // LDS map (160 KiB): [0, 56 K) stage 0 | [56 K, 158 K) stage 1, then the frame slots (+ the raw row-statistics block during the
-// k-loop) | 1920 zeroed bytes that the pad-row reads of the last slot's V plane run into.
+// k-loop) | 2 KiB of per-row LayerNorm statistics.
 #include "d3d_kernels.h"
 
 #include <math.h>
@@ -45,11 +45,15 @@ constexpr int QS_AIT = 4, QS_BIT = 3;                                    // 1-Ki
 constexpr int QS_J = 17, QS_FPT = 15, QS_ROWS = QS_J * QS_FPT;           // 255 token rows per tile
 constexpr int QS_PLANE = QS_J * 128, QS_SLOT = 6 * QS_PLANE;             // 2176, 13056
 constexpr int QS_QKV = QS_STAGE;                                         // frame slots start behind stage 0
-constexpr int QS_PAD = QS_QKV + 8 * QS_SLOT;                             // 161792: zeroed tail (15 rows x 128 B)
+constexpr int QS_STX = QS_QKV + 8 * QS_SLOT;                             // 161792: (rstd', -mean rstd) of the tile's 256 rows, 2 KiB
 constexpr int QS_RAW = 2 * QS_STAGE;                                     // raw statistics partials while the k-loop runs (16 KiB)
 constexpr int QS_RAW_MAX = 16384;
-constexpr int QS_LDS = QS_PAD + (32 - QS_J) * 128;                       // 163712
-static_assert(QS_LDS <= 160 * 1024 && QS_RAW + QS_RAW_MAX <= QS_PAD, "LDS map");
+constexpr int QS_LDS = QS_STX + QS_BM * 8;                               // 163840
+static_assert(QS_LDS <= 160 * 1024 && QS_RAW + QS_RAW_MAX <= QS_STX, "LDS map");
+// planes of a slot: V hi, V lo, K hi, K lo, Q hi, Q lo.  The fragment reads of the 15 pad rows of a plane run on into what follows
+// it: for V that must be FINITE (0 x NaN in the second product) -- V hi runs into V lo, V lo into K hi, both written in the same pass;
+// pad keys of K are overwritten with -inf scores and pad queries of Q are never stored: any bits will do there.
+constexpr int QS_PV = 0, QS_PK = 2 * QS_PLANE, QS_PQ = 4 * QS_PLANE;
 
 // swizzles of kernels_attn_x3.hip (K / Q rows: fragment reads of 16 consecutive rows at one logical chunk; V rows: transpose reads)
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -101,7 +105,8 @@ __device__ __forceinline__ u32x4 patch_rd(const unsigned char* patch, int row, i
 
 struct QsArgs {
   const _Float16* Ap;      // residual stream, pair layout [>= 255 mtiles + 1 rows][2 K] of 8 x
-  const _Float16* Wp;      // folded qkv weight W diag(gamma), pair layout, HEAD-MAJOR rows (192 h + 64 part + d), 2^k w
+  const _Float16* Wp;      // folded qkv weight W diag(gamma), pair layout, 2^k w, rows in TILE order: row 192 h + 48 wn + 16 part + x
+                           // = original row 512 part + 64 h + 16 wn + x (wave wn of a tile holds q, k, v columns 16 wn .. + 15 of head h)
   const float* bias;       // b + W beta, head-major
   const float* csum;       // sum_k W[n, k] gamma[k], head-major
   const float* st_in;      // (sum, sum of squares) partials of the rows: [rows][st_np][2]
@@ -135,13 +140,13 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n), n wave
 // are in registers) as whole 128-byte lines.
 __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Float16* out_row0, int D, unsigned* rw) {
   constexpr int T = QS_J;
-  unsigned char* const sQh = slot;
-  unsigned char* const sQl = slot + QS_PLANE;
-  unsigned char* const sKh = slot + 2 * QS_PLANE;
-  unsigned char* const sKl = slot + 3 * QS_PLANE;
-  unsigned char* const sVh = slot + 4 * QS_PLANE;
-  unsigned char* const sVl = slot + 5 * QS_PLANE;
-  unsigned char* const patch = slot;              // 4 KiB over the Q planes (4352 B)
+  unsigned char* const sVh = slot + QS_PV;
+  unsigned char* const sVl = slot + QS_PV + QS_PLANE;
+  unsigned char* const sKh = slot + QS_PK;
+  unsigned char* const sKl = slot + QS_PK + QS_PLANE;
+  unsigned char* const sQh = slot + QS_PQ;
+  unsigned char* const sQl = slot + QS_PQ + QS_PLANE;
+  unsigned char* const patch = slot + QS_PQ;      // 4 KiB over the Q planes (4352 B)
   const int r = lane & 31, h = lane >> 5;
   h8 qh[4], ql[4];
 #pragma unroll
@@ -296,7 +301,6 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       hd = o2 / mrem;
     }
   };
-  for (int idx = (int)threadIdx.x; idx < (QS_LDS - QS_PAD) / 16; idx += 512) reinterpret_cast<uint4*>(lds + QS_PAD)[idx] = make_uint4(0, 0, 0, 0);
 
   const int K = a.K;
   const size_t K2 = 2 * (size_t)K;
@@ -362,11 +366,21 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
     unsigned lofs_ = (unsigned)(lr_ * (int)K2 + csrc_ * 8) * 2u;
     const size_t it_stride = (size_t)64 * K2 * 2;
     const int dstA = wave * 1024 + lane * 16, dstB = QS_AREG + wave * 1024 + lane * 16;
+    // next tile's operand bases: its first k-tile is issued by the last two phases of this tile's k-loop (stage 0 is free then)
+    const char* ubAn = reinterpret_cast<const char*>(a.Ap) + (size_t)(mtn * QS_ROWS + wave * 8) * K2 * 2;
+    const char* ubBn = reinterpret_cast<const char*>(a.Wp) + (size_t)(hdn * QS_BN + wave * 8) * K2 * 2;
+    // piece IT (A: 0..3, W: 4..6) of k-tile KTT of this tile, or (KTT == nk) of k-tile 0 of the next one
 #define QS_PIECE(KTT, IT)                                                                                               \
     do {                                                                                                                \
+      const bool nxt_ = (KTT) >= nk;                                                                                    \
       const int st_ = ((KTT) & 1) * QS_STAGE;                                                                           \
-      if ((IT) < QS_AIT) QS_GLDS(sgpr_ptr(ubA + ((size_t)(KTT) * 128 + (IT) * it_stride)) + lofs_, st_ + dstA + (IT) * 8192); \
-      else QS_GLDS(sgpr_ptr(ubB + ((size_t)(KTT) * 128 + ((IT) - QS_AIT) * it_stride)) + lofs_, st_ + dstB + ((IT) - QS_AIT) * 8192); \
+      if ((IT) < QS_AIT) {                                                                                              \
+        const char* b_ = nxt_ ? ubAn + (IT) * it_stride : ubA + ((size_t)(KTT) * 128 + (IT) * it_stride);               \
+        QS_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstA + (IT) * 8192);                                                        \
+      } else {                                                                                                          \
+        const char* b_ = nxt_ ? ubBn + ((IT) - QS_AIT) * it_stride : ubB + ((size_t)(KTT) * 128 + ((IT) - QS_AIT) * it_stride); \
+        QS_GLDS(sgpr_ptr(b_) + lofs_, st_ + dstB + ((IT) - QS_AIT) * 8192);                                             \
+      }                                                                                                                 \
     } while (0)
 
     f32x4 acc[QS_TM][QS_NJ];
@@ -468,26 +482,27 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
     } while (0)
 
     QS_PHASE(0, 0, true, true, false, false);
-    QS_PHASE(0, 1, false, false, nk > 2, nk > 1);
+    QS_PHASE(0, 1, false, false, nk > 2 || has_next, nk > 1);
     int kt = 1;
     for (; kt + 2 < nk; ++kt) {
       QS_PHASE(kt, 0, true, false, false, false);
       QS_PHASE(kt, 1, false, false, true, true);
     }
-    if (nk > 2) {
+    if (nk > 2) {   // k-tile nk - 2: A(nk - 1) of this tile, then W(0) of the next tile
       QS_PHASE(kt, 0, true, false, false, false);
-      QS_PHASE(kt, 1, false, false, false, true);
+      QS_PHASE(kt, 1, false, false, has_next, true);
       ++kt;
     }
-    QS_PHASE(kt, 0, false, false, false, false);
+    // k-tile nk - 1: A(0) of the next tile
+    QS_PHASE(kt, 0, has_next, false, false, false);
     QS_PHASE(kt, 1, false, false, false, false);
 #undef QS_PHASE
 #undef QS_PIECE
     __builtin_amdgcn_s_setprio(0);
     QS_STAMP(0);
 
-    // ---- row statistics -> (rstd * out_scale, -mean rstd) per tile row, in stage 0 (free since k-tile nk - 2)
-    float2* const srow = reinterpret_cast<float2*>(lds);
+    // ---- row statistics -> (rstd * out_scale, -mean rstd) per tile row (their own 2 KiB: stage 0 already receives the next tile)
+    float2* const srow = reinterpret_cast<float2*>(lds + QS_STX);
     if (tid < QS_BM) {
       const int row = m0 + tid;
       float sm = 0.f, sq = 0.f;
@@ -520,36 +535,40 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       cs4[j] = *reinterpret_cast<const float4*>(a.csum + n);
       b4[j] = *reinterpret_cast<const float4*>(a.bias + n);
     }
-    float amaxj[QS_NJ] = {0.0f, 0.0f, 0.0f};   // max |value| per column group (its plane scale is wave-uniform: applied at the end)
+    float amaxj[QS_NJ] = {0.0f, 0.0f, 0.0f};   // max |value| per accumulator column tile j = q / k / v (plane scale applied at the end)
     // q / k / v of this pass's frames -> frame slots (LayerNorm fold and hi / lo split of x3q_epilogue8).  Frame fr of the tile:
-    // pass (fr >> 2) & 1, slot (fr & 3) + 4 (fr >> 3).  Rows beyond the matrix hold finite values (the engine zeroes the pad rows of
-    // the stream), so nothing non-finite can reach a slot -- the pad-row reads of a neighbour's V plane may see them.
+    // pass (fr >> 2) & 1, slot (fr & 3) + 4 (fr >> 3).  Column tile j of a wave IS part j (the weight rows are ordered that way at
+    // commit): q columns 16 wn .. + 15 of the head in j = 0, the same k columns in j = 1, v in j = 2 -- plane and scale are
+    // compile-time per j, and one address serves q and k (same row swizzle), one v.  Rows beyond the matrix hold finite values
+    // (the engine zeroes the pad rows of the stream): nothing non-finite can reach a slot.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int chunk = 2 * wn + (q >> 1), half8 = (q & 1) << 3;            // this lane's 8 bytes: 16-byte chunk d / 8, half (d & 4)
     auto write_pass = [&](int pass) {
 #pragma unroll
       for (int i = 0; i < QS_TM; ++i) {
         if (pass == 0 ? (i > 4) : (i < 4 && !(wm == 1 && i == 0))) continue;   // (wave-uniform: m-tiles without rows of this pass)
         const int R = wm * 128 + 16 * i + r16;
-        const int fr = R / QS_J, jr = R - fr * QS_J;
+        const int fr = (R * 241) >> 12, jr = R - fr * QS_J;               // R / 17 for R < 256
         if (((fr >> 2) & 1) != pass || fr >= QS_FPT) continue;
-        unsigned char* const slot = lds + QS_QKV + ((fr & 3) + 4 * (fr >> 3)) * QS_SLOT + jr * 128;
-        const int kk = (jr >> 1) & 7, vk = vkey(jr);
+        unsigned char* const row = lds + QS_QKV + ((fr & 3) + 4 * (fr >> 3)) * QS_SLOT + jr * 128 + half8;
+        unsigned char* const pkq = row + ((chunk ^ ((jr >> 1) & 7)) << 4);
+        unsigned char* const pv = row + ((chunk ^ vkey(jr)) << 4);
+        const f2 sx = (f2)(st[i].x), sy = (f2)(st[i].y);
 #pragma unroll
         for (int j = 0; j < QS_NJ; ++j) {
-          const int c0 = wn * 48 + 16 * j;                                 // (wave-uniform) first column of this accumulator tile
-          const int part = c0 >> 6;                                        // q / k / v: the same for the tile's 16 columns
-          const int d = (c0 & 63) + 4 * q;
-          const float osc = part == 0 ? 1.0f : 8.0f;
-          float v[4];
-          v[0] = fmaf(st[i].x, acc[i][j][0], fmaf(st[i].y, cs4[j].x, b4[j].x));
-          v[1] = fmaf(st[i].x, acc[i][j][1], fmaf(st[i].y, cs4[j].y, b4[j].y));
-          v[2] = fmaf(st[i].x, acc[i][j][2], fmaf(st[i].y, cs4[j].z, b4[j].z));
-          v[3] = fmaf(st[i].x, acc[i][j][3], fmaf(st[i].y, cs4[j].w, b4[j].w));
-          amaxj[j] = fmaxf(fmaxf(amaxj[j], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          const float osc = j == 0 ? 1.0f : 8.0f;
+          f2 a01, a23, c01, c23, b01, b23;
+          a01.x = acc[i][j][0]; a01.y = acc[i][j][1]; a23.x = acc[i][j][2]; a23.y = acc[i][j][3];
+          c01.x = cs4[j].x; c01.y = cs4[j].y; c23.x = cs4[j].z; c23.y = cs4[j].w;
+          b01.x = b4[j].x; b01.y = b4[j].y; b23.x = b4[j].z; b23.y = b4[j].w;
+          const f2 v01 = __builtin_elementwise_fma(sx, a01, __builtin_elementwise_fma(sy, c01, b01));
+          const f2 v23 = __builtin_elementwise_fma(sx, a23, __builtin_elementwise_fma(sy, c23, b23));
+          amaxj[j] = fmaxf(fmaxf(amaxj[j], fabsf(v01.x)), fabsf(v01.y));
+          amaxj[j] = fmaxf(fmaxf(amaxj[j], fabsf(v23.x)), fabsf(v23.y));
           unsigned h0, l0, h1, l1;
-          split_pair(v[0], v[1], osc, h0, l0);
-          split_pair(v[2], v[3], osc, h1, l1);
-          const int off = ((((d >> 3) ^ (part == 2 ? vk : kk)) << 4)) + ((d & 4) << 1);
-          unsigned char* const ph = slot + part * 2 * QS_PLANE + off;
+          split_pair(v01.x, v01.y, osc, h0, l0);
+          split_pair(v23.x, v23.y, osc, h1, l1);
+          unsigned char* const ph = j == 0 ? pkq + QS_PQ : (j == 1 ? pkq + QS_PK : pv + QS_PV);
           u32x2_alias hv, lv;
           hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
           *reinterpret_cast<u32x2_alias*>(ph) = hv;
@@ -573,16 +592,8 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
     {
       float amax = 0.0f;
 #pragma unroll
-      for (int j = 0; j < QS_NJ; ++j) amax = fmaxf(amax, amaxj[j] * (((wn * 48 + 16 * j) >> 6) == 0 ? 1.0f : 8.0f));
+      for (int j = 0; j < QS_NJ; ++j) amax = fmaxf(amax, amaxj[j] * (j == 0 ? 1.0f : 8.0f));
       if (amax > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
-    }
-    if (has_next) {   // the next tile's first k-tile into stage 0, under the second attention step
-      const char* ubAn = reinterpret_cast<const char*>(a.Ap) + (size_t)(mtn * QS_ROWS + wave * 8) * K2 * 2;
-      const char* ubBn = reinterpret_cast<const char*>(a.Wp) + (size_t)(hdn * QS_BN + wave * 8) * K2 * 2;
-#pragma unroll
-      for (int it = 0; it < QS_AIT; ++it) QS_GLDS(sgpr_ptr(ubAn + it * it_stride) + lofs_, dstA + it * 8192);
-#pragma unroll
-      for (int it = 0; it < QS_BIT; ++it) QS_GLDS(sgpr_ptr(ubBn + it * it_stride) + lofs_, dstB + it * 8192);
     }
     __syncthreads();
     QS_STAMP(4);
