@@ -138,7 +138,7 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n), n wave
 // One frame of one head from its LDS slot: the arithmetic of k_attn_temporal_x3p<1, 8, 3> (same MFMAs in the same order, same
 // softmax, same conversions), outputs through the wave-private patch (aliasing the slot's Q planes, dead once the query fragments
 // are in registers) as whole 128-byte lines.
-__device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Float16* out_row0, int D, unsigned* rw) {
+__device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Float16* out_row0, int D) {
   constexpr int T = QS_J;
   unsigned char* const sVh = slot + QS_PV;
   unsigned char* const sVl = slot + QS_PV + QS_PLANE;
@@ -234,7 +234,8 @@ __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Flo
   // O = O^T / (2^13 l) - v_query, packed as hi / lo of 8 o; whole lines out through the patch
   const float inv = 1.0f / (8192.0f * l);
   const int tqc = r < T ? r : 0;
-  float amax = 0.0f;
+  // (no range tracking here: |o| = |(P - I) V| <= 2.0001 max |v|, and the slot writer raises the guard when a |v| exceeds 4090 --
+  // half the plane range --, so an un-flagged run cannot overflow the output planes; 28 VALU instructions per unit less)
   u32x4 pw[6];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
@@ -262,7 +263,6 @@ __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Flo
       unsigned h0, l0, h1, l1;
       split_pair(o4[0], o4[1], 8.0f, h0, l0);
       split_pair(o4[2], o4[3], 8.0f, h1, l1);
-      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
       const h4 oh = __builtin_bit_cast(h4, make_uint2(h0, h1)), ol = __builtin_bit_cast(h4, make_uint2(l0, l1));
       patch_wr(patch, r, h, g4, oh, ol);
     }
@@ -271,7 +271,6 @@ __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Flo
     for (int it = 0; it < 3; ++it) pw[dt * 3 + it] = patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
     asm volatile("" ::: "memory");
   }
-  if (r < T && amax > X3_HALF_MAX * 0.125f) range_raise(rw, RANGE_BIT_ACT);
   _Float16* const pw_ptr = out_row0 + (size_t)(lane >> 3) * 2 * D + 8 * (lane & 7);
   const size_t pw_stride = (size_t)8 * 2 * D;
 #pragma unroll
@@ -493,6 +492,27 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       QS_PHASE(kt, 1, false, false, has_next, true);
       ++kt;
     }
+    // ---- row statistics -> (rstd * out_scale, -mean rstd) per tile row, in front of the last k-tile: every wave reduces 32 rows (lanes
+    // 0-31) in the shadow of its SIMD partner's MFMAs -- behind the k-loop this step was 1.1 us of a 38 us tile with half the waves
+    // idle.  The raw partials landed long ago (the first counted wait of the tile retired them; phase barriers since).
+    {
+      float2* const srow = reinterpret_cast<float2*>(lds + QS_STX);
+      if (lane < 32) {
+        const int t = wave * 32 + lane, row = m0 + t;
+        float sm = 0.f, sq = 0.f;
+        if (row < a.M) {
+          const float2* raw = st_dma ? reinterpret_cast<const float2*>(lds + QS_RAW) + t * a.st_np
+                                     : reinterpret_cast<const float2*>(a.st_in) + (size_t)row * a.st_np;
+          for (int p = 0; p < a.st_np; ++p) { sm += raw[p].x; sq += raw[p].y; }
+        }
+        if (sq >= (X3_HALF_MAX * 0.125f) * (X3_HALF_MAX * 0.125f)) range_raise(a.range, RANGE_BIT_ACT);   // (producer's planes, as x3q_tile)
+        const float mean = sm / (float)K;
+        const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
+        if (row < a.M && mean * mean > 256.0f * var) range_raise(a.range, RANGE_BIT_STATS);
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        srow[t] = make_float2(rstd * a.out_scale, -mean * rstd);
+      }
+    }
     // k-tile nk - 1: A(0) of the next tile
     QS_PHASE(kt, 0, has_next, false, false, false);
     QS_PHASE(kt, 1, false, false, false, false);
@@ -501,33 +521,12 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
     __builtin_amdgcn_s_setprio(0);
     QS_STAMP(0);
 
-    // ---- row statistics -> (rstd * out_scale, -mean rstd) per tile row (their own 2 KiB: stage 0 already receives the next tile)
-    float2* const srow = reinterpret_cast<float2*>(lds + QS_STX);
-    if (tid < QS_BM) {
-      const int row = m0 + tid;
-      float sm = 0.f, sq = 0.f;
-      if (row < a.M) {
-        if (st_dma) {
-          const float2* raw = reinterpret_cast<const float2*>(lds + QS_RAW) + tid * a.st_np;
-          for (int p = 0; p < a.st_np; ++p) { sm += raw[p].x; sq += raw[p].y; }
-        } else {
-          const float2* raw = reinterpret_cast<const float2*>(a.st_in) + (size_t)row * a.st_np;
-          for (int p = 0; p < a.st_np; ++p) { sm += raw[p].x; sq += raw[p].y; }
-        }
-      }
-      if (sq >= (X3_HALF_MAX * 0.125f) * (X3_HALF_MAX * 0.125f)) range_raise(a.range, RANGE_BIT_ACT);   // (producer's planes, as x3q_tile)
-      const float mean = sm / (float)K;
-      const float var = fmaxf(sq / (float)K - mean * mean, 0.0f);
-      if (row < a.M && mean * mean > 256.0f * var) range_raise(a.range, RANGE_BIT_STATS);
-      const float rstd = 1.0f / sqrtf(var + a.eps);
-      srow[tid] = make_float2(rstd * a.out_scale, -mean * rstd);
-    }
     __syncthreads();   // statistics visible; every wave is out of the k-loop: stage 1 and the LDS behind it become the frame slots
     QS_STAMP(1);
 
     float2 st[QS_TM];
 #pragma unroll
-    for (int i = 0; i < QS_TM; ++i) st[i] = srow[wm * 128 + 16 * i + r16];
+    for (int i = 0; i < QS_TM; ++i) st[i] = reinterpret_cast<const float2*>(lds + QS_STX)[wm * 128 + 16 * i + r16];
     float4 cs4[QS_NJ], b4[QS_NJ];
 #pragma unroll
     for (int j = 0; j < QS_NJ; ++j) {
@@ -580,7 +579,7 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
       const int fr = (wave & 3) + 4 * pass + 8 * (wave >> 2);             // frame of the tile this wave takes: slot = wave
       const long long gf = (long long)mt * QS_FPT + fr;
       if (fr < QS_FPT && gf < a.F)
-        qs_attention(lds + QS_QKV + wave * QS_SLOT, lane, a.out + ((size_t)gf * QS_J) * 2 * a.D + hd * 128, a.D, a.range);
+        qs_attention(lds + QS_QKV + wave * QS_SLOT, lane, a.out + ((size_t)gf * QS_J) * 2 * a.D + hd * 128, a.D);
     };
     write_pass(0);
     __syncthreads();
@@ -592,7 +591,7 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
     {
       float amax = 0.0f;
 #pragma unroll
-      for (int j = 0; j < QS_NJ; ++j) amax = fmaxf(amax, amaxj[j] * (j == 0 ? 1.0f : 8.0f));
+      for (int j = 0; j < QS_NJ; ++j) amax = fmaxf(amax, amaxj[j] * (j == 0 ? 1.0f : (j == 1 ? 8.0f : 16.015f)));   // v: flagged from |v| > 4090 on
       if (amax > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
     }
     __syncthreads();
