@@ -30,6 +30,8 @@
 // 16-byte chunk q (hi) and 4+q (lo) of row r16.
 #include "d3d_kernels.h"
 
+#include <algorithm>
+
 namespace d3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -192,7 +194,10 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   // epilogue of every workgroup, into a buffer nothing else reads
   unsigned long long st_c0 = 0, st_r0 = 0;
   if (diag) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-  unsigned char* const lds_x = lds + 2 * STAGE;   // beyond the operand stages (allocated only for the folded forms)
+  // beyond the operand stages and the persistent walk's epilogue patches, which start at stage 1 and take 64 KiB (allocated only for
+  // the folded forms)
+  constexpr int LDS_X = (PERSIST && STAGE + NW * 2 * 16 * 64 * 4 > 2 * STAGE) ? STAGE + NW * 2 * 16 * 64 * 4 : 2 * STAGE;
+  unsigned char* const lds_x = lds + LDS_X;
   const int tid = tidx;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -711,7 +716,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
 // slices handled by split * rem <= gridDim workgroups (x3q_tile's sub_wm / g_lo / g_hi), so the round that would keep rem CUs
 // busy for a whole tile time keeps split * rem CUs busy for a fraction of it.  A slice runs the same MFMAs in the same
 // order for its rows as the whole tile would: values do not change.
-struct X3Walk { int nfull, rem, split; unsigned long long* stamps; };   // stamps: diagnostic (100 MHz start / end per workgroup)
+struct X3Walk { int nfull, rem, split; unsigned long long* stamps; int rev; };   // stamps: diagnostic (100 MHz start / end per workgroup)
+// rev: the walk visits the M-tiles from the last to the first (LaunchCtx::reverse_walk): a kernel that starts where its producer ended
+// finds the rows written last still in the Infinity Cache
 
 template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
 __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
   constexpr int NW = WM * WN, BM = 16 * TM * WM, BN = 64 * WN;
   constexpr int A_IT = BM / 8 / NW, N_IT = (BM + BN) / 8 / NW;
   static_assert(NW == 8, "one 8-wave workgroup per CU");
-  static_assert(TM % 4 == 0 && (WM == 1 || WM == 2), "tail slices");
+  static_assert(TM % 2 == 0 && (WM == 1 || WM == 2), "tail slices");   // (four-way slices need TM % 4 == 0: x3q_walk)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int G = (int)gridDim.x, b = (int)blockIdx.x;
   const int vfull = (mtiles / 8) * 8 * ntiles, mrem = mtiles % 8;
@@ -736,6 +743,7 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
       mt = (mtiles / 8) * 8 + o2 % mrem;
       nt = o2 / mrem;
     }
+    if (wk.rev) mt = mtiles - 1 - mt;
   };
   const int nitems = wk.nfull + (b < wk.split * wk.rem ? 1 : 0);
   if (nitems == 0) return;
@@ -807,9 +815,9 @@ static unsigned long long* g_x3_diag = nullptr;
 thread_local LaunchCtx tl_launch_ctx;
 
 // walk of `tiles` tiles over `grid` persistent workgroups
-static X3Walk x3q_walk(int tiles, int grid) {
-  X3Walk w{tiles / grid, tiles % grid, 1, g_x3_diag};
-  if (w.rem > 0 && tl_launch_ctx.tail_slices) w.split = (4 * w.rem <= grid) ? 4 : ((2 * w.rem <= grid) ? 2 : 1);
+static X3Walk x3q_walk(int tiles, int grid, bool four_way = true) {
+  X3Walk w{tiles / grid, tiles % grid, 1, g_x3_diag, tl_launch_ctx.reverse_walk ? 1 : 0};
+  if (w.rem > 0 && tl_launch_ctx.tail_slices) w.split = (four_way && 4 * w.rem <= grid) ? 4 : ((2 * w.rem <= grid) ? 2 : 1);
   return w;
 }
 
@@ -878,17 +886,20 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
 // in an instantiation whose DMA issues sit behind uniform branches the compiler emits NO vmcnt wait before the k-tile
 // barrier (the fence of __syncthreads() normally provides it), so fragments were read before the last-issued pieces had
 // landed.  D3D_QKTILE now states the wait itself.
+template <int TM = 8>
 static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C,
                                      _Float16* Ch, _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols,
                                      hipStream_t s, const X3Fold* fold, int w_exp, bool bf16 = false) {
-  const int mtiles = (M + 255) / 256, ntiles = (N + 255) / 256;
+  constexpr int BM = 32 * TM;
+  const int mtiles = (M + BM - 1) / BM, ntiles = (N + 255) / 256;
   const int tiles = mtiles * ntiles;
   int n_cu = device_cu_count() / 8 * 8;   // (per device)
   if (n_cu < 8) n_cu = 8;
   const int grid = tiles < n_cu ? tiles / 8 * 8 : n_cu;
   if (grid < 8) return hipErrorInvalidValue;
-  const X3Walk wk = x3q_walk(tiles, grid);
-  size_t lds_bytes = 2 * (size_t)(512 * 128);
+  const X3Walk wk = x3q_walk(tiles, grid, TM % 4 == 0);
+  constexpr size_t STAGE = (size_t)(BM + 256) * 128;
+  size_t lds_bytes = std::max(2 * STAGE, STAGE + 65536);     // two operand stages; the epilogue patches (64 KiB) start at stage 1
   X3Tail tail{};
   tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
   tail.range = launch_range_word();
@@ -899,19 +910,22 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
     if (fold->st_out) fx |= FX_SO;
     tail.st_in = fold->st_in; tail.st_np = fold->st_np; tail.csum = fold->csum; tail.eps = fold->eps;
     tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out;
-    if (fx & FX_LNF) lds_bytes += (size_t)256 * 8 + 16384;   // (rstd, -mean rstd) per row + the raw partials staged by LDS-DMA
+    if (fx & FX_LNF) lds_bytes += (size_t)BM * 8 + 16384;   // (rstd, -mean rstd) per row + the raw partials staged by LDS-DMA
     if ((fx & FX_LNF) && (!fold->csum || fold->st_np < 1)) return hipErrorInvalidValue;
   }
 #define D3D_X3P_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
   do {                                                                                                                    \
-    auto kfn = k_linear_x3q_persist<8, 2, 4, EPI_, OS_, FX_>;                                                                      \
+    auto kfn = k_linear_x3q_persist<TM, 2, 4, EPI_, OS_, FX_>;                                                                     \
     static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */                                       \
     if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;                   \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles, ntiles,     \
                        qcols, wk, tail);                                                                                  \
   } while (0)
 #define D3D_X3P_LAUNCH(EPI_, OS_) D3D_X3P_LAUNCH_FX(EPI_, OS_, 0)
-  if (bf16) {
+  if constexpr (TM != 8) {   // the 192-row walk exists for the proj form only
+    if (!bf16 && fx == (FX_RP | FX_SO) && epi == EPI_RESIDUAL && outsplit == 2) D3D_X3P_LAUNCH_FX(EPI_RESIDUAL, 2, FX_RP | FX_SO);
+    else return hipErrorInvalidValue;
+  } else if (bf16) {
     tail.out_scale = 1.0f;
     if (fx == 0 && epi == EPI_NONE && outsplit == 3) D3D_X3P_LAUNCH_FX(EPI_NONE, 3, FX_BF16);
     else if (fx == 0 && epi == EPI_GELU && outsplit == 3) D3D_X3P_LAUNCH_FX(EPI_GELU, 3, FX_BF16);
@@ -1053,6 +1067,11 @@ int x3q_ntiles(int M, int N) { (void)M; return (N + 63) / 64; }   // statistics 
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
                                   _Float16* ch, _Float16* cl, int M, int N, int K, int epi, int outsplit, int qcols,
                                   hipStream_t s, const X3Fold* fold, int w_exp) {
+  // proj form (plane residual + row statistics; N = 512, the heaviest epilogue per MFMA): 192 x 256 tiles -- 232 VGPRs without a spill
+  // where the 256-row tile sits at 256 with 8, 10.8 rounds instead of 8.07: 0.477 -> 0.455 ms per launch (same-box A/B, three
+  // alternations; the same shape costs qkv +5.5 % and fc1 +2.3 %: they keep 256 rows).  Values do not depend on the tile shape.
+  if (x3q_big(M, N) && (K / PBK) % 2 == 0 && fold && fold->Rp && fold->st_out && epi == EPI_RESIDUAL && outsplit == 2)
+    return launch_x3q_persist<6>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold, w_exp);
   if (x3q_big(M, N) && (K / PBK) % 2 == 0)
     return launch_x3q_persist(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold, w_exp);
   if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
