@@ -42,8 +42,7 @@ inline int device_cu_count() {
 // two-stream loop turns them off.  Values do not depend on it.
 // range_word: the F16X3 range-guard word (device memory, below) of the ENGINE whose call is being served -- the C ABI entry points of
 // an engine set it around their launches; launches outside an engine (the single-op hooks) write to a per-device sink nobody reads.
-// reverse_walk: persistent GEMM walks visit their M-tiles from the last to the first (values do not depend on it).
-struct LaunchCtx { bool tail_slices = true; unsigned* range_word = nullptr; bool reverse_walk = false; };
+struct LaunchCtx { bool tail_slices = true; unsigned* range_word = nullptr; };
 extern thread_local LaunchCtx tl_launch_ctx;
 unsigned* range_sink_word();   // engine.hip: 4 bytes of device memory per device, allocated on first use (nullptr if that failed)
 inline unsigned* launch_range_word() { return tl_launch_ctx.range_word ? tl_launch_ctx.range_word : range_sink_word(); }

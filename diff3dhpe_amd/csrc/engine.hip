@@ -76,7 +76,6 @@ struct d3d_engine {
   bool opt_fused_postnorm = true, opt_fold_layernorm = true;
   // "fused_spatial": the spatial blocks' qkv GEMM and attention as ONE kernel (q / k / v never leave the chip); bit-identical
   bool opt_fused_spatial = true;
-  bool opt_alternate_walks = false;   // (experiment: experiments/NOTES.md)
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
@@ -377,9 +376,6 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
                     int N, int K, int epi, int qcols, const X3Fold& f) -> hipError_t {
       const int sub = f.st_in ? (epi == EPI_GELU ? D3D_KC_LINEAR_FC1 : D3D_KC_LINEAR_QKV) : (K == D ? D3D_KC_LINEAR_PROJ : D3D_KC_LINEAR_FC2);
       Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s, sub);
-      // "alternate_walks": proj and fc2 visit the M-tiles backwards -- each GEMM of the chain starts on the rows its producer wrote last
-      struct Rev { bool saved; Rev(bool on) : saved(tl_launch_ctx.reverse_walk) { tl_launch_ctx.reverse_walk = on; } ~Rev() { tl_launch_ctx.reverse_walk = saved; } }
-          rev(e->opt_alternate_walks && f.Rp != nullptr);
       return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f, wexp);
     };
     if (!temporal && fused_sp) {
@@ -1250,7 +1246,6 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;
   else if (k == "fused_spatial") e->opt_fused_spatial = value != 0;
-  else if (k == "alternate_walks") e->opt_alternate_walks = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
     e->opt_streams = (int)value;

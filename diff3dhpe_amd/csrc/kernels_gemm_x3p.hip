@@ -716,9 +716,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
 // slices handled by split * rem <= gridDim workgroups (x3q_tile's sub_wm / g_lo / g_hi), so the round that would keep rem CUs
 // busy for a whole tile time keeps split * rem CUs busy for a fraction of it.  A slice runs the same MFMAs in the same
 // order for its rows as the whole tile would: values do not change.
-struct X3Walk { int nfull, rem, split; unsigned long long* stamps; int rev; };   // stamps: diagnostic (100 MHz start / end per workgroup)
-// rev: the walk visits the M-tiles from the last to the first (LaunchCtx::reverse_walk): a kernel that starts where its producer ended
-// finds the rows written last still in the Infinity Cache
+struct X3Walk { int nfull, rem, split; unsigned long long* stamps; };   // stamps: diagnostic (100 MHz start / end per workgroup)
 
 template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
 __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
@@ -743,7 +741,6 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
       mt = (mtiles / 8) * 8 + o2 % mrem;
       nt = o2 / mrem;
     }
-    if (wk.rev) mt = mtiles - 1 - mt;
   };
   const int nitems = wk.nfull + (b < wk.split * wk.rem ? 1 : 0);
   if (nitems == 0) return;
@@ -816,7 +813,7 @@ thread_local LaunchCtx tl_launch_ctx;
 
 // walk of `tiles` tiles over `grid` persistent workgroups
 static X3Walk x3q_walk(int tiles, int grid, bool four_way = true) {
-  X3Walk w{tiles / grid, tiles % grid, 1, g_x3_diag, tl_launch_ctx.reverse_walk ? 1 : 0};
+  X3Walk w{tiles / grid, tiles % grid, 1, g_x3_diag};
   if (w.rem > 0 && tl_launch_ctx.tail_slices) w.split = (four_way && 4 * w.rem <= grid) ? 4 : ((2 * w.rem <= grid) ? 2 : 1);
   return w;
 }
