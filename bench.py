@@ -420,6 +420,12 @@ def main():
                      "timed_in": f"separate profiled pass of {a.profile_steps} samplings right after the timed region (one stream, HIP events "
                                  "around every kernel on the launch stream)",
                      "by_kernel_ms_per_step": {k: round(v["ms"] / psteps, 3) for k, v in prof.items() if v["launches"]}})
+        if prof.get("qkv_sattn", {}).get("launches"):   # spatial blocks: qkv GEMM + 17-key attention in one kernel ("fused_spatial")
+            v = prof["qkv_sattn"]
+            roof["qkv_sattn"] = {"avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                                 "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[a.precision], 4),
+                                 "note": "qkv GEMM (LayerNorm-folded) + spatial attention of a 15-frame group in one kernel; its launches "
+                                         "are in neither 'linear' nor 'attn_spatial'"}
         if any(v["launches"] for v in gemm_kinds.values()):
             pk = PEAK_TFLOPS[a.precision]
             roof["by_gemm"] = {k[7:]: {"avg_launch_ms": round(v["ms"] / v["launches"], 4),

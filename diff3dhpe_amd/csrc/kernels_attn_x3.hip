@@ -70,6 +70,13 @@ __device__ __forceinline__ void split_pair_f16(float e0, float e1, float k, unsi
   asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(e0), "s"(k), "v"(hi));
   asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(e1), "s"(k), "v"(hi));
 }
+// the same with the scale in a VGPR and without `volatile` (output steps: the compiler may schedule them among the patch writes)
+__device__ __forceinline__ void split_pair_v(float e0, float e1, float k, unsigned& hi, unsigned& lo) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(e0), "v"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(e1), "v"(k));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(e0), "v"(k), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(e1), "v"(k), "v"(hi));
+}
 // eight numerators (one 16-key k-step of a lane) -> the MFMA B fragments hi / lo of 1024 e
 __device__ __forceinline__ void split8_e(const float (&e)[8], h8& eh, h8& el) {
   unsigned hp[4], lp[4];
@@ -930,16 +937,29 @@ __device__ __forceinline__ void attn_x3s_half(const _Float16* __restrict__ Ph, c
       for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          h4 oh, ol;
+          // -(vq_hi + vq_lo) by two v_fma_mix_f32 on the packed fp16 halves (exact: the pair sums to <= 22 bits), one fma, then
+          // hi = fp16(8 o), lo = fp16(8 o - hi) by v_fma_mixlo / mixhi: 5.5 VALU instructions per value where convert / convert /
+          // add / fma / max / clamp / convert / convert back / subtract / convert took 10 (this step is VALU-issue-bound).  Same bits
+          // whenever |8 o| is inside the fp16 range; beyond it the range guard fires either way.
+          const uint2 ph2 = __builtin_bit_cast(uint2, vqh[dt * 4 + g4]), pl2 = __builtin_bit_cast(uint2, vql[dt * 4 + g4]);
+          float o8[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float vq8 = (float)vqh[dt * 4 + g4][e] + (float)vql[dt * 4 + g4][e];
-            const float o8 = __builtin_fmaf(oacc[dt][4 * g4 + e], inv8, -vq8);
-            amax = fmaxf(amax, fabsf(o8));
-            const float sc = __builtin_amdgcn_fmed3f(o8, -65504.0f, 65504.0f);
-            oh[e] = (_Float16)sc;
-            ol[e] = (_Float16)(sc - (float)oh[e]);
+          for (int pr = 0; pr < 2; ++pr) {
+            const unsigned ph_ = pr ? ph2.y : ph2.x, pl_ = pr ? pl2.y : pl2.x;
+            float n0, n1;
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(n0) : "v"(pl_), "v"(-1.0f));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(n0) : "v"(ph_), "v"(-1.0f), "v"(n0));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(n1) : "v"(pl_), "v"(-1.0f));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(n1) : "v"(ph_), "v"(-1.0f), "v"(n1));
+            o8[2 * pr] = __builtin_fmaf(oacc[dt][4 * g4 + 2 * pr], inv8, n0);
+            o8[2 * pr + 1] = __builtin_fmaf(oacc[dt][4 * g4 + 2 * pr + 1], inv8, n1);
           }
+          amax = fmaxf(fmaxf(amax, fabsf(o8[0])), fabsf(o8[1]));
+          amax = fmaxf(fmaxf(amax, fabsf(o8[2])), fabsf(o8[3]));
+          unsigned h0, l0, h1, l1;
+          split_pair_v(o8[0], o8[1], 1.0f, h0, l0);
+          split_pair_v(o8[2], o8[3], 1.0f, h1, l1);
+          const h4 oh = __builtin_bit_cast(h4, make_uint2(h0, h1)), ol = __builtin_bit_cast(h4, make_uint2(l0, l1));
           // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout)
           patch_wr(patch, r, h, g4, oh, ol);
         }

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (through gpurun, from the repo root): the bench lines DESIGN.md section 5 quotes, one JSON file each.
 #   profiles/bench_all.sh r03
 set -eo pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out
 python3 bench.py --steps 20 --warmup 5 > $out/${tag}_bench_f16x3.json 2> $out/${tag}_bench_f16x3.err
 python3 bench.py --steps 10 --warmup 3 --frames 81 --batch 128 --no-cpu-baseline > $out/${tag}_bench_f16x3_T81.json 2>/dev/null

@@ -6,7 +6,7 @@
 # The profiled bench runs ONE stream, without its own event-timed pass (--streams 1 --profile-steps 0): kernel durations in the
 # trace are then those of kernels running alone, which is what the per-kernel roofline figures mean.
 set -eo pipefail
-tag=${1:-r03_f16x3}; shift || true
+tag=${1:-r04_f16x3}; shift || true
 args="--steps 1 --warmup 1 --no-cpu-baseline --no-selfcheck --no-extras --streams 1 --profile-steps 0 $*"
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out

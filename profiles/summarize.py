@@ -50,6 +50,8 @@ _OUT = {"0": "fp32-out", "1": "planes-out", "2": "pair-out", "3": "bf16-out"}
 
 def short(name: str) -> str:
     name = demangle(name)
+    if "k_qkv_sattn" in name:
+        return "k_qkv_sattn<255 rows x 192 cols persistent, LN-folded qkv GEMM + 17-key attention from LDS> (spatial blocks)"
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("d3d::", "").strip()
     _FX = {"0": "", "1": ", LN-folded", "2": ", plane residual", "6": ", plane residual + row stats",
@@ -69,6 +71,8 @@ def short(name: str) -> str:
             role = "proj + norm2 / fc2 + post-norm + next norm1"
         return "k_linear_x3q<{}, {}, {}{}>{}".format(tile, _EPI[epi], _OUT[osp], _FX.get(fx or "0", ", fx" + str(fx)),
                                                    " (" + role + ")" if role else "")
+    if "k_qkv_sattn" in name:
+        return "k_qkv_sattn<255 rows x 192 cols persistent, LN-folded qkv GEMM + 17-key attention from LDS> (spatial blocks)"
     m = re.match(r"k_attn_temporal_x3<(\d+), (\d+)>", name)
     if m:
         return "k_attn_temporal_x3<{} key tiles, {} units/wg>{}".format(m.group(1), m.group(2), " (spatial blocks)" if m.group(2) != "1" else " (temporal blocks)")
@@ -163,8 +167,10 @@ def traffic(pmc_json, traffic_json, T, B, prec):
     def is_spatial(n):
         if "(temporal blocks)" in n:
             return False
+        if "k_qkv_sattn" in n:
+            return False
         return "k_attn_spatial" in n or "k_attn_temporal_x3p<1," in n or "k_attn_temporal_x3<1," in n or "(spatial blocks)" in n
-    cls = {"linear": lambda n: "k_linear" in n, "layernorm": lambda n: "k_layernorm" in n,
+    cls = {"linear": lambda n: "k_linear" in n, "layernorm": lambda n: "k_layernorm" in n, "qkv_sattn": lambda n: "k_qkv_sattn" in n,
            "attn_spatial": is_spatial, "attn_temporal": lambda n: ("k_attn_temporal" in n or "k_attn_bf16" in n) and not is_spatial(n)}
     tj = json.load(open(traffic_json)) if os.path.exists(traffic_json) else {}
     for c, pat in cls.items():
