@@ -187,6 +187,13 @@ hipError_t launch_embed(const float* x2d, const float* y, const float* Wf, const
                         const float* tvec, int64_t tvec_stride, float* X, int B, int T, int J, int D, int in_chans,
                         int y_bcast_T, hipStream_t s);
 
+// the same, written as the F16X3 residual-stream planes (pair layout of 8 X) + per-row (sum, sum of squares): embed and the
+// stream-entry row kernel in one pass (D == 512)
+bool embed_planes_ok(int D, int in_chans);
+hipError_t launch_embed_planes(const float* x2d, const float* y, const float* Wf, const float* bf, const float* spos,
+                               const float* tvec, int64_t tvec_stride, void* XP, float* stats, int B, int T, int J, int D,
+                               int in_chans, int y_bcast_T, hipStream_t s);
+
 // sinusoid + trunk + per-block projections: out (n, nblk, D)
 hipError_t launch_sinusoid(const float* times, const float* freqs, float* out, int n, int D, hipStream_t s);
 // out[n,N] = post(act_pre(in[n,K]) @ W[N,K]^T + b); act: 0 none, 1 gelu(post), 2 silu(pre)

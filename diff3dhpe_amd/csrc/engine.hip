@@ -342,21 +342,26 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   uint16_t* HIDx = reinterpret_cast<uint16_t*>(w.HID);
   uint16_t* QKVh = reinterpret_cast<uint16_t*>(w.QKV);
   uint16_t* QKVl = QKVh + (size_t)M * 3 * D;
-  {
-    Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
-    HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.HN, B, T, J, D, e->cfg.in_chans, y_bcast, s));
-  }
   const size_t MDb = (size_t)M * D * 4;                 // bytes of an (M, D) fp32 tensor = of its pair-layout planes
-  TRACE(0, 0, 0, w.HN, MDb);
   auto rowk = [&](LnArgs a, int outs) -> hipError_t {
     Prof p(e, D3D_KC_LAYERNORM, 8.0 * M * D, MD4 * (1 + outs), s);
     return launch_layernorm(a, s);
   };
-  {  // stream entry: planes + row statistics of x (no normalisation)
-    LnArgs a{};
-    a.x = w.HN; a.skip_ln1 = 1; a.y_x3 = XP; a.stats = w.ST1;
-    a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
-    HIP_TRY(rowk(a, 1));
+  if (embed_planes_ok(D, e->cfg.in_chans)) {   // embedding straight into the stream planes + row statistics (one pass over HBM)
+    Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
+    HIP_TRY(launch_embed_planes(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, XP, w.ST1, B, T, J, D, e->cfg.in_chans, y_bcast, s));
+  } else {
+    {
+      Prof p(e, D3D_KC_EMBED, 2.0 * M * D * e->cin, MD4 + (double)M * e->cin * 4.0, s);
+      HIP_TRY(launch_embed(x2d, y, e->fus_w, e->fus_b, e->spos, tvec, tvec_stride, w.HN, B, T, J, D, e->cfg.in_chans, y_bcast, s));
+    }
+    TRACE(0, 0, 0, w.HN, MDb);
+    {  // stream entry: planes + row statistics of x (no normalisation)
+      LnArgs a{};
+      a.x = w.HN; a.skip_ln1 = 1; a.y_x3 = XP; a.stats = w.ST1;
+      a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
+      HIP_TRY(rowk(a, 1));
+    }
   }
   TRACE(0, 1, 0, XP, MDb);
   TRACE(0, 1, 1, w.ST1, (size_t)M * 8);

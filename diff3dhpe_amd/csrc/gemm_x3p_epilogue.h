@@ -273,7 +273,8 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
   const int pc = (int)pair_col(8 * rc8);
   const float2* srow = reinterpret_cast<const float2*>(lds_x);
   const int npart = (N + 63) >> 6;
-  constexpr int PFMAX = (FX & FX_SO) ? 3 : 4;   // (the row-statistics form: 2 and 3 measure alike, 4 spills more)
+  // (the row-statistics form at 256 rows: 2 and 3 measure alike, 4 spills more; at 192 rows -- 232 VGPRs -- 4 fits: proj -0.5 %, 6 spills: +2.3 %)
+  constexpr int PFMAX = (FX & FX_SO) ? (TM == 6 ? 4 : 3) : 4;
   constexpr int PF = (EPI == EPI_RESIDUAL) ? (TM < PFMAX ? TM : PFMAX) : 0;   // residual window, see x3q_epilogue
   const unsigned ob = (unsigned)(rrow * N + 8 * rc8) * 4u;            // this lane's 8 floats in row rrow (fp32 buffer)
   const unsigned obh = (unsigned)(rrow * N + 8 * rc8) * 2u;           // ... in an [M][N] fp16 plane

@@ -73,6 +73,13 @@ __device__ __forceinline__ void ln_row(float4 (&v)[NV], int D, int lane, const f
   }
 }
 
+// (sum, sum of squares) contribution of four values, every operation stated (no contraction left to the compiler): the row kernel
+// and the embedding kernel that writes the same statistics form them identically
+__device__ __forceinline__ void sums4(const float4 v, float& sm, float& sq) {
+  sm = __fadd_rn(sm, __fadd_rn(__fadd_rn(v.x, v.y), __fadd_rn(v.z, v.w)));
+  sq = __fadd_rn(sq, __fadd_rn(__fmaf_rn(v.x, v.x, __fmul_rn(v.y, v.y)), __fmaf_rn(v.z, v.z, __fmul_rn(v.w, v.w))));
+}
+
 __device__ __forceinline__ void add4(float4& a, const float4 b) {
   a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
 }
@@ -135,10 +142,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_layernorm(LnArgs a) {
     float sm = 0.f, sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (4 * (lane + 64 * i) < D) {
-        sm += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-      }
+      if (4 * (lane + 64 * i) < D) sums4(v[i], sm, sq);
     sm = wave_sum(sm);
     sq = wave_sum(sq);
     if (lane == 0) *reinterpret_cast<float2*>(a.stats + 2 * (size_t)row) = make_float2(sm, sq);
@@ -263,6 +267,101 @@ hipError_t launch_embed(const float* x2d, const float* y, const float* Wf, const
     D3D_EMBED(1) D3D_EMBED(2) D3D_EMBED(3) D3D_EMBED(4) D3D_EMBED(5)
   }
 #undef D3D_EMBED
+  return hipGetLastError();
+}
+
+// The same embedding for the plane-resident F16X3 flow (D = 512): one wave per token row, lane l holds columns 4 l .. + 3 and
+// 256 + 4 l .. + 3 -- the layout of k_layernorm<2> --, and writes what embed + the stream-entry row kernel used to produce in two
+// passes over HBM: the fp16 (hi, lo) planes of 8 x in the pair layout and the row's (sum, sum of squares) for the LayerNorm folded into
+// the first qkv GEMM.  Same fma chain per element as k_embed, same split and the same stated summation (sums4, wave_sum) as k_layernorm.
+template <int CIN2>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_embed_planes(const float* __restrict__ x2d, const float* __restrict__ y,
+                                                                       const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                                       const float* __restrict__ spos, const float* __restrict__ tvec,
+                                                                       int64_t tvec_stride, _Float16* __restrict__ XP,
+                                                                       float* __restrict__ stats, int M, int T, int J, int y_bcast_T,
+                                                                       int tokens_per_wave, unsigned* rw) {
+  constexpr int CIN = CIN2 + 3, D = 512;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int m_begin = gw * tokens_per_wave, m_end = min(M, m_begin + tokens_per_wave);
+  if (m_begin >= M) return;
+  float w[2][4][CIN], bias[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * (lane + 64 * i) + q;
+#pragma unroll
+      for (int k = 0; k < CIN; ++k) w[i][q][k] = Wf[(size_t)c * CIN + k];
+      bias[i][q] = bf[c];
+    }
+  float amax = 0.0f;
+  for (int m = m_begin; m < m_end; ++m) {
+    const int j = m % J;
+    const int b = m / (T * J);
+    float in[CIN];
+#pragma unroll
+    for (int k = 0; k < CIN2; ++k) in[k] = x2d[(size_t)m * CIN2 + k];
+    const size_t my = y_bcast_T ? ((size_t)b * J + j) : (size_t)m;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) in[CIN2 + k] = y[my * 3 + k];
+    float4 v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      const float4 sp = *reinterpret_cast<const float4*>(spos + (size_t)j * D + c);
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) acc = fmaf(in[k], w[i][q][k], acc);
+        o[q] = acc + bias[i][q];
+      }
+      o[0] += sp.x; o[1] += sp.y; o[2] += sp.z; o[3] += sp.w;
+      if (tvec) {
+        const float4 tv = *reinterpret_cast<const float4*>(tvec + (size_t)b * tvec_stride + c);
+        o[0] += tv.x; o[1] += tv.y; o[2] += tv.z; o[3] += tv.w;
+      }
+      v[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    _Float16* yp = XP + (size_t)m * 2 * D;
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      h4v hi, lo;
+      split4_x3(v[i], hi, lo, amax);
+      *reinterpret_cast<h4v*>(yp + pair_col(c)) = hi;
+      *reinterpret_cast<h4v*>(yp + pair_col(c) + PAIR_LO) = lo;
+      sums4(v[i], sm, sq);
+    }
+    sm = wave_sum(sm);
+    sq = wave_sum(sq);
+    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)m) = make_float2(sm, sq);
+  }
+  if (amax > X3_HALF_MAX) range_raise(rw, RANGE_BIT_ACT);
+}
+
+bool embed_planes_ok(int D, int in_chans) { return D == 512 && in_chans >= 1 && in_chans <= 5; }
+
+hipError_t launch_embed_planes(const float* x2d, const float* y, const float* Wf, const float* bf, const float* spos,
+                               const float* tvec, int64_t tvec_stride, void* XP, float* stats, int B, int T, int J, int D,
+                               int in_chans, int y_bcast_T, hipStream_t s) {
+  if (!embed_planes_ok(D, in_chans) || !XP || !stats) return hipErrorInvalidValue;
+  const int M = B * T * J;
+  const int tpw = 16;
+  const unsigned grid = (unsigned)((M + tpw * WAVES_PER_BLOCK - 1) / (tpw * WAVES_PER_BLOCK));
+#define D3D_EMBEDP(C2)                                                                                                  \
+  case C2:                                                                                                              \
+    hipLaunchKernelGGL(k_embed_planes<C2>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, x2d, y, Wf, bf, spos, tvec,    \
+                       tvec_stride, (_Float16*)XP, stats, M, T, J, y_bcast_T, tpw, launch_range_word());               \
+    break;
+  switch (in_chans) {
+    D3D_EMBEDP(1) D3D_EMBEDP(2) D3D_EMBEDP(3) D3D_EMBEDP(4) D3D_EMBEDP(5)
+  }
+#undef D3D_EMBEDP
   return hipGetLastError();
 }
 
