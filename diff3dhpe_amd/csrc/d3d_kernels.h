@@ -34,6 +34,13 @@ inline int device_cu_count() {
   cache[dev & 63].store(n, std::memory_order_release);
   return n;
 }
+// workgroups of `fn` (block threads, dyn_lds bytes of dynamic LDS) that one CU holds at a time -- registers AND LDS, as the runtime
+// computes it; a persistent kernel sized beyond this runs its surplus workgroups as a second, thinner wave of work.  0 on error.
+inline int resident_workgroups_per_cu(const void* fn, int block, size_t dyn_lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, block, dyn_lds) != hipSuccess) return 0;
+  return nb;
+}
 
 // Launch context of the calling thread (launches are issued synchronously by the thread that calls the C ABI).  tail_slices:
 // whether a persistent GEMM walk cuts the tiles of its partly filled last round into row slices (kernels_gemm_x3p.hip, X3Walk).

@@ -1041,7 +1041,20 @@ static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float1
   if (n_cu <= 0) return hipErrorUnknown;
   const long long units = (long long)B * J * H;
   if (units > 0x7fffffffLL || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-  const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;   // resident workgroups per CU
+  // resident workgroups per CU: what registers and LDS allow together (asked from the runtime once per device: sized by the LDS
+  // alone, the T = 81 form launched three 3-wave workgroups per CU where the register file held two -- a third of its units
+  // then ran as a second pass at half the residency)
+  static std::atomic<unsigned long long> per_cu_cache[64];   // (lds_bytes << 8) | workgroups: the wave-private form's LDS varies with T
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorUnknown;
+  const unsigned long long cached = per_cu_cache[dev & 63].load(std::memory_order_acquire);
+  int per_cu = (cached >> 8) == (unsigned long long)lds_bytes ? (int)(cached & 255) : 0;
+  if (per_cu <= 0) {
+    per_cu = resident_workgroups_per_cu(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU, WIT>), 64 * NKT * MU, lds_bytes);
+    if (per_cu <= 0) per_cu = 1;
+    if (per_cu > 255) per_cu = 255;
+    per_cu_cache[dev & 63].store(((unsigned long long)lds_bytes << 8) | (unsigned)per_cu, std::memory_order_release);
+  }
   const long long wgs = (units + MU - 1) / MU;
   const long long grid = wgs < (long long)n_cu * per_cu ? wgs : (long long)n_cu * per_cu;
   hipLaunchKernelGGL((k_attn_temporal_x3p<NKT, MU, WIT>), dim3((unsigned)grid), dim3(64 * NKT * MU), lds_bytes, s, ph, pl, ox, T, J, H,
