@@ -497,6 +497,24 @@ def main():
     if rank == 0:
         if extras:
             line.update(extras)
+        if world == 1 and not a.no_extras:
+            # what THIS chip sustains today for the two resources that co-limit the F16X3 / bf16 GEMM k-loop (d3d_probe_machine): fp16
+            # MFMA work in register loops at the power-limited clock, and the k-loop's L2 -> LDS staging stream alone.  Beside the
+            # nominal peaks, not instead of them: roofline.frac stays against MI355X_MICROARCH.md's 2.5 PFLOP/s.
+            try:
+                from diff3dhpe_amd.engine import probe_machine
+                pm = probe_machine(dev, ms_target=150.0)
+                mp = {"mfma_f16_tflops_sustained": round(pm["mfma_f16_tflops"], 1),
+                      "mfma_f16_frac_of_nominal": round(pm["mfma_f16_tflops"] / 2500.0, 4),
+                      "l2_to_lds_staging_gbps_chip": round(pm["l2_to_lds_gbps"], 1),
+                      "note": "register-only fp16 MFMA loops (2 waves per SIMD, operands with real hi / lo statistics) and the k-loop's LDS-DMA "
+                              "stream alone (64 KiB stages from L2-resident rows, no MFMA), each ~150 ms on this device right after the bench"}
+                if a.precision in ("f16x3", "bf16") and roof.get("achieved") and roof.get("bound") == "mfma":
+                    issued = roof["achieved"] * (3.0 if a.precision == "f16x3" else 1.0)
+                    mp["roofline_frac_of_sustained_mfma"] = round(issued / pm["mfma_f16_tflops"], 4)
+                line["machine_probes"] = mp
+            except Exception as ex:      # a probe never fails a bench run
+                line["machine_probes"] = {"error": str(ex)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, S, 0, a.cpu_budget)
             line["speedup_vs_cpu_baseline"] = round(value / max(line["cpu_baseline"]["value"], 1e-9), 1)

@@ -248,6 +248,8 @@ hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, con
 
 // debug trace: *out += position-weighted 64-bit sum of the buffer's 32-bit words (order-independent)
 hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, int rot, hipStream_t s);
+// probes.hip: what the chip sustains (what 0: fp16 MFMA TFLOP/s in register loops; 1: L2 -> LDS staging GB/s chip-wide)
+hipError_t launch_probe_machine(int what, float ms_target, float* result, hipStream_t s);
 
 // ---- kernels_attn.hip -------------------------------------------------------------------------------------------
 // qkv: (B*T*J, 3*D) -> out (B*T*J, D), GRAND core  O = softmax(q k^T * dh^-0.5) v - v

@@ -1501,6 +1501,12 @@ int make_pair(TmpPair& t, const float* src_dev, int rows, int cols, bool weight,
 }
 }  // namespace
 
+int d3d_probe_machine(int32_t what, float ms_target, float* result, void* stream) {
+  if (!result || (what != 0 && what != 1) || !(ms_target > 0.f) || ms_target > 2000.f) return fail(D3D_EINVAL, "bad argument");
+  HIP_TRY(launch_probe_machine(what, ms_target, result, reinterpret_cast<hipStream_t>(stream)));
+  return D3D_OK;
+}
+
 int d3d_op_linear(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M, int32_t N,
                   int32_t K, int32_t epi, int32_t precision, void* stream) {
   return d3d_op_linear_bench(A, W, bias, R, C, M, N, K, epi, precision, 0, 1, nullptr, stream);

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   if (WAVEP) dma(2, tok0, hd, 0);
   load_q(tok0, hd);
   h4 po_h[8], po_l[8];          // packed outputs of the previous unit, stored one barrier later
-  size_t po_off = 0;
+  size_t po_off = 0; (void)po_off;
   bool po_valid = false;
   // WAVEP: the outputs go through a wave-private 4 KiB LDS patch (32 rows x one 128-byte line, 16-byte chunks XOR-swizzled by
   // row) and leave as whole lines, 16 B per lane, 8 lanes per row: 6 store instructions per unit instead of 16 that each wrote

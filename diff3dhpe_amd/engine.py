@@ -326,6 +326,21 @@ def op_linear_bench(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, 
     return out, ms.value
 
 
+def probe_machine(device=None, ms_target: float = 100.0) -> dict:
+    """What this device sustains for the two resources that co-limit the F16X3 GEMM k-loop (d3d_probe_machine, include/d3d.h):
+    {"mfma_f16_tflops": fp16 MFMA work in register loops at the power-limited clock,
+     "l2_to_lds_gbps": the k-loop's LDS-DMA staging stream alone, summed over the CUs}."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = {}
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for what, key in ((0, "mfma_f16_tflops"), (1, "l2_to_lds_gbps")):
+            r = C.c_float(0.0)
+            _lib.check(_lib.lib().d3d_probe_machine(what, float(ms_target), C.byref(r), st))
+            out[key] = r.value
+    return out
+
+
 def op_linear_postnorm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor,
                        beta: torch.Tensor, eps: float = 1e-6, pos: Optional[torch.Tensor] = None, pos_div: int = 1,
                        tvec: Optional[torch.Tensor] = None, rows_per_batch: int = 1, with_stats: bool = False, reps: int = 1):

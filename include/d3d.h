@@ -292,6 +292,15 @@ int d3d_op_layernorm(const float* x_dev, const float* gamma_dev, const float* be
 int d3d_op_attention(const float* qkv_dev, float* out_dev, int32_t B, int32_t T, int32_t J, int32_t D, int32_t H,
                      int32_t temporal, int32_t precision, int32_t force_generic, void* stream);
 
+/* ---- machine probes (measurement support; no reference counterpart) ------------------------------------------------ */
+/* What THIS device sustains for the two resources that co-limit the F16X3 GEMM k-loop, measured over about ms_target
+ * milliseconds on `stream` (a bench line can then state its roofline fraction against measured ceilings beside the nominal
+ * peaks of MI355X_MICROARCH.md; bench.py's "machine_probes" object).  what 0: *result = TFLOP/s of fp16 MFMA work
+ * (v_mfma_f32_16x16x32_f16, two waves per SIMD on every CU, register operands with the statistics of real hi / lo halves --
+ * the power-limited clock included); what 1: *result = GB/s, summed over the CUs, of the k-loop's staging stream alone
+ * (global_load_lds_dwordx4 pieces of 256 x 256 x 32 stages from L2-resident operand rows, no MFMA).  Needs no engine. */
+int d3d_probe_machine(int32_t what, float ms_target, float* result, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

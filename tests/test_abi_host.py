@@ -105,6 +105,15 @@ def test_product_path_fails_loudly_without_a_device():
         net.forward_denoise(torch.zeros(1, 9, 17, 5), torch.zeros(1, dtype=torch.long))
 
 
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-device failure mode")
+def test_machine_probe_needs_a_device_and_checks_its_arguments():
+    L = _lib.lib()
+    r = C.c_float(0.0)
+    assert L.d3d_probe_machine(0, 10.0, C.byref(r), None) == -3          # D3D_EHIP: nothing is estimated on the host
+    assert L.d3d_probe_machine(5, 10.0, C.byref(r), None) == -1
+    assert L.d3d_probe_machine(1, -1.0, C.byref(r), None) == -1
+
+
 def test_product_package_never_imports_the_oracle():
     import subprocess, sys
     code = "import sys; import diff3dhpe_amd, diff3dhpe_amd.parallel, diff3dhpe_amd.evaluate; " \

@@ -353,3 +353,19 @@ def test_fused_spatial_blocks_with_garbage_workspace_and_large_batch():
     assert torch.equal(fused, plain)
     for lo in (0, 13):                                           # and batch-size independent, as every kernel of the engine
         assert torch.equal(eng.ddim_sample(x2d[lo:lo + 13].contiguous(), nz[lo:lo + 13].contiguous()), plain[lo:lo + 13])
+
+
+# ------------------------------------------------------------------------------------------------ machine probes
+def test_machine_probes_report_plausible_ceilings():
+    """d3d_probe_machine (bench.py's "machine_probes"): the sustained fp16 MFMA rate lies under the nominal 2.5 PFLOP/s and above the
+    rate the GEMM class itself reaches; the staging stream from L2 runs well above what HBM could deliver; bad arguments are refused."""
+    from diff3dhpe_amd.engine import probe_machine
+    pm = probe_machine(ms_target=40.0)
+    assert 1100.0 < pm["mfma_f16_tflops"] < 2500.0, pm
+    assert 8000.0 < pm["l2_to_lds_gbps"] < 60000.0, pm
+    import ctypes as C
+    r = C.c_float(0.0)
+    L = _lib.lib()
+    assert L.d3d_probe_machine(2, 10.0, C.byref(r), None) == -1
+    assert L.d3d_probe_machine(0, 0.0, C.byref(r), None) == -1
+    assert L.d3d_probe_machine(0, 10.0, None, None) == -1
