@@ -38,5 +38,8 @@ python3 - <<PY
 import json, time
 p = "profiles/hbm_traffic.json"; d = json.load(open(p)); d["_collected"] = "${tag}, " + time.strftime("%Y-%m-%d"); json.dump(d, open(p, "w"), indent=1)
 PY
+# one reviewable table per tag: launch time x algorithmic work x counters (add the sustained MFMA rate of bench.py's machine_probes by hand:
+#   python3 profiles/roofline_table.py $tag $T $B $prec <TFLOP/s>)
+python3 profiles/roofline_table.py $tag $T $B $prec > profiles/${tag}_roofline.md || true
 cp profiles/${tag}_* profiles/hbm_traffic.json gpurun_out/ 2>/dev/null || true
 cat profiles/${tag}_kernel_stats.md
