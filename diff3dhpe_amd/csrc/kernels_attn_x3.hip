@@ -415,15 +415,15 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
   dma(1, tok0, hd);
   if (WAVEP) dma(2, tok0, hd, 0);
   load_q(tok0, hd);
-  h4 po_h[8], po_l[8];          // packed outputs of the previous unit, stored one barrier later
   size_t po_off = 0; (void)po_off;
   bool po_valid = false;
   // WAVEP: the outputs go through a wave-private 4 KiB LDS patch (32 rows x one 128-byte line, 16-byte chunks XOR-swizzled by
   // row) and leave as whole lines, 16 B per lane, 8 lanes per row: 6 store instructions per unit instead of 16 that each wrote
   // 16-byte pieces of 17 different lines (this kernel is bound by the rate at which a wave gets memory instructions through)
   unsigned char* const patch = lds_all + MU * NPL * PL + (TP - T) * 128 + (int)(threadIdx.x >> 6) * 4096;
-  // !WAVEP (T = 81: three workgroups per CU, LDS is what limits them): a 1 KiB patch per wave (8 rows), four passes per line
-  unsigned char* const patch1 = lds_all + 4 * PLANE + (int)(threadIdx.x >> 6) * 1024;
+  // !WAVEP (T = 81: two 3-wave workgroups per CU by registers): the same 4 KiB patch per wave behind the four planes (it used to be a 1 KiB
+  // patch written in four 8-row passes of 8-byte pieces -- 2-way bank conflicts, a quarter of the LDS cycles of the kernel)
+  unsigned char* const patch1 = lds_all + 4 * PLANE + (int)(threadIdx.x >> 6) * 4096;
   u32x4 pq[8];                  // [dt * 4 + p]: row 32 wave + 8 p + (lane >> 3), chunk lane & 7 of line dt
   u32x4 pw[2 * WIT];            // [dt * WIT + it]: row 8 it + (lane >> 3), chunk lane & 7 of line dt
   _Float16* pw_ptr = out_x3;    // row (lane >> 3), this lane's chunk of line 0 (row 8 it: + it * pw_stride)
@@ -571,34 +571,18 @@ __global__ __launch_bounds__(64 * NKT * MU) void k_attn_temporal_x3p(const _Floa
             oh[e] = (_Float16)sc;
             ol[e] = (_Float16)(sc - (float)oh[e]);
           }
-          if (WAVEP) {   // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout)
-            patch_wr(patch, r, h, g4, oh, ol);
-            if (g4 == 3) {
-              asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
+          // columns 8 g4 + 4 h .. + 3 of line dt: hi halves in chunk g4, lo halves in chunk 4 + g4 (pair layout)
+          patch_wr(WAVEP ? patch : patch1, r, h, g4, oh, ol);
+          if (g4 == 3) {
+            asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
+            if (WAVEP) {
 #pragma unroll
               for (int it = 0; it < WIT; ++it) pw[dt * WIT + it] = patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
-            }
-          } else {
-            po_h[g4] = oh;       // (this line's four column groups, transposed below)
-            po_l[g4] = ol;
-          }
-        }
-        if (!WAVEP) {      // 8 rows at a time through the 1 KiB patch: rows 8 pp .. 8 pp + 7 of this wave's 32, written by their own lanes
+            } else {
 #pragma unroll
-          for (int pp = 0; pp < 4; ++pp) {
-            if ((r >> 3) == pp) {
-              const int rr = r & 7, sw = (rr >> 1) & 3;
-#pragma unroll
-              for (int g4 = 0; g4 < 4; ++g4) {
-                *reinterpret_cast<h4_alias*>(patch1 + rr * 128 + ((g4 ^ sw) << 4) + 8 * h) = po_h[g4];
-                *reinterpret_cast<h4_alias*>(patch1 + rr * 128 + (((4 + g4) ^ sw) << 4) + 8 * h) = po_l[g4];
-              }
+              for (int pp = 0; pp < 4; ++pp) pq[dt * 4 + pp] = patch_rd(patch1, 8 * pp + (lane >> 3), lane & 7);
             }
-            // other lanes' writes are read below: a compiler-level barrier, or the read of a lane that did not write in this
-            // pass is "optimised" into the value it read in the previous one (single-thread reasoning: it was)
-            asm volatile("" ::: "memory");
-            const int row = lane >> 3;
-            pq[dt * 4 + pp] = *reinterpret_cast<const u32x4_alias*>(patch1 + row * 128 + (((lane & 7) ^ ((row >> 1) & 3)) << 4));
+            asm volatile("" ::: "memory");     // (line dt + 1 reuses the patch)
           }
         }
       }
@@ -1032,7 +1016,7 @@ template <int NKT, int MU = 1, int WIT = 3>
 static hipError_t launch_x3p_nkt(const _Float16* ph, const _Float16* pl, _Float16* ox, int B, int T, int J, int D, int H,
                                  hipStream_t s) {
   // wave-private units (MU > 1, NKT == 1): 6 planes of T rows per wave (V double-buffered) + one zeroed pad behind the last
-  const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 + (size_t)MU * 4096 : (size_t)4 * 32 * NKT * 128 + (size_t)NKT * 1024;
+  const size_t lds_bytes = MU > 1 ? (size_t)MU * 6 * T * 128 + (size_t)(32 * NKT - T) * 128 + (size_t)MU * 4096 : (size_t)4 * 32 * NKT * 128 + (size_t)NKT * 4096;
   static std::atomic<unsigned long long> attr_set{0};   // one bit per device
   if (hipError_t e = lds_optin(reinterpret_cast<const void*>(&k_attn_temporal_x3p<NKT, MU, WIT>), MU > 1 ? (size_t)160 * 1024 : lds_bytes,
                                attr_set))
