@@ -4,6 +4,7 @@
 //   order 0: triples per n-tile (the production order): consecutive MFMAs share at most one operand, every third none
 //   order 1: A-stationary snake: (bh0..3, al) (bl3..0, ah) (bh3..0, ah) -- every consecutive pair shares one operand, the A side
 //            changes twice per group; per accumulator the same three products in the same order (bit-identical)
+//   order 4: pairs of n-tiles interleaved (dependent MFMAs one apart), production order per accumulator (bit-identical)
 //   order 2: one operand pair for everything (lower bound of operand toggling; wrong arithmetic)
 // hipcc --offload-arch=gfx950 -O3 experiments/mfma_order.hip -o experiments/mfma_order && experiments/mfma_order
 #include <hip/hip_runtime.h>
@@ -38,6 +39,13 @@ __global__ __launch_bounds__(512) void loop(const _Float16* in, float* out, int 
         for (int j = 3; j >= 0; --j) MMA(bl[j], AH, acc[g][j]);
 #pragma unroll
         for (int j = 3; j >= 0; --j) MMA(bh[j], AH, acc[g][j]);
+      } else if (ORDER == 4) {   // pairs of n-tiles interleaved: a dependent MFMA never follows its producer directly; production order per accumulator
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          MMA(bh[jp], AL, acc[g][jp]); MMA(bh[jp + 1], AL, acc[g][jp + 1]);
+          MMA(bl[jp], AH, acc[g][jp]); MMA(bl[jp + 1], AH, acc[g][jp + 1]);
+          MMA(bh[jp], AH, acc[g][jp]); MMA(bh[jp + 1], AH, acc[g][jp + 1]);
+        }
       } else if (ORDER == 3) {   // W-stationary: (bh_j, al) (bh_j, ah) (bl_j, ah) -- NOT the production order of additions
 #pragma unroll
         for (int j = 0; j < 4; ++j) { MMA(bh[j], AL, acc[g][j]); MMA(bh[j], AH, acc[g][j]); MMA(bl[j], AH, acc[g][j]); }
@@ -75,19 +83,23 @@ int main() {
   hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 60000;
-  for (int round = 0; round < 3; ++round)
-    for (int order = 0; order < 4; ++order) {
-      for (int rep = 0; rep < 2; ++rep) {
-        hipEventRecord(e0);
-        if (order == 0) hipLaunchKernelGGL(loop<0>, dim3(256), dim3(512), 0, 0, din, dout, iters);
-        else if (order == 1) hipLaunchKernelGGL(loop<1>, dim3(256), dim3(512), 0, 0, din, dout, iters);
-        else if (order == 3) hipLaunchKernelGGL(loop<3>, dim3(256), dim3(512), 0, 0, din, dout, iters);
-        else hipLaunchKernelGGL(loop<2>, dim3(256), dim3(512), 0, 0, din, dout, iters);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double flops = 256.0 * 8 * iters * 96.0 * 16384.0;
-        if (rep == 1) printf("round %d order %d: %.3f ms  %.0f TFLOP/s fp16\n", round, order, ms, flops / ms / 1e9);
+  for (int threads : {512, 256})     // 2 waves per SIMD (the GEMM's occupancy) / 1 wave per SIMD (a wave running alone at a phase's end)
+    for (int round = 0; round < 2; ++round)
+      for (int order : {0, 1, 4, 3, 2}) {
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {
+          hipEventRecord(e0);
+          if (order == 0) hipLaunchKernelGGL(loop<0>, dim3(256), dim3(threads), 0, 0, din, dout, iters);
+          else if (order == 1) hipLaunchKernelGGL(loop<1>, dim3(256), dim3(threads), 0, 0, din, dout, iters);
+          else if (order == 4) hipLaunchKernelGGL(loop<4>, dim3(256), dim3(threads), 0, 0, din, dout, iters);
+          else if (order == 3) hipLaunchKernelGGL(loop<3>, dim3(256), dim3(threads), 0, 0, din, dout, iters);
+          else hipLaunchKernelGGL(loop<2>, dim3(256), dim3(threads), 0, 0, din, dout, iters);
+          hipEventRecord(e1); hipEventSynchronize(e1);
+          hipEventElapsedTime(&ms, e0, e1);
+        }
+        const double flops = 256.0 * (threads / 64) * iters * 96.0 * 16384.0;
+        printf("waves/SIMD %d round %d order %d: %.3f ms  %.0f TFLOP/s fp16  (%.1f cycles per MFMA and SIMD at 1.9 GHz)\n", threads / 256, round, order, ms,
+               flops / ms / 1e9, ms * 1e-3 * 1.9e9 / ((double)iters * 96.0 * (threads / 256)));
       }
-    }
   return 0;
 }
