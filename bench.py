@@ -426,6 +426,12 @@ def main():
                                  "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[a.precision], 4),
                                  "note": "qkv GEMM (LayerNorm-folded) + spatial attention of a 15-frame group in one kernel; its launches "
                                          "are in neither 'linear' nor 'attn_spatial'"}
+        if prof.get("qkv_tattn", {}).get("launches"):   # temporal blocks likewise ("fused_temporal")
+            v = prof["qkv_tattn"]
+            roof["qkv_tattn"] = {"avg_launch_ms": round(v["ms"] / v["launches"], 4),
+                                 "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[a.precision], 4),
+                                 "note": "qkv GEMM (LayerNorm-folded) + temporal attention of one (batch, joint) group in one kernel; its launches "
+                                         "are in neither 'linear' nor 'attn_temporal'"}
         if any(v["launches"] for v in gemm_kinds.values()):
             pk = PEAK_TFLOPS[a.precision]
             roof["by_gemm"] = {k[7:]: {"avg_launch_ms": round(v["ms"] / v["launches"], 4),

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd3d_hip.so")
 
 PREC_FP32, PREC_F16X3, PREC_BF16 = 0, 1, 2
-KC_COUNT = 12
+KC_COUNT = 13
 RANGE_ACT, RANGE_WEIGHT, RANGE_STATS = 1, 2, 4
 PRECISIONS = {"fp32": PREC_FP32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
 

@@ -76,6 +76,8 @@ struct d3d_engine {
   bool opt_fused_postnorm = true, opt_fold_layernorm = true;
   // "fused_spatial": the spatial blocks' qkv GEMM and attention as ONE kernel (q / k / v never leave the chip); bit-identical
   bool opt_fused_spatial = true;
+  // "fused_temporal": the same for the temporal blocks where the frame count fits one tile (T in 193..256: kernels_qkv_tattn.hip)
+  bool opt_fused_temporal = true;
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
@@ -370,6 +372,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     const size_t Mp = (size_t)((reinterpret_cast<char*>(w.HN) - reinterpret_cast<char*>(w.X)) / ((size_t)D * 4));   // rows of w.X as carved
     if (Mp > (size_t)M) HIP_TRY(hipMemsetAsync(XP + (size_t)M * 2 * D, 0, (Mp - (size_t)M) * 2 * D * sizeof(uint16_t), s));
   }
+  const bool fused_tp = e->opt_fused_temporal && qkv_tattn_ok(T, J, D, e->H, D);
   const int np2 = x3q_ntiles(M, D);                     // statistics partials per row written by a GEMM epilogue
   int np1 = 1;                                          // ... per row in w.ST1 (1 after a row kernel)
   // post-norm inside the fc2 epilogue (X3PostNorm) where the tile shape for it exists; else fp32 + the row kernel
@@ -383,7 +386,12 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (f.Rp ? 2 : 1)), s, sub);
       return launch_linear_x3p(A, W, bias, nullptr, C, Ch, Cl, M, N, K, epi, outsplit, qcols, 0, s, &f, wexp);
     };
-    if (!temporal && fused_sp) {
+    if (temporal && fused_tp && bw.qkv_f3h) {
+      // temporal block: q, k, v of one (batch, joint) group stay in LDS and feed the T-key attention in the same kernel (kernels_qkv_tattn.hip)
+      Prof p(e, D3D_KC_QKV_TATTN, 2.0 * M * 3.0 * D * D + 4.0 * M * (double)T * D, 2.0 * MD4 + 4.0 * 3.0 * D * D, s);
+      HIP_TRY(launch_qkv_tattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, 1e-6f, bw.qkv_fe, AOx, B, T, J, D, D, e->H, s));
+      TRACE(k, 3, 0, AOx, MDb);
+    } else if (!temporal && fused_sp) {
       // spatial block: q, k, v of a frame group stay in LDS and feed the 17-key attention in the same kernel (kernels_qkv_sattn.hip)
       Prof p(e, D3D_KC_QKV_SATTN, 2.0 * M * 3.0 * D * D + 4.0 * M * (double)J * D, 2.0 * MD4 + 4.0 * 3.0 * D * D, s);
       HIP_TRY(launch_qkv_sattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, 1e-6f, bw.qkv_fe, AOx, M, D, J, D, e->H, s));
@@ -839,6 +847,7 @@ int d3d_engine_commit_weights(d3d_engine* e) {
     std::vector<uint16_t> host(per_blk * e->nblk, 0);
     const size_t fold_per_blk = 2 * (3 * D + Dm) + 2 * 3 * D;
     const bool head_major = qkv_sattn_ok(e->J, e->D, e->H, e->D);
+    const bool tile_order_t = qkv_tattn_ok(e->T, e->J, e->D, e->H, e->D);
     std::vector<float> fold(fold_per_blk * e->nblk, 0.f);
     if (e->arena_fold) { (void)hipFree(e->arena_fold); e->arena_fold = nullptr; }
     HIP_TRY(hipMalloc(&e->arena_fold, fold.size() * sizeof(float)));
@@ -887,7 +896,8 @@ int d3d_engine_commit_weights(d3d_engine* e) {
         fo += 2 * rows;
       };
       folded(p + ".attn.qkv.weight", p + ".attn.qkv.bias", p + ".norm1", 3 * D, D, b.qkv_f3, b.qkv_cs, b.qkv_fb, b.qkv_fe);
-      if (head_major && !(k & 1)) {   // spatial block: the same folded rows once more in head-major order (same per-matrix exponent)
+      if ((k & 1) ? tile_order_t : head_major) {   // the same folded rows once more in tile order (same per-matrix exponent): spatial
+                                                   // blocks for kernels_qkv_sattn.hip, temporal blocks for kernels_qkv_tattn.hip
         const size_t dh = D / e->H, rows = 3 * D;
         std::vector<float> whm(rows * D);
         const size_t f_cs = (size_t)(b.qkv_cs - e->arena_fold), f_fb = (size_t)(b.qkv_fb - e->arena_fold);
@@ -1251,6 +1261,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;
   else if (k == "fused_spatial") e->opt_fused_spatial = value != 0;
+  else if (k == "fused_temporal") e->opt_fused_temporal = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
     e->opt_streams = (int)value;
@@ -1461,7 +1472,7 @@ int d3d_engine_profile_read(d3d_engine* e, int32_t cls, double* total_ms, int64_
 
 const char* d3d_kernel_class_name(int32_t cls) {
   static const char* names[D3D_KC_COUNT] = {"linear", "attn_spatial", "attn_temporal", "layernorm", "embed", "head", "other",
-                                            "linear_qkv", "linear_proj", "linear_fc1", "linear_fc2", "qkv_sattn"};
+                                            "linear_qkv", "linear_proj", "linear_fc1", "linear_fc2", "qkv_sattn", "qkv_tattn"};
   return (cls >= 0 && cls < D3D_KC_COUNT) ? names[cls] : "?";
 }
 

@@ -208,7 +208,10 @@ int d3d_window_gather(const float* seq_dev, int32_t n_frames, int32_t T, int32_t
 /* spatial blocks of the F16X3 flow: the LayerNorm-folded qkv GEMM and the 17-key attention as ONE kernel ("fused_spatial"); its
  * launches are counted here only (neither under D3D_KC_LINEAR nor D3D_KC_ATTN_SPATIAL) */
 #define D3D_KC_QKV_SATTN 11
-#define D3D_KC_COUNT 12
+/* temporal blocks likewise ("fused_temporal": the qkv GEMM of one (batch, joint) group and its T-key attention as ONE kernel); counted
+ * here only (neither under D3D_KC_LINEAR nor D3D_KC_ATTN_TEMPORAL) */
+#define D3D_KC_QKV_TATTN 12
+#define D3D_KC_COUNT 13
 int d3d_engine_set_profiling(d3d_engine* e, int32_t on);
 int d3d_engine_profile_reset(d3d_engine* e);
 int d3d_engine_profile_read(d3d_engine* e, int32_t kernel_class, double* total_ms, int64_t* launches, double* flops,

@@ -369,3 +369,26 @@ def test_machine_probes_report_plausible_ceilings():
     assert L.d3d_probe_machine(2, 10.0, C.byref(r), None) == -1
     assert L.d3d_probe_machine(0, 0.0, C.byref(r), None) == -1
     assert L.d3d_probe_machine(0, 10.0, None, None) == -1
+
+
+# ------------------------------------------------------------------------------------------------ fused temporal blocks
+@pytest.mark.parametrize("T,B,family", [(243, 2, "uniform"), (243, 9, "trainedlike"), (200, 3, "uniform"), (256, 1, "uniform"), (193, 2, "trainedlike")])
+def test_fused_temporal_blocks_are_bit_identical_to_the_two_kernel_flow(T, B, family):
+    """"fused_temporal": the temporal blocks' LayerNorm-folded qkv GEMM and T-key attention as one kernel where the frames of a joint fit
+    one 256-row tile (kernels_qkv_tattn.hip: K / V planes and the query exchange in LDS).  Same MFMAs in the same order per element, the
+    epilogue arithmetic of the qkv GEMM and the attention arithmetic of k_attn_temporal_x3s: the sampling is bit for bit the one of
+    the two-kernel flow.  Frame counts with and without pad rows in the tile, few and many groups per workgroup, both weight families."""
+    cfg = cfg_full(T)
+    _, diff = _product(cfg, 11 if family == "trainedlike" else 5, "f16x3", sampling=2, family=family)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(B, T, 78)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eng.range_flags(clear=True)
+    eng.set_option("fused_temporal", 1)
+    fused = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_temporal", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_temporal", 1)
+    again = eng.ddim_sample(x2d, nz).clone()
+    assert torch.isfinite(fused).all() and eng.range_flags() == 0
+    assert torch.equal(fused, plain) and torch.equal(fused, again)
