@@ -165,6 +165,7 @@ hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, cons
 // kernels_qkv_tattn.hip: the temporal counterpart -- the LayerNorm-folded qkv GEMM of one (batch, joint) group (T in 193..256 frames) x one
 // head with the T-key attention of k_attn_temporal_x3s run from LDS; the same tile-ordered weight / bias / csum as launch_qkv_sattn.
 bool qkv_tattn_ok(int T, int J, int D, int H, int K);
+void set_qkv_tattn_diag(int on);   // "qt_diag": in-kernel stamp report of every 50th launch
 hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, const float* bias_to, const float* csum_to, const float* st_in,
                             int st_np, float eps, int w_exp, void* out_x3, int B, int T, int J, int K, int D, int H, hipStream_t s);
 

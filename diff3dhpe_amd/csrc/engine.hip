@@ -1257,6 +1257,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   if (k == "gemm_diag") { g_opt_gemm_diag = value != 0; return D3D_OK; }     // process-wide: e may be NULL
   if (k == "attn_diag") { g_opt_attn_diag = value != 0; return D3D_OK; }
   if (k == "qs_diag") { set_qkv_sattn_diag(value != 0); return D3D_OK; }
+  if (k == "qt_diag") { set_qkv_tattn_diag(value != 0); return D3D_OK; }
   if (!e) return fail(D3D_EINVAL, "null engine");
   if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;

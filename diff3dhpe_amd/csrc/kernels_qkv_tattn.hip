@@ -3,7 +3,7 @@
 // removes from the unfused flow (k_linear_x3q_persist<qkv form> + k_attn_temporal_x3s): the q / k / v planes never exist in HBM -- 1.62 GB
 // written and 1.62 GB read back per launch pair at the bench shape -- and one kernel launch per temporal block.
 //
-// Tile = the T (193 ... 256) frames of ONE joint of one batch element x ONE head's q, k, v: 256 token rows (row t = token (b T + t) J + j:
+// Tile = the T (193 ... 255) frames of ONE joint of one batch element x ONE head's q, k, v: 256 token rows (row t = token (b T + t) J + j:
 // the DMA walks the rows by stride, pad rows repeat the last frame) x 192 output columns of the tile-ordered folded weight (as the spatial
 // kernel: accumulator column tile j of every wave is q / k / v).  Eight waves (2 x 4), 128 rows x 48 columns each; the k-loop is the
 // two-phase persistent loop of kernels_qkv_sattn.hip on the same 256 x 192 x 32 stage.  Per output element the same MFMAs in the same
@@ -366,9 +366,8 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
   int bj = 0, hd = 0;
   tile_of(b, bj, hd);
   // first k-tile of a tile: wave w moves pieces w, w + 8, ... (8 rows x 128 B each) of A, then of W; tile row t is token tok0 + min(t, T - 1) J
-  auto stage_first = [&](int bj_, int hd_) {
+  auto stage_first = [&](int bj_, int hd_, int wave) {   // (the pieces of `wave`: the issuing wave may move another wave's share as well)
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lr = lane >> 3, csrc = (lane & 7) ^ (((wave & 1) << 2) | (lr >> 1));
     const size_t tok0_ = (size_t)(bj_ / J) * T * J + (size_t)(bj_ % J);
     const char* tA = reinterpret_cast<const char*>(a.Ap) + tok0_ * K2 * 2;
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
 #pragma unroll
     for (int it = 0; it < QT_BIT; ++it) QT_GLDS(sgpr_ptr(ubB + it * it_stride) + lofsW, QT_AREG + wave * 1024 + lane * 16 + it * 8192);
   };
-  stage_first(bj, hd);
+  stage_first(bj, hd, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
   int tid_o = (int)threadIdx.x;
   unsigned long long dg[6] = {0, 0, 0, 0, 0, 0};
   const unsigned long long dg_r0 = a.diag ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -604,7 +603,6 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       cs4[j] = *reinterpret_cast<const float4*>(a.csum + n);
       b4[j] = *reinterpret_cast<const float4*>(a.bias + n);
     }
-    __syncthreads();   // every wave holds its rows' statistics: the exchange region (which they sat in) may be written
     QT_STAMP(1);
 
     // ---- q / k / v -> LDS (LayerNorm fold and hi / lo split of x3q_epilogue8; column tile j of a wave is q / k / v: plane and scale
@@ -645,11 +643,21 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         }
       }
     };
-    // first half's queries travel with the planes; the second half's follow while the first half already computes scores
-    write_rows(wm == 0, true);
+    // K and V planes first (they do not touch the region the statistics sat in), then the first half's queries behind a barrier that by
+    // then costs nothing: every wave read its statistics long before
+    write_rows(false, true);
+    __syncthreads();                                   // B0: every wave holds its rows' statistics: the exchange planes may be written
+    if (wm == 0) write_rows(true, false);
     {
       float amax = fmaxf(fmaxf(amaxj[1], amaxj[2]) * 8.0f, wm == 0 ? amaxj[0] : 0.0f);
       if (amax > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
+    }
+    // the word through which the second half synchronises its query exchange by itself (B3'): in the last pad row of the V lo plane
+    // (T <= 255: key 255 is a pad key -- its numerator is an exact zero, any finite bits will do), zeroed by the lane that wrote there
+    unsigned* const xsync = reinterpret_cast<unsigned*>(lds + QT_V + QT_PLANE + 255 * 128);
+    if (wave == 7 && lane == 63) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      *reinterpret_cast<volatile unsigned*>(xsync) = 0u;
     }
     __syncthreads();                                   // B1: K, V, Q(half 0) written
     QT_STAMP(2);
@@ -677,17 +685,22 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         __builtin_amdgcn_s_barrier();                  // B2: half 0 holds its queries: the exchange planes may be rewritten
         qt_scores(lds, lane, qh, ql, sacc);
       }
-      __builtin_amdgcn_s_barrier();                    // B3
       qt_softmax(lane, T, sacc, lsum);
       __builtin_amdgcn_s_barrier();                    // B4: every wave is through its scores (K dead), the exchange planes are patches now
-      if (more) stage_first(bjn, hdn);
+      QT_STAMP(3);
       qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
+      QT_STAMP(4);
+      // the next tile's first k-tile into the dead K planes: both halves' pieces from this half, which is a step ahead and would idle
+      if (more) { stage_first(bjn, hdn, wave); stage_first(bjn, hdn, wave + 4); }
     } else {
       __builtin_amdgcn_s_barrier();                    // B2
       write_rows(true, false);
       if (amaxj[0] > X3_HALF_MAX) range_raise(a.range, RANGE_BIT_ACT);
+      // B3': the four waves of this half meet at an LDS counter (a workgroup barrier would hold the first half at its scores)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                    // B3: Q(half 1) written
+      if (lane == 0) atomicAdd(xsync, 1u);
+      while (*reinterpret_cast<volatile unsigned*>(xsync) < 4u) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
       f32x16 sacc[QT_NKT];
       float lsum = 0.f;
       {
@@ -696,11 +709,9 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         qt_scores(lds, lane, qh, ql, sacc);
       }
       __builtin_amdgcn_s_barrier();                    // B4
-      if (more) stage_first(bjn, hdn);
       qt_softmax(lane, T, sacc, lsum);
       qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
     }
-    QT_STAMP(3);
     bj = bjn; hd = hdn;
     __syncthreads();   // planes and patches are read before the next tile's statistics block and second k-tile are staged over them
     QT_STAMP(5);
@@ -715,7 +726,10 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
 
 }  // namespace
 
-bool qkv_tattn_ok(int T, int J, int D, int H, int K) { return T > 192 && T <= 256 && J >= 1 && H == 8 && D == 512 && K % 64 == 0 && K >= 128; }
+static std::atomic<int> g_qt_diag{0};
+void set_qkv_tattn_diag(int on) { g_qt_diag = on; }
+
+bool qkv_tattn_ok(int T, int J, int D, int H, int K) { return T > 192 && T <= 255 && J >= 1 && H == 8 && D == 512 && K % 64 == 0 && K >= 128; }
 
 // Tokens M = B T J, rows (b T + t) J + j.
 hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, const float* bias_to, const float* csum_to, const float* st_in,
@@ -735,6 +749,31 @@ hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, cons
   if (n_cu <= 0) return hipErrorUnknown;
   const int tiles = a.BJ * 8;
   const int grid = tiles < n_cu ? tiles : n_cu;
+  if (g_qt_diag.load() > 0) {   // "qt_diag" option: every 50th launch with stamps of wave 0, summarised on stderr (synchronises the stream)
+    static std::atomic<int> count{0};
+    if (count.fetch_add(1) % 50 == 10) {
+      unsigned long long* buf = nullptr;
+      if (hipMalloc(&buf, (size_t)grid * 64) != hipSuccess) return hipErrorOutOfMemory;
+      (void)hipMemsetAsync(buf, 0, (size_t)grid * 64, s);
+      a.diag = buf;
+      hipLaunchKernelGGL(k_qkv_tattn, dim3(grid), dim3(512), QT_LDS, s, a);
+      (void)hipStreamSynchronize(s);
+      std::vector<unsigned long long> h((size_t)grid * 8);
+      (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(buf);
+      double sum[6] = {0}, tiles_n = 0, cyc = 0, ticks = 0;
+      for (int g = 0; g < grid; ++g) {
+        for (int i = 0; i < 6; ++i) { sum[i] += (double)h[8 * g + i]; cyc += (double)h[8 * g + i]; }
+        tiles_n += (double)h[8 * g + 6]; ticks += (double)h[8 * g + 7];
+      }
+      const double ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;   // cycles per ns (100 MHz ticks = 10 ns)
+      fprintf(stderr, "[qt diag] B J = %d, tiles %d on %d workgroups, clock %.2f GHz; per tile (us, wave 0): k-loop %.2f  statistics -> registers %.2f  "
+              "plane writes %.2f  query exchange + scores + softmax %.2f  products + outputs %.2f  end barrier %.2f  | total %.2f\n", a.BJ, tiles, grid, ghz,
+              sum[0] / tiles_n / ghz / 1e3, sum[1] / tiles_n / ghz / 1e3, sum[2] / tiles_n / ghz / 1e3, sum[3] / tiles_n / ghz / 1e3,
+              sum[4] / tiles_n / ghz / 1e3, sum[5] / tiles_n / ghz / 1e3, cyc / tiles_n / ghz / 1e3);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(k_qkv_tattn, dim3(grid), dim3(512), QT_LDS, s, a);
   return hipGetLastError();
 }
