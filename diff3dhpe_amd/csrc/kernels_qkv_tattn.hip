@@ -655,16 +655,17 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
     // the word through which the second half synchronises its query exchange by itself (B3'): in the last pad row of the V lo plane
     // (T <= 255: key 255 is a pad key -- its numerator is an exact zero, any finite bits will do), zeroed by the lane that wrote there
     unsigned* const xsync = reinterpret_cast<unsigned*>(lds + QT_V + QT_PLANE + 255 * 128);
-    if (wave == 7 && lane == 63) {
+    if (wave == 7 && lane == 63) {   // [0]: second half's queries written; [1]: second half through its scores
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      *reinterpret_cast<volatile unsigned*>(xsync) = 0u;
+      reinterpret_cast<volatile unsigned*>(xsync)[0] = 0u;
+      reinterpret_cast<volatile unsigned*>(xsync)[1] = 0u;
     }
     __syncthreads();                                   // B1: K, V, Q(half 0) written
     QT_STAMP(2);
     // From here the two halves run separate instruction streams that meet the same three barriers (B2, B3, B4); from B3 on the two
-    // waves of a SIMD (w and w + 4) are a step apart -- one in an MFMA step, one in a VALU step:
-    //   half 0: read Q | B2 | scores            | B3 | softmax            | B4 | stage next k-tile 0, products, outputs
-    //   half 1:        | B2 | write Q(half 1)   | B3 | read Q, scores     | B4 | stage next k-tile 0, softmax, products, outputs
+    // waves of a SIMD (w and w + 4) are about a step apart -- one in an MFMA step, one in a VALU step:
+    //   half 0: read Q | B2 | scores, softmax                          | B4' (no wait) | products, outputs, both halves' prefetch pieces
+    //   half 1:        | B2 | write Q(half 1) | B3' | read Q, scores | raise B4' | softmax, products, outputs
     _Float16* const out_unit = a.out + tok0 * 2 * a.D + hd * 128;
     auto read_q = [&](h8 (&qh)[4], h8 (&ql)[4]) {   // this wave's 32 queries (rows 32 (wave & 3) + r of its half's exchange planes), all 64 dims
       const int r = lane & 31, h = lane >> 5;
@@ -686,7 +687,10 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         qt_scores(lds, lane, qh, ql, sacc);
       }
       qt_softmax(lane, T, sacc, lsum);
-      __builtin_amdgcn_s_barrier();                    // B4: every wave is through its scores (K dead), the exchange planes are patches now
+      // B4': the second half is through its scores -- it holds its queries (the exchange planes become patches) and K is dead (the
+      // prefetch below); a counter it raised long before this point, not a barrier it would have to wait at
+      while (reinterpret_cast<volatile unsigned*>(xsync)[1] < 4u) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
       QT_STAMP(3);
       qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
       QT_STAMP(4);
@@ -708,7 +712,8 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         read_q(qh, ql);
         qt_scores(lds, lane, qh, ql, sacc);
       }
-      __builtin_amdgcn_s_barrier();                    // B4
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(xsync + 1, 1u);         // B4'
       qt_softmax(lane, T, sacc, lsum);
       qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
     }
