@@ -338,16 +338,19 @@ def test_fused_spatial_blocks_are_bit_identical_to_the_two_kernel_flow(T, B, fam
 
 
 def test_fused_spatial_blocks_with_garbage_workspace_and_large_batch():
-    """The fused kernel stages rows beyond the matrix (its 255-row tiles over a 256-row padded stream) and must not let them
-    reach a stored value: workspace filled with NaN, B = 32 at T = 243 (30 tiles per workgroup, ragged last M-tile), two streams."""
+    """The fused spatial kernel stages rows beyond the matrix (its 255-row tiles over a 256-row padded stream), the fused temporal one
+    repeats a group's last frame in its pad rows: neither may let them reach a stored value: workspace filled with NaN, B = 32 at
+    T = 243 (30 / 17 tiles per workgroup, ragged last M-tile), two streams."""
     cfg = cfg_full(243)
     _, diff = _product(cfg, 5, "f16x3", sampling=1)
     eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
     inp = inputs(32, 243, 78)
     x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
     eng.set_option("fused_spatial", 0)
+    eng.set_option("fused_temporal", 0)                          # (both block types as two kernels: the flow the goldens pinned first)
     plain = eng.ddim_sample(x2d, nz).clone()
     eng.set_option("fused_spatial", 1)
+    eng.set_option("fused_temporal", 1)
     eng._workspace(32).view(torch.float32).fill_(float("nan"))
     fused = eng.ddim_sample(x2d, nz)
     assert torch.equal(fused, plain)
