@@ -693,9 +693,9 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       asm volatile("" ::: "memory");
       QT_STAMP(3);
       qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
-      QT_STAMP(4);
       // the next tile's first k-tile into the dead K planes: both halves' pieces from this half, which is a step ahead and would idle
       if (more) { stage_first(bjn, hdn, wave); stage_first(bjn, hdn, wave + 4); }
+      QT_STAMP(4);
     } else {
       __builtin_amdgcn_s_barrier();                    // B2
       write_rows(true, false);
@@ -714,18 +714,21 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) atomicAdd(xsync + 1, 1u);         // B4'
+      QT_STAMP(3);
       qt_softmax(lane, T, sacc, lsum);
       qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
+      QT_STAMP(4);
     }
     bj = bjn; hd = hdn;
     __syncthreads();   // planes and patches are read before the next tile's statistics block and second k-tile are staged over them
     QT_STAMP(5);
   }
 #undef QT_STAMP
-  if (a.diag && threadIdx.x == 0) {
-    for (int i = 0; i < 6; ++i) a.diag[8 * b + i] = dg[i];
-    a.diag[8 * b + 6] = (unsigned long long)nitems;
-    a.diag[8 * b + 7] = __builtin_amdgcn_s_memrealtime() - dg_r0;
+  if (a.diag && (threadIdx.x == 0 || threadIdx.x == 256)) {   // wave 0 (first half) and wave 4 (second half)
+    unsigned long long* d = a.diag + 16 * b + (threadIdx.x ? 8 : 0);
+    for (int i = 0; i < 6; ++i) d[i] = dg[i];
+    d[6] = (unsigned long long)nitems;
+    d[7] = __builtin_amdgcn_s_memrealtime() - dg_r0;
   }
 }
 
@@ -758,24 +761,29 @@ hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, cons
     static std::atomic<int> count{0};
     if (count.fetch_add(1) % 50 == 10) {
       unsigned long long* buf = nullptr;
-      if (hipMalloc(&buf, (size_t)grid * 64) != hipSuccess) return hipErrorOutOfMemory;
-      (void)hipMemsetAsync(buf, 0, (size_t)grid * 64, s);
+      if (hipMalloc(&buf, (size_t)grid * 128) != hipSuccess) return hipErrorOutOfMemory;
+      (void)hipMemsetAsync(buf, 0, (size_t)grid * 128, s);
       a.diag = buf;
       hipLaunchKernelGGL(k_qkv_tattn, dim3(grid), dim3(512), QT_LDS, s, a);
       (void)hipStreamSynchronize(s);
-      std::vector<unsigned long long> h((size_t)grid * 8);
+      std::vector<unsigned long long> h((size_t)grid * 16);
       (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
       (void)hipFree(buf);
-      double sum[6] = {0}, tiles_n = 0, cyc = 0, ticks = 0;
-      for (int g = 0; g < grid; ++g) {
-        for (int i = 0; i < 6; ++i) { sum[i] += (double)h[8 * g + i]; cyc += (double)h[8 * g + i]; }
-        tiles_n += (double)h[8 * g + 6]; ticks += (double)h[8 * g + 7];
+      for (int half = 0; half < 2; ++half) {
+        double sum[6] = {0}, tiles_n = 0, cyc = 0, ticks = 0;
+        for (int g = 0; g < grid; ++g) {
+          const unsigned long long* d = &h[16 * (size_t)g + 8 * half];
+          for (int i = 0; i < 6; ++i) { sum[i] += (double)d[i]; cyc += (double)d[i]; }
+          tiles_n += (double)d[6]; ticks += (double)d[7];
+        }
+        const double ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;   // cycles per ns (100 MHz ticks = 10 ns)
+        fprintf(stderr, "[qt diag] half %d (wave %d): B J = %d, tiles %d on %d workgroups, clock %.2f GHz; per tile (us): k-loop %.2f  statistics -> registers %.2f  "
+                "plane writes %.2f  %s %.2f  %s %.2f  end barrier %.2f  | total %.2f\n", half, 4 * half, a.BJ, tiles, grid, ghz,
+                sum[0] / tiles_n / ghz / 1e3, sum[1] / tiles_n / ghz / 1e3, sum[2] / tiles_n / ghz / 1e3,
+                half ? "wait + query exchange + scores" : "query read + scores + softmax", sum[3] / tiles_n / ghz / 1e3,
+                half ? "softmax + products + outputs" : "products + outputs + prefetch issue", sum[4] / tiles_n / ghz / 1e3,
+                sum[5] / tiles_n / ghz / 1e3, cyc / tiles_n / ghz / 1e3);
       }
-      const double ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;   // cycles per ns (100 MHz ticks = 10 ns)
-      fprintf(stderr, "[qt diag] B J = %d, tiles %d on %d workgroups, clock %.2f GHz; per tile (us, wave 0): k-loop %.2f  statistics -> registers %.2f  "
-              "plane writes %.2f  query exchange + scores + softmax %.2f  products + outputs %.2f  end barrier %.2f  | total %.2f\n", a.BJ, tiles, grid, ghz,
-              sum[0] / tiles_n / ghz / 1e3, sum[1] / tiles_n / ghz / 1e3, sum[2] / tiles_n / ghz / 1e3, sum[3] / tiles_n / ghz / 1e3,
-              sum[4] / tiles_n / ghz / 1e3, sum[5] / tiles_n / ghz / 1e3, cyc / tiles_n / ghz / 1e3);
       return hipGetLastError();
     }
   }
