@@ -133,6 +133,9 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *   "fused_spatial"   1 (default) / 0: F16X3 flow, spatial blocks (17 joints of a frame, D = 512, 8 heads): the qkv GEMM of a group
  *                     of 15 frames keeps q / k / v in LDS and runs the frames' attention in the same kernel (S2S:67 + 73-83; the
  *                     q / k / v planes never go to HBM) / qkv GEMM and attention as two kernels.  Bit-identical either way.
+ *   "fused_temporal"  1 (default) / 0: the same for the temporal blocks where the frames of a joint fit one 256-row tile (193 <= T <= 255,
+ *                     D = 512, 8 heads): the qkv GEMM of one (batch, joint) group keeps K / V in LDS, exchanges the queries there and runs
+ *                     the group's T-key attention in the same kernel (S2S:67 + 73-83 for the per-joint groups) / two kernels.  Bit-identical.
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
