@@ -22,6 +22,7 @@
 // LDS map (160 KiB): [0, 56 K) stage 0 | [56 K, 158 K) stage 1, then the frame slots (+ the raw row-statistics block during the
 // k-loop) | 2 KiB of per-row LayerNorm statistics.
 #include "d3d_kernels.h"
+#include "qkv_fused_kloop.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -394,104 +395,14 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
     const int aoff = (wm * 128 + r16) * 128 + foff, boff = QS_AREG + (wn * 48 + r16) * 128 + foff;
     h8 bh[QS_NJ], bl[QS_NJ], ah[2], al[2];
     int issued_prev = st_issued;
-    // one phase (kernels_gemm_x3p.hip D3D_PHASE, WPF form): H = 0: m-tiles 0-3 of k-tile KT, issues A(KT+1) (and all of W(1), ahead of
-    // A(1), in a tile's first phase); H = 1: m-tiles 4-7, issues W(KT+2); the W fragments of KT+1 replace those of KT behind the
-    // last group's MFMA triples (W_AHEAD), the odd phase's first A pair is requested by the last group of the even phase
-#define QS_PHASE(KT, H, DO_A, W_FULL1, DO_W, W_AHEAD)                                                                    \
-    do {                                                                                                                 \
-      wait_vm(issued_prev);                                                                                              \
-      __builtin_amdgcn_s_barrier();                                                                                      \
-      __builtin_amdgcn_s_setprio(3);                                                                                     \
-      asm volatile("" : "+v"(lofs_) : : "memory");                                                                       \
-      const unsigned char* sb = lds + ((KT) & 1) * QS_STAGE;                                                             \
-      constexpr int G0 = (H) * 4, G1 = G0 + 4;                                                                           \
-      if ((H) == 0) {                                                                                                    \
-        ah[0] = *reinterpret_cast<const h8*>(sb + aoff);                                                                 \
-        al[0] = *reinterpret_cast<const h8*>(sb + (aoff ^ 64));                                                          \
-        if (W_FULL1) {                                                                                                   \
-          _Pragma("unroll") for (int j = 0; j < QS_NJ; ++j) {                                                            \
-            bh[j] = *reinterpret_cast<const h8*>(sb + boff + j * 2048);                                                  \
-            bl[j] = *reinterpret_cast<const h8*>(sb + ((boff + j * 2048) ^ 64));                                         \
-          }                                                                                                              \
-        }                                                                                                                \
-      }                                                                                                                  \
-      _Pragma("unroll") for (int g = G0; g < G1; ++g) {                                                                  \
-        if (g + 1 < (((H) == 0) ? QS_TM : G1)) {                                                                         \
-          ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                    \
-          al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                           \
-        }                                                                                                                \
-        if ((H) == 0) {                                                                                                  \
-          _Pragma("unroll") for (int pp = 0; pp < 2; ++pp) {                                                             \
-            const int sl = (g - G0) * 2 + pp;                                                                            \
-            if (W_FULL1) {                                                                                               \
-              if (sl < QS_BIT) QS_PIECE((KT) + 1, QS_AIT + sl);                                                          \
-              else if (sl < QS_AIT + QS_BIT) { if (DO_A) QS_PIECE((KT) + 1, sl - QS_BIT); }                              \
-            } else if (sl < QS_AIT) { if (DO_A) QS_PIECE((KT) + 1, sl); }                                                \
-          }                                                                                                              \
-        } else if (g - G0 < QS_BIT) {                                                                                    \
-          if (DO_W) QS_PIECE((KT) + 2, QS_AIT + (g - G0));                                                               \
-        }                                                                                                                \
-        const bool w_ahead_ = (H) == 1 && g == G1 - 1 && (W_AHEAD);                                                      \
-        _Pragma("unroll") for (int j = 0; j < QS_NJ; ++j) {                                                              \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                      \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
-          if (w_ahead_) {                                                                                                \
-            const unsigned char* sbn = lds + (((KT) + 1) & 1) * QS_STAGE;                                                \
-            bh[j] = *reinterpret_cast<const h8*>(sbn + boff + j * 2048);                                                 \
-            bl[j] = *reinterpret_cast<const h8*>(sbn + ((boff + j * 2048) ^ 64));                                        \
-          }                                                                                                              \
-        }                                                                                                                \
-        if (w_ahead_) {              /* MFMA triple, its W pair's successor, ...; the piece in between */                 \
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
-        } else if ((H) == 0 && g == G0 && (W_FULL1)) {   /* a tile's opening: fragments just ahead of their MFMAs */       \
-          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                             \
-        } else {                     /* 2 MFMAs, a read, 2 MFMAs, a read, 2 MFMAs, a piece, 1 MFMA, the other piece, 2 MFMAs */ \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                             \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
-        }                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (g - G0 == 0) __builtin_amdgcn_s_setprio(2);                                                                  \
-        else if (g - G0 == 1) __builtin_amdgcn_s_setprio(1);                                                             \
-        else __builtin_amdgcn_s_setprio(0);                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-      }                                                                                                                  \
-      if ((H) == 0) issued_prev = (DO_A) ? QS_AIT : 0;                                                                   \
-      else issued_prev = (DO_W) ? QS_BIT : 0;                                                                            \
-    } while (0)
-
-    QS_PHASE(0, 0, true, true, false, false);
-    QS_PHASE(0, 1, false, false, nk > 2 || has_next, nk > 1);
-    int kt = 1;
-    for (; kt + 2 < nk; ++kt) {
-      QS_PHASE(kt, 0, true, false, false, false);
-      QS_PHASE(kt, 1, false, false, true, true);
-    }
-    if (nk > 2) {   // k-tile nk - 2: A(nk - 1) of this tile, then W(0) of the next tile
-      QS_PHASE(kt, 0, true, false, false, false);
-      QS_PHASE(kt, 1, false, false, has_next, true);
-      ++kt;
-    }
+    // the k-loop: qkv_fused_kloop.h (shared with the other fused kernel), this kernel's constants and DMA pieces behind the QF_ names
+#define QF_STAGE QS_STAGE
+#define QF_NJ QS_NJ
+#define QF_TM QS_TM
+#define QF_AIT QS_AIT
+#define QF_BIT QS_BIT
+#define QF_PIECE(KTT, IT) QS_PIECE(KTT, IT)
+    QF_KLOOP_HEAD
     // ---- row statistics -> (rstd * out_scale, -mean rstd) per tile row, in front of the last k-tile: every wave reduces 32 rows (lanes
     // 0-31) in the shadow of its SIMD partner's MFMAs -- behind the k-loop this step was 1.1 us of a 38 us tile with half the waves
     // idle.  The raw partials landed long ago (the first counted wait of the tile retired them; phase barriers since).
@@ -513,10 +424,13 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
         srow[t] = make_float2(rstd * a.out_scale, -mean * rstd);
       }
     }
-    // k-tile nk - 1: A(0) of the next tile
-    QS_PHASE(kt, 0, has_next, false, false, false);
-    QS_PHASE(kt, 1, false, false, false, false);
-#undef QS_PHASE
+    QF_KLOOP_TAIL
+#undef QF_STAGE
+#undef QF_NJ
+#undef QF_TM
+#undef QF_AIT
+#undef QF_BIT
+#undef QF_PIECE
 #undef QS_PIECE
     __builtin_amdgcn_s_setprio(0);
     QS_STAMP(0);
