@@ -395,3 +395,26 @@ def test_fused_temporal_blocks_are_bit_identical_to_the_two_kernel_flow(T, B, fa
     again = eng.ddim_sample(x2d, nz).clone()
     assert torch.isfinite(fused).all() and eng.range_flags() == 0
     assert torch.equal(fused, plain) and torch.equal(fused, again)
+
+
+def test_fused_temporal_blocks_with_another_joint_count():
+    """The fused temporal kernel walks a group's frames by the joint stride: 21 joints (the spatial blocks then take the two-kernel
+    flow -- their fusion needs 17), T = 200, depth 2: against the CPU oracle inside the gate, and bit for bit the two-kernel flow."""
+    from oracle import d3d_oracle as orc
+    from diff3dhpe_amd.spec import DenoiserConfig
+    from diff3dhpe_amd.synth import synth_inputs
+    J, T = 21, 200
+    cfg = DenoiserConfig(num_frame=T, num_joints=J, embed_dim=512, depth=2)
+    net, diff = build_product(cfg, 34, sampling=2, precision="f16x3")
+    inp = {k: torch.from_numpy(v) for k, v in synth_inputs(2, T, J, seed=351).items()}
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eng.set_option("fused_temporal", 1)
+    fused = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_temporal", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_temporal", 1)
+    ref = orc.ddim_sample_loop(torch_sd(cfg, 34), orc.diffusion_tables("cosine", 1000), inp["x2d"], inp["noise"], num_timesteps=1000,
+                               sampling_timesteps=2, depth=cfg.depth)
+    assert torch.equal(fused, plain)
+    assert maxabs(fused, ref) <= GATE, maxabs(fused, ref)
