@@ -14,8 +14,10 @@
 // kernels_attn_x3.hip) + 32 KiB through which the queries are exchanged -- a wave of the GEMM holds 16 of the 64 head dims of 128 rows,
 // a wave of the attention needs all 64 dims of 32 rows -- in two halves of 128 rows, and which then serve as the eight 4 KiB output
 // patches.  No step barriers inside the attention (K and V are static, unlike the restaged planes of the stand-alone kernel): the
-// two waves of a SIMD drift through their MFMA and VALU steps out of phase by themselves (the second half starts an exchange later).
-// The next tile's first k-tile is requested once every wave is through its score step (K dead) and lands under the rest.
+// two waves of a SIMD drift through their MFMA and VALU steps out of phase by themselves (the second half starts an exchange later); the
+// halves meet at two LDS counters in a pad row of the V lo plane (key 255: T <= 255), not at workgroup barriers, which held the first
+// half at the second half's pace.  The next tile's first k-tile goes into the dead K planes, every wave's pieces issued by the first
+// half after its outputs (it idles there until the second half is through).  In-kernel stamps: "qt_diag" option.
 #include "d3d_kernels.h"
 #include "qkv_fused_kloop.h"
 
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
     }
     __syncthreads();                                   // B1: K, V, Q(half 0) written
     QT_STAMP(2);
-    // From here the two halves run separate instruction streams that meet the same three barriers (B2, B3, B4); from B3 on the two
+    // From here the two halves run separate instruction streams that meet at ONE barrier (B2) and two counters (B3', B4'); from then on the two
     // waves of a SIMD (w and w + 4) are about a step apart -- one in an MFMA step, one in a VALU step:
     //   half 0: read Q | B2 | scores, softmax                          | B4' (no wait) | products, outputs, both halves' prefetch pieces
     //   half 1:        | B2 | write Q(half 1) | B3' | read Q, scores | raise B4' | softmax, products, outputs
