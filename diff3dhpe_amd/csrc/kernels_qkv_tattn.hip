@@ -153,14 +153,18 @@ __device__ __forceinline__ void split_pair_v(float e0, float e1, float k, unsign
 }
 
 constexpr int QT_NKT = 8;
+#ifndef QT_PB1
+#define QT_PB1 1   // the second half.s steps run one priority level above the first half.s: it is the one that is behind (-0.7 % per launch)
+#endif
 // Scores (qt_scores) and softmax (qt_softmax) of one wave's 32 queries against the T keys in the K planes: the score and softmax steps
 // of k_attn_temporal_x3s (same MFMAs in the same order, same arithmetic).  After qt_softmax sacc[kt] holds the packed hi (slots 0-7) /
 // lo (8-15) halves of 1024 e, l the row sum.
+template <int PB>
 __device__ __forceinline__ void qt_scores(unsigned char* const lds, int lane, const h8 (&qh)[4], const h8 (&ql)[4], f32x16 (&sacc)[QT_NKT]) {
   constexpr int NKT = QT_NKT, PLANE = QT_PLANE;
   const int r = lane & 31, h = lane >> 5;
   unsigned char* const sKh = lds + QT_K;
-  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_setprio(2 + PB);
   {
     h8 kfh[3], kfl[3];
     unsigned kaddr[4];
@@ -187,8 +191,9 @@ __device__ __forceinline__ void qt_scores(unsigned char* const lds, int lane, co
       __builtin_amdgcn_sched_barrier(0);
     });
   }
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(PB);
 }
+template <int PB>
 __device__ __forceinline__ void qt_softmax(int lane, int T, f32x16 (&sacc)[QT_NKT], float& l) {
   constexpr int NKT = QT_NKT;
   const int h = lane >> 5;
@@ -228,6 +233,7 @@ __device__ __forceinline__ void qt_softmax(int lane, int T, f32x16 (&sacc)[QT_NK
 }
 
 // Products, output arithmetic and stores of one wave's 32 queries: the product and output steps of k_attn_temporal_x3s.
+template <int PB>
 __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, int wave, int lane, int T, int J, int D, const f32x16 (&sacc)[QT_NKT],
                                                     float l, _Float16* out_unit, unsigned* rw) {
   constexpr int NKT = QT_NKT, PLANE = QT_PLANE;
@@ -236,7 +242,7 @@ __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, in
   unsigned char* const sVl = lds + QT_V + PLANE;
   unsigned char* const patch = lds + QT_Q + wave * 4096;
   const int tq = 32 * wave + r;
-  __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(1 + PB);
   f32x16 oacc[2];
 #pragma unroll
   for (int q = 0; q < 16; ++q) { oacc[0][q] = 0.f; oacc[1][q] = 0.f; }
@@ -285,7 +291,7 @@ __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, in
       __builtin_amdgcn_sched_barrier(0);
     });
   }
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(PB);
   // v_query (this wave's own rows of V)
   h4 vqh[8], vql[8];
   {
@@ -600,15 +606,15 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         h8 qh[4], ql[4];
         read_q(qh, ql);
         __builtin_amdgcn_s_barrier();                  // B2: half 0 holds its queries: the exchange planes may be rewritten
-        qt_scores(lds, lane, qh, ql, sacc);
+        qt_scores<0>(lds, lane, qh, ql, sacc);
       }
-      qt_softmax(lane, T, sacc, lsum);
+      qt_softmax<0>(lane, T, sacc, lsum);
       // B4': the second half is through its scores -- it holds its queries (the exchange planes become patches) and K is dead (the
       // prefetch below); a counter it raised long before this point, not a barrier it would have to wait at
       while (reinterpret_cast<volatile unsigned*>(xsync)[1] < 4u) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
       QT_STAMP(3);
-      qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
+      qt_products_outputs<0>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
       // the next tile's first k-tile into the dead K planes: both halves' pieces from this half, which is a step ahead and would idle
       if (more) { stage_first(bjn, hdn, wave); stage_first(bjn, hdn, wave + 4); }
       QT_STAMP(4);
@@ -626,13 +632,13 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       {
         h8 qh[4], ql[4];
         read_q(qh, ql);
-        qt_scores(lds, lane, qh, ql, sacc);
+        qt_scores<QT_PB1>(lds, lane, qh, ql, sacc);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) atomicAdd(xsync + 1, 1u);         // B4'
       QT_STAMP(3);
-      qt_softmax(lane, T, sacc, lsum);
-      qt_products_outputs(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
+      qt_softmax<QT_PB1>(lane, T, sacc, lsum);
+      qt_products_outputs<QT_PB1>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
       QT_STAMP(4);
     }
     bj = bjn; hd = hdn;
