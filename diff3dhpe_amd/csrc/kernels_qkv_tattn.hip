@@ -154,7 +154,7 @@ __device__ __forceinline__ void split_pair_v(float e0, float e1, float k, unsign
 
 constexpr int QT_NKT = 8;
 #ifndef QT_PB1
-#define QT_PB1 1   // the second half.s steps run one priority level above the first half.s: it is the one that is behind (-0.7 % per launch)
+#define QT_PB1 1   // the second half's steps run one priority level above the first half's: it is the one that is behind (-0.7 % per launch)
 #endif
 // Scores (qt_scores) and softmax (qt_softmax) of one wave's 32 queries against the T keys in the K planes: the score and softmax steps
 // of k_attn_temporal_x3s (same MFMAs in the same order, same arithmetic).  After qt_softmax sacc[kt] holds the packed hi (slots 0-7) /
