@@ -258,7 +258,8 @@ template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool CHECK>
 __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch, unsigned char* lds_x, const float* __restrict__ bias,
                                               float* Ct, _Float16* Cht, _Float16* Clt, const _Float16* Rpt,
                                               const float* __restrict__ csum, float* st_out, int mt0, int nt0, int rbase, int lane,
-                                              int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE, unsigned* rw) {
+                                              int M, int N, int qcols, int gl, int gh, const float P_OUT_SCALE, unsigned* rw,
+                                              float2* statp = nullptr) {
   static_assert(EPI != EPI_RESIDUAL || (FX & FX_RP), "the 8-column epilogue takes its residual from planes");
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
   const int rrow = lane >> 3, rc8 = lane & 7;          // read side
@@ -348,7 +349,10 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
         if (ok) sums8(v, sm, sq);
         sm = row8_sum(sm);
         sq = row8_sum(sq);
-        if (rc8 == 0 && m < M) *reinterpret_cast<float2*>(st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
+        // the row's partial goes to a wave-private LDS row first: twelve 8-byte stores of 8 lanes each per wave and tile cost the wave as
+        // many vector-memory issue slots as its 16-byte plane stores do; they leave below as two instructions of 64 / 32 rows
+        if (statp) { if (rc8 == 0) statp[16 * i + row] = make_float2(sm, sq); }
+        else if (rc8 == 0 && m < M) *reinterpret_cast<float2*>(st_out + 2 * ((size_t)m * npart + (nt0 >> 6))) = make_float2(sm, sq);
         if (!ok) continue;
       }
       if constexpr (OUTSPLIT == 3) {
@@ -378,6 +382,17 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
       __builtin_amdgcn_sched_barrier(0);
     } else if (i & 1) {
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr ((FX & FX_SO) != 0) {
+    if (statp) {
+      D3D_PATCH_FENCE();   // (rows written by other lanes)
+#pragma unroll
+      for (int r0 = 0; r0 < 16 * TM; r0 += 64) {
+        const int rr = r0 + lane;
+        if (rr < 16 * TM && (rr >> 4) >= gl && (rr >> 4) < gh && mt0 + rr < M)
+          *reinterpret_cast<float2*>(st_out + 2 * ((size_t)(mt0 + rr) * npart + (nt0 >> 6))) = statp[rr];
+      }
     }
   }
   if constexpr (OUTSPLIT != 0 && OUTSPLIT != 3 && !(FX & FX_SO)) range_note(rw, amax * osc);

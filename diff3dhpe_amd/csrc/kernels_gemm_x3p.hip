@@ -623,6 +623,8 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   unsigned long long st_c1 = 0, st_r1 = 0;
   if (diag) { st_c1 = __builtin_amdgcn_s_memtime(); st_r1 = __builtin_amdgcn_s_memrealtime(); }
   float* patch = reinterpret_cast<float*>(lds + (PERSIST ? STAGE : 0)) + wave * (2 * 16 * 64);
+  // row-statistics form: a wave-private kilobyte behind the patches collects the wave's (sum, sum of squares) rows (x3q_epilogue8)
+  float2* const statp = ((FX & FX_SO) && !(FX & FX_LNF)) ? reinterpret_cast<float2*>(lds_x) + wave * 128 : nullptr;
   const _Float16* Rpt = (FX & FX_RP) ? fx.Rp + 2 * tbase : nullptr;
   constexpr bool PLANES = (OUTSPLIT != 0 || (FX & FX_RP)) && !(EPI == EPI_RESIDUAL && !(FX & FX_RP));
   const bool full = FULL || (m0 + BM <= M && n0 + BN <= N);
@@ -651,13 +653,13 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       // (the row-statistics form keeps one copy per instantiation: with two copies under the branch its accumulators spill)
       if constexpr (FULL)
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range, statp);
       else if (full && !(FX & FX_SO))
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, false>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
+                                                           mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range, statp);
       else
         x3q_epilogue8<TM, WM, WN, EPI, OUTSPLIT, FX, true>(acc, patch, lds_x, bias, Ct, Cht, Clt, Rpt, fx.csum, fx.st_out, mt0, nt0,
-                                                          mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range);
+                                                          mt0 - m0, lane, M, N, qcols, gl, gh, fx.out_scale, fx.range, statp);
       done = true;
     }
   }
@@ -837,6 +839,7 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
     tail.st_in = fold->st_in; tail.st_np = fold->st_np; tail.csum = fold->csum; tail.eps = fold->eps;
     tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out;
     if (fx & FX_LNF) lds_bytes += (size_t)BM * 8;   // row statistics beyond the operand stages
+    else if (fx & FX_SO) lds_bytes += 8 * 1024;     // a kilobyte per wave for the rows' statistics (x3q_epilogue8)
     if ((fx & FX_LNF) && (!fold->csum || fold->st_np < 1)) return hipErrorInvalidValue;
   }
 #define D3D_X3Q_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
@@ -908,6 +911,7 @@ static hipError_t launch_x3q_persist(const _Float16* Ap, const _Float16* Wp, con
     tail.st_in = fold->st_in; tail.st_np = fold->st_np; tail.csum = fold->csum; tail.eps = fold->eps;
     tail.Rp = (const _Float16*)fold->Rp; tail.st_out = fold->st_out;
     if (fx & FX_LNF) lds_bytes += (size_t)BM * 8 + 16384;   // (rstd, -mean rstd) per row + the raw partials staged by LDS-DMA
+    else if (fx & FX_SO) lds_bytes += 8 * 1024;              // a kilobyte per wave for the rows' statistics (x3q_epilogue8)
     if ((fx & FX_LNF) && (!fold->csum || fold->st_np < 1)) return hipErrorInvalidValue;
   }
 #define D3D_X3P_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
