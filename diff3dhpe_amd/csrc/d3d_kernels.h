@@ -164,6 +164,11 @@ hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, cons
                             int st_np, float eps, int w_exp, void* out_x3, int M, int K, int J, int D, int H, hipStream_t s);
 // kernels_qkv_tattn.hip: the temporal counterpart -- the LayerNorm-folded qkv GEMM of one (batch, joint) group (T in 193..256 frames) x one
 // head with the T-key attention of k_attn_temporal_x3s run from LDS; the same tile-ordered weight / bias / csum as launch_qkv_sattn.
+// kernels_fc1_x3.hip: fc1 (LayerNorm-folded, GELU, accumulator-order pair output) on the hand-specialised k-loop of the fused kernels,
+// whole 256 x 256 tiles only (buffers padded to 256 rows, finite pad rows); bit-identical to launch_linear_x3p's form.
+bool fc1_x3_ok(int N, int K);
+hipError_t launch_fc1_x3(const void* Apair, const void* Wpair, const float* bias_f, const float* csum, const float* st_in, int st_np,
+                         float eps, int w_exp, void* out_pair, int M, int N, int K, hipStream_t s);
 bool qkv_tattn_ok(int T, int J, int D, int H, int K);
 void set_qkv_tattn_diag(int on);   // "qt_diag": in-kernel stamp report of every 50th launch
 hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, const float* bias_to, const float* csum_to, const float* st_in,

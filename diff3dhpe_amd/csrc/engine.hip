@@ -78,6 +78,8 @@ struct d3d_engine {
   bool opt_fused_spatial = true;
   // "fused_temporal": the same for the temporal blocks where the frame count fits one tile (T in 193..256: kernels_qkv_tattn.hip)
   bool opt_fused_temporal = true;
+  // "fc1_kernel": fc1 on its own kernel (kernels_fc1_x3.hip) where the launch fills the chip for a few rounds; bit-identical
+  bool opt_fc1_kernel = true;
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
@@ -368,7 +370,10 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   TRACE(0, 1, 0, XP, MDb);
   TRACE(0, 1, 1, w.ST1, (size_t)M * 8);
   const bool fused_sp = e->opt_fused_spatial && qkv_sattn_ok(J, D, e->H, D) && e->blk[0].qkv_f3h != nullptr;
-  if (fused_sp) {   // the fused spatial kernel stages (and multiplies) up to 255 rows beyond the matrix: finite values there
+  // the dedicated fc1 kernel runs whole 256-row tiles without guards (a launch of at least two rounds of tiles; smaller ones keep the
+  // template's 256 x 128 / sliced forms)
+  const bool fc1_own = e->opt_fc1_kernel && fc1_x3_ok(e->Dm, D) && (size_t)((M + 255) / 256) * (size_t)(e->Dm / 256) >= 512;
+  if (fused_sp || fc1_own) {   // the fused spatial kernel / the fc1 kernel stage (and multiply) rows beyond the matrix: finite values there
     const size_t Mp = (size_t)((reinterpret_cast<char*>(w.HN) - reinterpret_cast<char*>(w.X)) / ((size_t)D * 4));   // rows of w.X as carved
     if (Mp > (size_t)M) HIP_TRY(hipMemsetAsync(XP + (size_t)M * 2 * D, 0, (Mp - (size_t)M) * 2 * D * sizeof(uint16_t), s));
   }
@@ -421,7 +426,12 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     {  // hidden = gelu(norm2(x) W1^T + b1), LayerNorm folded
       X3Fold f{};
       f.st_in = w.ST2; f.st_np = np2; f.csum = bw.fc1_cs; f.eps = 1e-6f;
-      HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fe, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
+      if (fc1_own) {
+        Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)e->Dm * D, 4.0 * ((double)M * D + (double)e->Dm * D + (double)M * e->Dm), s, D3D_KC_LINEAR_FC1);
+        HIP_TRY(launch_fc1_x3(XP, bw.fc1_f3, bw.fc1_fb, bw.fc1_cs, w.ST2, np2, 1e-6f, bw.fc1_fe, HIDx, M, e->Dm, D, s));
+      } else {
+        HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fe, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
+      }
     }
     TRACE(k, 5, 0, HIDx, (size_t)M * e->Dm * 4);
     const float* pn_g = temporal ? e->tn_g : e->sn_g;
@@ -1263,6 +1273,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;
   else if (k == "fused_spatial") e->opt_fused_spatial = value != 0;
   else if (k == "fused_temporal") e->opt_fused_temporal = value != 0;
+  else if (k == "fc1_kernel") e->opt_fc1_kernel = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
     e->opt_streams = (int)value;

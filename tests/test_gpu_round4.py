@@ -418,3 +418,25 @@ def test_fused_temporal_blocks_with_another_joint_count():
                                sampling_timesteps=2, depth=cfg.depth)
     assert torch.equal(fused, plain)
     assert maxabs(fused, ref) <= GATE, maxabs(fused, ref)
+
+
+# ------------------------------------------------------------------------------------------------ dedicated fc1 kernel
+@pytest.mark.parametrize("T,B,family", [(243, 32, "uniform"), (243, 33, "trainedlike"), (81, 96, "uniform")])
+def test_fc1_kernel_is_bit_identical_to_the_template_form(T, B, family):
+    """"fc1_kernel" (default): fc1 on its own kernel (kernels_fc1_x3.hip: the hand-specialised k-loop of the fused kernels, whole 256-row
+    tiles over padded buffers) from two rounds of tiles on; same MFMAs in the same order and the template's own epilogue function: bit
+    for bit the token GEMM's LN-folded GELU form.  Ragged last M-tile (rows beyond the matrix are staged and multiplied, never read
+    back), NaN-filled workspace, the range guard silent."""
+    cfg = cfg_full(T)
+    _, diff = _product(cfg, 11 if family == "trainedlike" else 5, "f16x3", sampling=1, family=family)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(B, T, 79)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eng.set_option("fc1_kernel", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fc1_kernel", 1)
+    eng._workspace(B).view(torch.float32).fill_(float("nan"))
+    eng.range_flags(clear=True)
+    own = eng.ddim_sample(x2d, nz).clone()
+    assert torch.isfinite(own).all() and eng.range_flags() == 0
+    assert torch.equal(own, plain)
