@@ -136,6 +136,9 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *   "fused_temporal"  1 (default) / 0: the same for the temporal blocks where the frames of a joint fit one 256-row tile (193 <= T <= 255,
  *                     D = 512, 8 heads): the qkv GEMM of one (batch, joint) group keeps K / V in LDS, exchanges the queries there and runs
  *                     the group's T-key attention in the same kernel (S2S:67 + 73-83 for the per-joint groups) / two kernels.  Bit-identical.
+ *   "fc1_kernel"      1 (default) / 0: fc1 (LayerNorm-folded, GELU) on its own kernel -- the hand-specialised k-loop of the fused kernels
+ *                     with the token GEMM's own epilogue function, from two rounds of 256 x 256 tiles on -- / as a form of the token GEMM.
+ *                     Bit-identical.
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
