@@ -166,6 +166,11 @@ hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, cons
 // head with the T-key attention of k_attn_temporal_x3s run from LDS; the same tile-ordered weight / bias / csum as launch_qkv_sattn.
 // kernels_fc1_x3.hip: fc1 (LayerNorm-folded, GELU, accumulator-order pair output) on the hand-specialised k-loop of the fused kernels,
 // whole 256 x 256 tiles only (buffers padded to 256 rows, finite pad rows); bit-identical to launch_linear_x3p's form.
+// kernels_proj_x3.hip: proj (plane residual in place + row statistics) likewise, whole 192 x 256 tiles (M % 192 == 0: the caller runs the
+// remaining rows through launch_linear_x3p); bit-identical to launch_linear_x3p's form.
+bool proj_x3_ok(int N, int K);
+hipError_t launch_proj_x3(const void* Apair, const void* Wpair, const float* bias, void* Xpair, float* st_out, int w_exp, int M, int N, int K,
+                          hipStream_t s);
 bool fc1_x3_ok(int N, int K);
 hipError_t launch_fc1_x3(const void* Apair, const void* Wpair, const float* bias_f, const float* csum, const float* st_in, int st_np,
                          float eps, int w_exp, void* out_pair, int M, int N, int K, hipStream_t s);

@@ -80,6 +80,8 @@ struct d3d_engine {
   bool opt_fused_temporal = true;
   // "fc1_kernel": fc1 on its own kernel (kernels_fc1_x3.hip) where the launch fills the chip for a few rounds; bit-identical
   bool opt_fc1_kernel = true;
+  // "proj_kernel": the same for proj (kernels_proj_x3.hip: whole 192-row tiles; the rows behind the last whole tile stay with the template)
+  bool opt_proj_kernel = true;
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
@@ -419,7 +421,19 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     {  // x += attn Wproj^T + b, plane to plane in place; row statistics of the new x for the folded norm2
       X3Fold f{};
       f.Rp = XP; f.st_out = w.ST2;
-      HIP_TRY(gemm(AOx, bw.proj_x3, bw.proj_e, bw.projb, nullptr, XP, nullptr, 2, D, D, EPI_RESIDUAL, 0, f));
+      const int Mw = (M / 192) * 192;     // rows in whole 192-row tiles
+      if (e->opt_proj_kernel && proj_x3_ok(D, D) && (size_t)(Mw / 192) * (size_t)(D / 256) >= 512) {
+        Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)D * D, 4.0 * ((double)M * D + (double)D * D + 2.0 * M * D), s, D3D_KC_LINEAR_PROJ);
+        HIP_TRY(launch_proj_x3(AOx, bw.proj_x3, bw.projb, XP, w.ST2, bw.proj_e, Mw, D, D, s));
+        if (M > Mw) {   // the ragged rest: the template's checked forms, on the sub-matrix behind the whole tiles
+          X3Fold fr{};
+          fr.Rp = XP + (size_t)Mw * 2 * D; fr.st_out = w.ST2 + (size_t)Mw * np2 * 2;
+          HIP_TRY(launch_linear_x3p(AOx + (size_t)Mw * 2 * D, bw.proj_x3, bw.projb, nullptr, nullptr, XP + (size_t)Mw * 2 * D, nullptr, M - Mw, D, D,
+                                    EPI_RESIDUAL, 2, 0, 0, s, &fr, bw.proj_e));
+        }
+      } else {
+        HIP_TRY(gemm(AOx, bw.proj_x3, bw.proj_e, bw.projb, nullptr, XP, nullptr, 2, D, D, EPI_RESIDUAL, 0, f));
+      }
     }
     TRACE(k, 4, 0, XP, MDb);
     TRACE(k, 4, 1, w.ST2, (size_t)M * 8 * np2);
@@ -1274,6 +1288,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   else if (k == "fused_spatial") e->opt_fused_spatial = value != 0;
   else if (k == "fused_temporal") e->opt_fused_temporal = value != 0;
   else if (k == "fc1_kernel") e->opt_fc1_kernel = value != 0;
+  else if (k == "proj_kernel") e->opt_proj_kernel = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
     e->opt_streams = (int)value;

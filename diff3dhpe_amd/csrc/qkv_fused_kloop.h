@@ -1,5 +1,5 @@
 // The k-loop of the two fused qkv + attention kernels (kernels_qkv_sattn.hip, kernels_qkv_tattn.hip): the two-phase persistent loop of
-// kernels_gemm_x3p.hip (D3D_PHASE, WPF form) hand-specialised for a 256 x 192 x 32 stage -- eight waves (2 x 4) of 128 rows x 48 columns,
+// kernels_gemm_x3p.hip (D3D_PHASE, WPF form) hand-specialised for whole tiles -- eight waves (2 x 4) of 8 QF_TM rows x 16 QF_NJ columns (256 x 192 / 256 x 256 / 192 x 256 stages),
 // W fragments a phase ahead, counted vmcnt waits.  Included INSIDE the tile loop of a kernel that has defined, in scope:
 //   QF_STAGE, QF_NJ, QF_TM, QF_AIT, QF_BIT (constants), QF_PIECE(KTT, IT) (issues DMA piece IT of k-tile KTT), wait_vm(n),
 //   lds, acc[QF_TM][QF_NJ], aoff, boff, ah[2], al[2], bh[QF_NJ], bl[QF_NJ], lofs_, issued_prev, nk, has_next.
@@ -17,7 +17,9 @@
       __builtin_amdgcn_s_setprio(3);                                                                                     \
       asm volatile("" : "+v"(lofs_) : : "memory");                                                                       \
       const unsigned char* sb = lds + ((KT) & 1) * QF_STAGE;                                                             \
-      constexpr int G0 = (H) * 4, G1 = G0 + 4;                                                                           \
+      constexpr int G0 = (H) * (QF_TM / 2), G1 = G0 + QF_TM / 2;                                                         \
+      constexpr int SPG_ = (QF_AIT + QF_BIT + QF_TM / 2 - 1) / (QF_TM / 2);   /* piece slots per group, even phase (2 at QF_TM 8) */ \
+      constexpr int WPG_ = (QF_BIT + QF_TM / 2 - 1) / (QF_TM / 2);             /* W pieces per group, odd phase (1 at QF_TM 8) */    \
       if ((H) == 0) {                                                                                                    \
         ah[0] = *reinterpret_cast<const h8*>(sb + aoff);                                                                 \
         al[0] = *reinterpret_cast<const h8*>(sb + (aoff ^ 64));                                                          \
@@ -33,7 +35,7 @@
           ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + aoff + (g + 1) * 2048);                                    \
           al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sb + ((aoff + (g + 1) * 2048) ^ 64));                           \
         }                                                                                                                \
-        if ((H) == 0) {                                                                                                  \
+        if ((H) == 0 && SPG_ == 2) {                                                                                     \
           _Pragma("unroll") for (int pp = 0; pp < 2; ++pp) {                                                             \
             const int sl = (g - G0) * 2 + pp;                                                                            \
             if (W_FULL1) {                                                                                               \
@@ -41,8 +43,23 @@
               else if (sl < QF_AIT + QF_BIT) { if (DO_A) QF_PIECE((KT) + 1, sl - QF_BIT); }                              \
             } else if (sl < QF_AIT) { if (DO_A) QF_PIECE((KT) + 1, sl); }                                                \
           }                                                                                                              \
-        } else if (g - G0 < QF_BIT) {                                                                                    \
-          if (DO_W) QF_PIECE((KT) + 2, QF_AIT + (g - G0));                                                               \
+        } else if ((H) == 0) {       /* (three m-tile groups per phase: more slots per group) */                          \
+          _Pragma("unroll") for (int pp = 0; pp < SPG_; ++pp) {                                                          \
+            const int sl = (g - G0) * SPG_ + pp;                                                                         \
+            if (W_FULL1) {                                                                                               \
+              if (sl < QF_BIT) QF_PIECE((KT) + 1, QF_AIT + sl);                                                          \
+              else if (sl < QF_AIT + QF_BIT) { if (DO_A) QF_PIECE((KT) + 1, sl - QF_BIT); }                              \
+            } else if (sl < QF_AIT) { if (DO_A) QF_PIECE((KT) + 1, sl); }                                                \
+          }                                                                                                              \
+        } else if (WPG_ == 1) {                                                                                          \
+          if (g - G0 < QF_BIT) {                                                                                         \
+            if (DO_W) QF_PIECE((KT) + 2, QF_AIT + (g - G0));                                                             \
+          }                                                                                                              \
+        } else {                                                                                                         \
+          _Pragma("unroll") for (int pp = 0; pp < WPG_; ++pp) {                                                          \
+            const int wp = (g - G0) * WPG_ + pp;                                                                         \
+            if (wp < QF_BIT) { if (DO_W) QF_PIECE((KT) + 2, QF_AIT + wp); }                                              \
+          }                                                                                                              \
         }                                                                                                                \
         const bool w_ahead_ = (H) == 1 && g == G1 - 1 && (W_AHEAD);                                                      \
         _Pragma("unroll") for (int j = 0; j < QF_NJ; ++j) {                                                              \

@@ -440,3 +440,23 @@ def test_fc1_kernel_is_bit_identical_to_the_template_form(T, B, family):
     own = eng.ddim_sample(x2d, nz).clone()
     assert torch.isfinite(own).all() and eng.range_flags() == 0
     assert torch.equal(own, plain)
+
+
+@pytest.mark.parametrize("T,B,family", [(243, 32, "uniform"), (243, 33, "trainedlike"), (81, 97, "uniform")])
+def test_proj_kernel_is_bit_identical_to_the_template_form(T, B, family):
+    """"proj_kernel" (default): proj on its own kernel (kernels_proj_x3.hip: whole 192-row tiles on the hand-specialised k-loop, the
+    template's own epilogue function; the rows behind the last whole tile through the template's checked forms): bit for bit the
+    token GEMM's plane-residual + row-statistics form.  Token counts that are and are not multiples of 192, NaN-filled workspace."""
+    cfg = cfg_full(T)
+    _, diff = _product(cfg, 11 if family == "trainedlike" else 5, "f16x3", sampling=1, family=family)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(B, T, 80)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eng.set_option("proj_kernel", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("proj_kernel", 1)
+    eng._workspace(B).view(torch.float32).fill_(float("nan"))
+    eng.range_flags(clear=True)
+    own = eng.ddim_sample(x2d, nz).clone()
+    assert torch.isfinite(own).all() and eng.range_flags() == 0
+    assert torch.equal(own, plain)
