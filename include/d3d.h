@@ -139,6 +139,7 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *   "fc1_kernel"      1 (default) / 0: fc1 (LayerNorm-folded, GELU) on its own kernel -- the hand-specialised k-loop of the fused kernels
  *                     with the token GEMM's own epilogue function, from two rounds of 256 x 256 tiles on -- / as a form of the token GEMM.
  *                     Bit-identical.
+ *   "proj_kernel"     1 (default) / 0: the same for proj (192 x 256 tiles; rows behind the last whole tile through the token GEMM).
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
