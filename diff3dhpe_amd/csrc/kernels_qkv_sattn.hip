@@ -104,6 +104,12 @@ __device__ __forceinline__ u32x4 patch_rd(const unsigned char* patch, int row, i
   return *reinterpret_cast<const u32x4_alias*>(patch + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
+// Diagnostic builds only (-DQS_ABL=n, wrong results; experiments/lds_conflict_attribution.sh): 1 no slot writes, 2 no attention units,
+// 4 no output patches -- which LDS accesses the bank-conflict counter belongs to.
+#ifndef QS_ABL
+#define QS_ABL 0
+#endif
+
 struct QsArgs {
   const _Float16* Ap;      // residual stream, pair layout [>= 255 mtiles + 1 rows][2 K] of 8 x
   const _Float16* Wp;      // folded qkv weight W diag(gamma), pair layout, 2^k w, rows in TILE order: row 192 h + 48 wn + 16 part + x
@@ -265,11 +271,12 @@ __device__ __forceinline__ void qs_attention(unsigned char* slot, int lane, _Flo
       split_pair(o4[0], o4[1], 8.0f, h0, l0);
       split_pair(o4[2], o4[3], 8.0f, h1, l1);
       const h4 oh = __builtin_bit_cast(h4, make_uint2(h0, h1)), ol = __builtin_bit_cast(h4, make_uint2(l0, l1));
-      patch_wr(patch, r, h, g4, oh, ol);
+      if (!(QS_ABL & 4)) patch_wr(patch, r, h, g4, oh, ol);
+      else asm volatile("" ::"v"(oh), "v"(ol));
     }
     asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
 #pragma unroll
-    for (int it = 0; it < 3; ++it) pw[dt * 3 + it] = patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
+    for (int it = 0; it < 3; ++it) pw[dt * 3 + it] = (QS_ABL & 4) ? u32x4{0u, 0u, 0u, 0u} : patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
     asm volatile("" ::: "memory");
   }
   _Float16* const pw_ptr = out_row0 + (size_t)(lane >> 3) * 2 * D + 8 * (lane & 7);
@@ -484,15 +491,17 @@ __global__ __launch_bounds__(512) void k_qkv_sattn(QsArgs a) {
           unsigned char* const ph = j == 0 ? pkq + QS_PQ : (j == 1 ? pkq + QS_PK : pv + QS_PV);
           u32x2_alias hv, lv;
           hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
-          *reinterpret_cast<u32x2_alias*>(ph) = hv;
-          *reinterpret_cast<u32x2_alias*>(ph + QS_PLANE) = lv;
+          if (!(QS_ABL & 1)) {
+            *reinterpret_cast<u32x2_alias*>(ph) = hv;
+            *reinterpret_cast<u32x2_alias*>(ph + QS_PLANE) = lv;
+          }
         }
       }
     };
     auto attend = [&](int pass) {
       const int fr = (wave & 3) + 4 * pass + 8 * (wave >> 2);             // frame of the tile this wave takes: slot = wave
       const long long gf = (long long)mt * QS_FPT + fr;
-      if (fr < QS_FPT && gf < a.F)
+      if (!(QS_ABL & 2) && fr < QS_FPT && gf < a.F)
         qs_attention(lds + QS_QKV + wave * QS_SLOT, lane, a.out + ((size_t)gf * QS_J) * 2 * a.D + hd * 128, a.D);
     };
     write_pass(0);

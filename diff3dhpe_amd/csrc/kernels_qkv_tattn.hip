@@ -159,6 +159,12 @@ constexpr int QT_NKT = 8;
 // Scores (qt_scores) and softmax (qt_softmax) of one wave's 32 queries against the T keys in the K planes: the score and softmax steps
 // of k_attn_temporal_x3s (same MFMAs in the same order, same arithmetic).  After qt_softmax sacc[kt] holds the packed hi (slots 0-7) /
 // lo (8-15) halves of 1024 e, l the row sum.
+// Diagnostic builds only (-DQT_ABL=n, wrong results; experiments/lds_conflict_attribution.sh): 1 no plane / exchange writes, 2 no score
+// step (K fragment reads), 4 no V fragment reads in the product step, 8 no output patches, 16 no query fragment reads.
+#ifndef QT_ABL
+#define QT_ABL 0
+#endif
+
 template <int PB>
 __device__ __forceinline__ void qt_scores(unsigned char* const lds, int lane, const h8 (&qh)[4], const h8 (&ql)[4], f32x16 (&sacc)[QT_NKT]) {
   constexpr int NKT = QT_NKT, PLANE = QT_PLANE;
@@ -260,6 +266,7 @@ __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, in
     auto vread = [&](auto jc, s4v(&f)[8]) {
       constexpr int off = decltype(jc)::value * 2048;
       static_assert(off + PLANE < 65536, "ds offset field");
+      if constexpr ((QT_ABL & 4) != 0) return;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         lds_read_tr16_b64<off>(f[4 * dt], vaddr[2 * dt]);
@@ -331,11 +338,12 @@ __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, in
         split_pair_v(o8[0], o8[1], 1.0f, h0, l0);
         split_pair_v(o8[2], o8[3], 1.0f, h1, l1);
         const h4 oh = __builtin_bit_cast(h4, make_uint2(h0, h1)), ol = __builtin_bit_cast(h4, make_uint2(l0, l1));
-        patch_wr(patch, r, h, g4, oh, ol);
+        if (!(QT_ABL & 8)) patch_wr(patch, r, h, g4, oh, ol);
+        else asm volatile("" ::"v"(oh), "v"(ol));
       }
       asm volatile("" ::: "memory");     // (the rows read back were written by other lanes)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) po[dt * 4 + it] = patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
+      for (int it = 0; it < 4; ++it) po[dt * 4 + it] = (QT_ABL & 8) ? u32x4{0u, 0u, 0u, 0u} : patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
       asm volatile("" ::: "memory");
     }
     if (tq < T && amax > X3_HALF_MAX) range_raise(rw, RANGE_BIT_ACT);
@@ -560,8 +568,10 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
           else { ph = lds + QT_V + vswz(R, chunk) + half8; pstride = QT_PLANE; }
           u32x2_alias hv, lv;
           hv[0] = h0; hv[1] = h1; lv[0] = l0; lv[1] = l1;
-          *reinterpret_cast<u32x2_alias*>(ph) = hv;
-          *reinterpret_cast<u32x2_alias*>(ph + pstride) = lv;
+          if (!(QT_ABL & 1)) {
+            *reinterpret_cast<u32x2_alias*>(ph) = hv;
+            *reinterpret_cast<u32x2_alias*>(ph + pstride) = lv;
+          }
         }
       }
     };
@@ -593,6 +603,7 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       const int r = lane & 31, h = lane >> 5;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+        if (QT_ABL & 16) continue;
         const int qo = kswz(32 * (wave & 3) + r, 2 * ks + h);
         qh[ks] = *reinterpret_cast<const h8*>(lds + QT_Q + qo);
         ql[ks] = *reinterpret_cast<const h8*>(lds + QT_Q + 128 * 128 + qo);
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         h8 qh[4], ql[4];
         read_q(qh, ql);
         __builtin_amdgcn_s_barrier();                  // B2: half 0 holds its queries: the exchange planes may be rewritten
-        qt_scores<0>(lds, lane, qh, ql, sacc);
+        if (!(QT_ABL & 2)) qt_scores<0>(lds, lane, qh, ql, sacc);
       }
       qt_softmax<0>(lane, T, sacc, lsum);
       // B4': the second half is through its scores -- it holds its queries (the exchange planes become patches) and K is dead (the
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       {
         h8 qh[4], ql[4];
         read_q(qh, ql);
-        qt_scores<QT_PB1>(lds, lane, qh, ql, sacc);
+        if (!(QT_ABL & 2)) qt_scores<QT_PB1>(lds, lane, qh, ql, sacc);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) atomicAdd(xsync + 1, 1u);         // B4'
