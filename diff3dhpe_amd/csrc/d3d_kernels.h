@@ -162,8 +162,8 @@ bool qkv_sattn_ok(int J, int D, int H, int K);
 void set_qkv_sattn_diag(int on);   // "qs_diag" option: in-kernel stamp report of every 50th launch on stderr
 hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, const float* bias_hm, const float* csum_hm, const float* st_in,
                             int st_np, float eps, int w_exp, void* out_x3, int M, int K, int J, int D, int H, hipStream_t s);
-// kernels_qkv_tattn.hip: the temporal counterpart -- the LayerNorm-folded qkv GEMM of one (batch, joint) group (T in 193..256 frames) x one
-// head with the T-key attention of k_attn_temporal_x3s run from LDS; the same tile-ordered weight / bias / csum as launch_qkv_sattn.
+// kernels_qkv_tattn.hip: the temporal counterpart -- the LayerNorm-folded qkv GEMM of one (batch, joint) group (T in 193..255 frames; T <= 127:
+// of 255 / T joints of one batch element, per-joint key windows) x one head with the T-key attention of k_attn_temporal_x3s run from LDS; the same tile-ordered weight / bias / csum as launch_qkv_sattn.
 // kernels_fc1_x3.hip: fc1 (LayerNorm-folded, GELU, accumulator-order pair output) on the hand-specialised k-loop of the fused kernels,
 // whole 256 x 256 tiles only (buffers padded to 256 rows, finite pad rows); bit-identical to launch_linear_x3p's form.
 // kernels_proj_x3.hip: proj (plane residual in place + row statistics) likewise, whole 192 x 256 tiles (M % 192 == 0: the caller runs the

@@ -76,7 +76,8 @@ struct d3d_engine {
   bool opt_fused_postnorm = true, opt_fold_layernorm = true;
   // "fused_spatial": the spatial blocks' qkv GEMM and attention as ONE kernel (q / k / v never leave the chip); bit-identical
   bool opt_fused_spatial = true;
-  // "fused_temporal": the same for the temporal blocks where the frame count fits one tile (T in 193..256: kernels_qkv_tattn.hip)
+  // "fused_temporal": the same for the temporal blocks where the frame count fits one tile (T in 193..255, or T <= 127 with several joints
+  // per tile: kernels_qkv_tattn.hip)
   bool opt_fused_temporal = true;
   // "fc1_kernel": fc1 on its own kernel (kernels_fc1_x3.hip) where the launch fills the chip for a few rounds; bit-identical
   bool opt_fc1_kernel = true;
@@ -736,7 +737,7 @@ unsigned* d3d::range_sink_word() {
 extern "C" {
 
 const char* d3d_last_error(void) { return g_err.c_str(); }
-int d3d_version(void) { return 121; }
+int d3d_version(void) { return 122; }
 
 int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out) {
   // torch.linspace(-1, N-1, S+1) in fp32 (two-sided evaluation around the midpoint), .int() truncation, reversed

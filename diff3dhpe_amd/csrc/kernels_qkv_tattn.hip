@@ -18,6 +18,12 @@
 // halves meet at two LDS counters in a pad row of the V lo plane (key 255: T <= 255), not at workgroup barriers, which held the first
 // half at the second half's pace.  The next tile's first k-tile goes into the dead K planes, every wave's pieces issued by the first
 // half after its outputs (it idles there until the second half is through).  In-kernel stamps: "qt_diag" option.
+//
+// T <= 127 (the T = 81 / 27 configurations): the GROUPED form k_qkv_tattn<true> -- the frames of G = 255 / T joints of ONE batch element per
+// tile (tile row R = frame R % T of joint jt G + R / T), the same k-loop / plane writes / exchange; a query sees the keys of its own joint
+// (masks in the softmax) and a wave computes only the key tiles that hold keys of its queries' joints.  As accurate as the two-kernel flow,
+// not bit-identical to it (the softmax sum and the key-tile products group the keys by tile position); which joints share a tile depends on
+// the joint index alone, so a batch element's arithmetic does not depend on its position in the batch.
 #include "d3d_kernels.h"
 #include "qkv_fused_kloop.h"
 
@@ -106,7 +112,10 @@ struct QtArgs {
   int st_np;
   float eps, out_scale;    // LayerNorm eps; 2^-(3 + k)
   _Float16* out;           // attention output, pair layout [M][2 D] of 8 o
-  int M, K, T, J, BJ, D;   // tokens, GEMM depth, frames per group, joints, groups (B J), model width (8 heads x 64)
+  int M, K, T, J, BJ, D;   // tokens, GEMM depth, frames per group, joints, tiles per head (B J; grouped form: B TPS), model width (8 heads x 64)
+  int G, TPS, Tinv;        // grouped form (k_qkv_tattn<true>, T <= 127): G = 255 / T joints' frames per tile, TPS = ceil(J / G) tiles per batch
+                           // element, Tinv = 65536 / T + 1: R / T = (R Tinv) >> 16 for every tile row R < 256 (the fraction of R / T is at most
+                           // 126 / 127, the product's excess below 256 / 65536)
   unsigned* range;         // the engine's range-guard word
   unsigned long long* diag;   // diagnostic launches only ("qs_diag"): per workgroup 8 words -- cycles of wave 0 in the k-loop, the statistics
                               // step, the plane writes, the query exchange, scores + softmax, the rest of the attention, tiles, 100 MHz ticks
@@ -165,13 +174,44 @@ constexpr int QT_NKT = 8;
 #define QT_ABL 0
 #endif
 
-template <int PB>
-__device__ __forceinline__ void qt_scores(unsigned char* const lds, int lane, const h8 (&qh)[4], const h8 (&ql)[4], f32x16 (&sacc)[QT_NKT]) {
+template <int PB, bool GRP = false>
+__device__ __forceinline__ void qt_scores(unsigned char* const lds, int lane, const h8 (&qh)[4], const h8 (&ql)[4], f32x16 (&sacc)[QT_NKT],
+                                          int kt_lo = 0, int kt_hi = QT_NKT - 1) {
   constexpr int NKT = QT_NKT, PLANE = QT_PLANE;
   const int r = lane & 31, h = lane >> 5;
   unsigned char* const sKh = lds + QT_K;
   __builtin_amdgcn_s_setprio(2 + PB);
-  {
+  if constexpr (GRP) {   // grouped form: only the key tiles [kt_lo, kt_hi] (wave-uniform) that hold keys of this wave's groups
+    unsigned kaddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = (unsigned)(uintptr_t)(sKh + kswz(r, 2 * ks + h));
+    static_for<NKT>([&](auto ktc) {
+      constexpr int kt = decltype(ktc)::value;
+      if (kt >= kt_lo && kt <= kt_hi) {
+        h8 kfh[3], kfl[3];
+        lds_read_b128<kt * 4096>(kfh[0], kaddr[0]); lds_read_b128<kt * 4096 + PLANE>(kfl[0], kaddr[0]);
+        lds_read_b128<kt * 4096>(kfh[1], kaddr[1]); lds_read_b128<kt * 4096 + PLANE>(kfl[1], kaddr[1]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc[kt][q] = 0.f;
+        static_for<4>([&](auto ksc) {
+          constexpr int ks = decltype(ksc)::value;
+          if constexpr (ks + 2 < 4) {
+            lds_read_b128<kt * 4096>(kfh[(ks + 2) % 3], kaddr[ks + 2]);
+            lds_read_b128<kt * 4096 + PLANE>(kfl[(ks + 2) % 3], kaddr[ks + 2]);
+          }
+          lgkm_wait<(ks + 2 < 4) ? 4 : (ks + 1 < 4 ? 2 : 0)>();
+          __builtin_amdgcn_sched_barrier(0);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[ks % 3], qh[ks], sacc[kt], 0, 0, 0);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[ks % 3], ql[ks], sacc[kt], 0, 0, 0);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[ks % 3], qh[ks], sacc[kt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc[kt][q] = 0.f;
+      }
+    });
+  } else {
     h8 kfh[3], kfl[3];
     unsigned kaddr[4];
 #pragma unroll
@@ -199,27 +239,36 @@ __device__ __forceinline__ void qt_scores(unsigned char* const lds, int lane, co
   }
   __builtin_amdgcn_s_setprio(PB);
 }
-template <int PB>
-__device__ __forceinline__ void qt_softmax(int lane, int T, f32x16 (&sacc)[QT_NKT], float& l) {
+// GRP (grouped form): this lane's query sees the keys [klo, khi) of its own group only, all inside the key tiles [kt_lo, kt_hi] (wave-uniform:
+// the tiles the score step computed; the others are never touched)
+template <int PB, bool GRP = false>
+__device__ __forceinline__ void qt_softmax(int lane, int T, f32x16 (&sacc)[QT_NKT], float& l, int kt_lo = 0, int kt_hi = QT_NKT - 1, int klo = 0,
+                                           int khi = 0) {
   constexpr int NKT = QT_NKT;
   const int h = lane >> 5;
   float m = -INFINITY;
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (GRP && (kt < kt_lo || kt > kt_hi)) continue;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      if (kt >= 6) {   // (T > 192: only the last two key tiles can hold pad keys)
+      if (GRP) {
+        const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (key < klo || key >= khi) sacc[kt][q] = -INFINITY;
+      } else if (kt >= 6) {   // (T > 192: only the last two key tiles can hold pad keys)
         const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
         if (key >= T) sacc[kt][q] = -INFINITY;
       }
       m = fmaxf(m, sacc[kt][q]);
     }
+  }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   constexpr float C_EXP = 1.4426950408889634f / 64.0f;
   const float mb = m * C_EXP;
   l = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
+    if (GRP && (kt < kt_lo || kt > kt_hi)) continue;
     float e[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -239,9 +288,12 @@ __device__ __forceinline__ void qt_softmax(int lane, int T, f32x16 (&sacc)[QT_NK
 }
 
 // Products, output arithmetic and stores of one wave's 32 queries: the product and output steps of k_attn_temporal_x3s.
-template <int PB>
+// GRP (grouped form): key tiles [kt_lo, kt_hi] only; TV = G T valid tile rows; the output row of tile row R is out_unit + orow(R) (a lambda of
+// the kernel: the row's token), stored where orow(R) >= 0
+template <int PB, bool GRP = false, class ORow = int>
 __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, int wave, int lane, int T, int J, int D, const f32x16 (&sacc)[QT_NKT],
-                                                    float l, _Float16* out_unit, unsigned* rw) {
+                                                    float l, _Float16* out_unit, unsigned* rw, int kt_lo = 0, int kt_hi = QT_NKT - 1,
+                                                    ORow orow = 0) {
   constexpr int NKT = QT_NKT, PLANE = QT_PLANE;
   const int r = lane & 31, h = lane >> 5;
   unsigned char* const sVh = lds + QT_V;
@@ -275,14 +327,19 @@ __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, in
         lds_read_tr16_b64<off + PLANE>(f[4 * dt + 3], vaddr[2 * dt + 1]);
       }
     };
-    vread(std::integral_constant<int, 0>{}, vf[0]);
+    if constexpr (!GRP) vread(std::integral_constant<int, 0>{}, vf[0]);
     static_for<2 * NKT>([&](auto jc) {
       constexpr int j = decltype(jc)::value, kt = j >> 1, s2 = j & 1;
-      if constexpr (j + 1 < 2 * NKT) vread(std::integral_constant<int, j + 1>{}, vf[(j + 1) & 1]);
+      if (GRP && (kt < kt_lo || kt > kt_hi)) return;
+      if constexpr (GRP) {   // (no read ahead across key tiles: which one follows is a run-time matter; both steps of a tile at once)
+        if constexpr (s2 == 0) { vread(jc, vf[0]); vread(std::integral_constant<int, j + 1>{}, vf[1]); }
+      } else {
+        if constexpr (j + 1 < 2 * NKT) vread(std::integral_constant<int, j + 1>{}, vf[(j + 1) & 1]);
+      }
       typedef float f32x4_ __attribute__((ext_vector_type(4)));
       const h8 eh = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 4 * s2, 4 * s2 + 1, 4 * s2 + 2, 4 * s2 + 3));
       const h8 el = __builtin_bit_cast(h8, (f32x4_)__builtin_shufflevector(sacc[kt], sacc[kt], 8 + 4 * s2, 9 + 4 * s2, 10 + 4 * s2, 11 + 4 * s2));
-      lgkm_wait<(j + 1 < 2 * NKT) ? 8 : 0>();
+      lgkm_wait<(GRP ? s2 == 0 : j + 1 < 2 * NKT) ? 8 : 0>();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -302,7 +359,7 @@ __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, in
   // v_query (this wave's own rows of V)
   h4 vqh[8], vql[8];
   {
-    const int tqc = tq < T ? tq : 0;
+    const int tqc = (GRP || tq < T) ? tq : 0;   // (grouped form: every plane row holds finite values)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int vo = vswz(tqc, c) + 8 * h;
@@ -346,18 +403,39 @@ __device__ __forceinline__ void qt_products_outputs(unsigned char* const lds, in
       for (int it = 0; it < 4; ++it) po[dt * 4 + it] = (QT_ABL & 8) ? u32x4{0u, 0u, 0u, 0u} : patch_rd(patch, 8 * it + (lane >> 3), lane & 7);
       asm volatile("" ::: "memory");
     }
-    if (tq < T && amax > X3_HALF_MAX) range_raise(rw, RANGE_BIT_ACT);
-  }
-  _Float16* const po_ptr = out_unit + (size_t)(32 * wave + (lane >> 3)) * J * 2 * D + 8 * (lane & 7);
-  const size_t po_stride = (size_t)8 * J * 2 * D;
-#pragma unroll
-  for (int it = 0; it < 4; ++it)
-    if (32 * wave + 8 * it + (lane >> 3) < T) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(po_ptr + it * po_stride + dt * 64) = po[dt * 4 + it];
+    if constexpr (GRP) {
+      if (orow(tq) >= 0 && amax > X3_HALF_MAX) range_raise(rw, RANGE_BIT_ACT);
+    } else {
+      if (tq < T && amax > X3_HALF_MAX) range_raise(rw, RANGE_BIT_ACT);
     }
+  }
+  if constexpr (GRP) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int tokr = orow(32 * wave + 8 * it + (lane >> 3));
+      if (tokr >= 0) {
+        _Float16* const pp = out_unit + (size_t)tokr * 2 * D + 8 * (lane & 7);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(pp + dt * 64) = po[dt * 4 + it];
+      }
+    }
+  } else {
+    _Float16* const po_ptr = out_unit + (size_t)(32 * wave + (lane >> 3)) * J * 2 * D + 8 * (lane & 7);
+    const size_t po_stride = (size_t)8 * J * 2 * D;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (32 * wave + 8 * it + (lane >> 3) < T) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<u32x4*>(po_ptr + it * po_stride + dt * 64) = po[dt * 4 + it];
+      }
+  }
 }
 
+// GRP = false: one (batch, joint) group of 193 ... 255 frames per tile.  GRP = true (T <= 127): the frames of G = 255 / T joints of ONE batch
+// element per tile -- tile row R = frame R % T of joint jt G + R / T --; a query sees the keys of its own joint only (masks in the softmax,
+// and only the key tiles that hold them are computed).  Which joints share a tile depends on the joint index alone: a batch element's
+// arithmetic does not depend on its position in the batch.
+template <bool GRP>
 __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int G = (int)gridDim.x, b = (int)blockIdx.x;
@@ -382,18 +460,30 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
   const int nk = K / 32;
   int bj = 0, hd = 0;
   tile_of(b, bj, hd);
+  // grouped form: token row (from the batch element's first token) of tile row R of joint tile jt, -1 for the pad rows of the tile and for
+  // joints beyond J in an element's last tile
+  auto grow = [&](int R, int jt) -> int {
+    const int g = (R * a.Tinv) >> 16, t = R - g * T, j = jt * a.G + g;
+    return (g < a.G && j < J) ? t * J + j : -1;
+  };
   // first k-tile of a tile: wave w moves pieces w, w + 8, ... (8 rows x 128 B each) of A, then of W; tile row t is token tok0 + min(t, T - 1) J
   auto stage_first = [&](int bj_, int hd_, int wave) {   // (the pieces of `wave`: the issuing wave may move another wave's share as well)
     const int lane = threadIdx.x & 63;
     const int lr = lane >> 3, csrc = (lane & 7) ^ (((wave & 1) << 2) | (lr >> 1));
-    const size_t tok0_ = (size_t)(bj_ / J) * T * J + (size_t)(bj_ % J);
+    const size_t tok0_ = GRP ? (size_t)(bj_ / a.TPS) * T * J : (size_t)(bj_ / J) * T * J + (size_t)(bj_ % J);
     const char* tA = reinterpret_cast<const char*>(a.Ap) + tok0_ * K2 * 2;
     const char* ubB = reinterpret_cast<const char*>(a.Wp) + (size_t)(hd_ * QT_BN + wave * 8) * K2 * 2;
     const unsigned lofsW = (unsigned)(lr * (int)K2 + csrc * 8) * 2u;
 #pragma unroll
     for (int it = 0; it < QT_AIT; ++it) {
       const int row = wave * 8 + 64 * it + lr;
-      const unsigned lo = (unsigned)(((size_t)(row < T ? row : T - 1) * J * K2 + csrc * 8) * 2);
+      unsigned lo;
+      if constexpr (GRP) {
+        const int jt_ = bj_ % a.TPS, tr = grow(row, jt_);
+        lo = (unsigned)(((size_t)(tr >= 0 ? tr : jt_ * a.G) * K2 + csrc * 8) * 2);   // (pad rows repeat the tile's first token: finite values)
+      } else {
+        lo = (unsigned)(((size_t)(row < T ? row : T - 1) * J * K2 + csrc * 8) * 2);
+      }
       QT_GLDS(sgpr_ptr(tA) + lo, wave * 1024 + lane * 16 + it * 8192);
     }
     const size_t it_stride = (size_t)64 * K2 * 2;
@@ -422,7 +512,8 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
     constexpr bool has_next = false;   // (the k-loop stages nothing of the next tile: the planes need the whole LDS)
     int bjn = 0, hdn = 0;
     if (more) tile_of((item + 1) * G + b, bjn, hdn);
-    const size_t tok0 = (size_t)(bj / J) * T * J + (size_t)(bj % J);
+    const size_t tok0 = GRP ? (size_t)(bj / a.TPS) * T * J : (size_t)(bj / J) * T * J + (size_t)(bj % J);   // GRP: the batch element's first token
+    const int jt = GRP ? bj % a.TPS : 0;
     const int n0 = hd * QT_BN;
 
     // ---- row statistics of the folded LayerNorm: raw partials gathered by LDS-DMA under the k-loop -- lane l of piece pc serves row
@@ -434,7 +525,13 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int pc = wave + it * 8, row = 16 * pc + (lane >> 2);
-        const unsigned lo = (unsigned)((size_t)(row < T ? row : T - 1) * J * 64 + (lane & 3) * 16);
+        unsigned lo;
+        if constexpr (GRP) {
+          const int tr = grow(row, jt);
+          lo = (unsigned)((size_t)(tr >= 0 ? tr : jt * a.G) * 64 + (lane & 3) * 16);
+        } else {
+          lo = (unsigned)((size_t)(row < T ? row : T - 1) * J * 64 + (lane & 3) * 16);
+        }
         QT_GLDS(sgpr_ptr(src) + lo, QT_RAW + pc * 1024 + lane * 16);
         ++st_issued;
       }
@@ -453,13 +550,23 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       const int row = wave * 8 + 192 + lr_;
       lofsA3_ = (unsigned)(((size_t)(row < T ? row : T - 1) * J * K2 + csrc_ * 8) * 2);
     }
+    unsigned lofsAg_[QT_AIT] = {0u, 0u, 0u, 0u};                                                // grouped form: A piece it, from the element's first token
+    if constexpr (GRP) {
+#pragma unroll
+      for (int it = 0; it < QT_AIT; ++it) {
+        const int tr = grow(wave * 8 + 64 * it + lr_, jt);
+        lofsAg_[it] = (unsigned)(((size_t)(tr >= 0 ? tr : jt * a.G) * K2 + csrc_ * 8) * 2);
+      }
+    }
     const size_t it_stride = (size_t)64 * K2 * 2, it_strideA = (size_t)64 * J * K2 * 2;
     const int dstA = wave * 1024 + lane * 16, dstB = QT_AREG + wave * 1024 + lane * 16;
     // piece IT (A: 0..3, W: 4..6) of k-tile KTT of this tile
 #define QT_PIECE(KTT, IT)                                                                                               \
     do {                                                                                                                \
       const int st_ = ((KTT) & 1) * QT_STAGE;                                                                           \
-      if ((IT) < 3) {                                                                                                   \
+      if (GRP && (IT) < QT_AIT) {                                                                                       \
+        QT_GLDS(sgpr_ptr(tA + (size_t)(KTT) * 128) + lofsAg_[(IT) < QT_AIT ? (IT) : 0], st_ + dstA + (IT) * 8192);      \
+      } else if ((IT) < 3) {                                                                                            \
         QT_GLDS(sgpr_ptr(ubA + ((size_t)(KTT) * 128 + (IT) * it_strideA)) + lofsA_, st_ + dstA + (IT) * 8192);          \
       } else if ((IT) == 3) {                                                                                           \
         QT_GLDS(sgpr_ptr(tA + (size_t)(KTT) * 128) + lofsA3_, st_ + dstA + 3 * 8192);                                   \
@@ -495,7 +602,13 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       float2* const srow = reinterpret_cast<float2*>(lds + QT_STX);
       if (lane < 32) {
         const int t = wave * 32 + lane;
-        const size_t row = tok0 + (size_t)(t < T ? t : T - 1) * J;          // (pad rows of the tile repeat the last frame: finite values)
+        size_t row;
+        if constexpr (GRP) {
+          const int tr = grow(t, jt);
+          row = tok0 + (size_t)(tr >= 0 ? tr : jt * a.G);
+        } else {
+          row = tok0 + (size_t)(t < T ? t : T - 1) * J;          // (pad rows of the tile repeat the last frame: finite values)
+        }
         float sm = 0.f, sq = 0.f;
         {
           const float2* raw = st_dma ? reinterpret_cast<const float2*>(lds + QT_RAW) + t * a.st_np
@@ -519,7 +632,8 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
 #undef QF_PIECE
 #undef QT_PIECE
     __builtin_amdgcn_s_setprio(0);
-    asm volatile("" : "+v"(lofsA_), "+v"(lofsA3_));
+    if constexpr (GRP) asm volatile("" : "+v"(lofsAg_[0]), "+v"(lofsAg_[1]), "+v"(lofsAg_[2]), "+v"(lofsAg_[3]));
+    else asm volatile("" : "+v"(lofsA_), "+v"(lofsA3_));
     QT_STAMP(0);
 
     __syncthreads();   // statistics visible; every wave is out of the k-loop: the LDS becomes planes + exchange
@@ -599,6 +713,18 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
     //   half 0: read Q | B2 | scores, softmax                          | B4' (no wait) | products, outputs, both halves' prefetch pieces
     //   half 1:        | B2 | write Q(half 1) | B3' | read Q, scores | raise B4' | softmax, products, outputs
     _Float16* const out_unit = a.out + tok0 * 2 * a.D + hd * 128;
+    // grouped form: the key tiles this wave's 32 queries need (wave-uniform) and this lane's key window
+    int kt_lo = 0, kt_hi = QT_NKT - 1, klo = 0, khi = 0;
+    if constexpr (GRP) {
+      const int TV = a.G * T;
+      const int qa = 32 * wave < TV ? 32 * wave : TV - 1, qb = 32 * wave + 31 < TV ? 32 * wave + 31 : TV - 1;
+      kt_lo = (((qa * a.Tinv) >> 16) * T) >> 5;
+      kt_hi = (((qb * a.Tinv) >> 16) * T + T - 1) >> 5;
+      const int tq = 32 * wave + (lane & 31);
+      klo = (((tq < TV ? tq : TV - 1) * a.Tinv) >> 16) * T;
+      khi = klo + T;
+    }
+    auto orow = [&](int R) -> int { return grow(R, jt); };
     auto read_q = [&](h8 (&qh)[4], h8 (&ql)[4]) {   // this wave's 32 queries (rows 32 (wave & 3) + r of its half's exchange planes), all 64 dims
       const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -617,15 +743,16 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
         h8 qh[4], ql[4];
         read_q(qh, ql);
         __builtin_amdgcn_s_barrier();                  // B2: half 0 holds its queries: the exchange planes may be rewritten
-        if (!(QT_ABL & 2)) qt_scores<0>(lds, lane, qh, ql, sacc);
+        if (!(QT_ABL & 2)) qt_scores<0, GRP>(lds, lane, qh, ql, sacc, kt_lo, kt_hi);
       }
-      qt_softmax<0>(lane, T, sacc, lsum);
+      qt_softmax<0, GRP>(lane, T, sacc, lsum, kt_lo, kt_hi, klo, khi);
       // B4': the second half is through its scores -- it holds its queries (the exchange planes become patches) and K is dead (the
       // prefetch below); a counter it raised long before this point, not a barrier it would have to wait at
       while (reinterpret_cast<volatile unsigned*>(xsync)[1] < 4u) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
       QT_STAMP(3);
-      qt_products_outputs<0>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
+      if constexpr (GRP) qt_products_outputs<0, true>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range, kt_lo, kt_hi, orow);
+      else qt_products_outputs<0>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
       // the next tile's first k-tile into the dead K planes: both halves' pieces from this half, which is a step ahead and would idle
       if (more) { stage_first(bjn, hdn, wave); stage_first(bjn, hdn, wave + 4); }
       QT_STAMP(4);
@@ -643,13 +770,14 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
       {
         h8 qh[4], ql[4];
         read_q(qh, ql);
-        if (!(QT_ABL & 2)) qt_scores<QT_PB1>(lds, lane, qh, ql, sacc);
+        if (!(QT_ABL & 2)) qt_scores<QT_PB1, GRP>(lds, lane, qh, ql, sacc, kt_lo, kt_hi);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) atomicAdd(xsync + 1, 1u);         // B4'
       QT_STAMP(3);
-      qt_softmax<QT_PB1>(lane, T, sacc, lsum);
-      qt_products_outputs<QT_PB1>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
+      qt_softmax<QT_PB1, GRP>(lane, T, sacc, lsum, kt_lo, kt_hi, klo, khi);
+      if constexpr (GRP) qt_products_outputs<QT_PB1, true>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range, kt_lo, kt_hi, orow);
+      else qt_products_outputs<QT_PB1>(lds, wave, lane, T, J, a.D, sacc, lsum, out_unit, a.range);
       QT_STAMP(4);
     }
     bj = bjn; hd = hdn;
@@ -670,7 +798,10 @@ __global__ __launch_bounds__(512) void k_qkv_tattn(QtArgs a) {
 static std::atomic<int> g_qt_diag{0};
 void set_qkv_tattn_diag(int on) { g_qt_diag = on; }
 
-bool qkv_tattn_ok(int T, int J, int D, int H, int K) { return T > 192 && T <= 255 && J >= 1 && H == 8 && D == 512 && K % 64 == 0 && K >= 128; }
+// T in 193 ... 255: one joint's frames per tile; T in 2 ... 127: the frames of 255 / T joints per tile (grouped form)
+bool qkv_tattn_ok(int T, int J, int D, int H, int K) {
+  return ((T > 192 && T <= 255) || (T >= 2 && T <= 127)) && J >= 1 && H == 8 && D == 512 && K % 64 == 0 && K >= 128;
+}
 
 // Tokens M = B T J, rows (b T + t) J + j.
 hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, const float* bias_to, const float* csum_to, const float* st_in,
@@ -683,9 +814,18 @@ hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, cons
   a.Ap = (const _Float16*)Apair; a.Wp = (const _Float16*)Wpair_tileorder; a.bias = bias_to; a.csum = csum_to; a.st_in = st_in;
   a.st_np = st_np; a.eps = eps; a.out_scale = ldexpf(1.0f, -(3 + w_exp));
   a.out = (_Float16*)out_x3; a.M = B * T * J; a.K = K; a.T = T; a.J = J; a.BJ = B * J; a.D = D;
+  const bool grp = T <= 127;
+  if (grp) {
+    a.G = 255 / T < J ? 255 / T : J;
+    a.TPS = (J + a.G - 1) / a.G;
+    a.Tinv = 65536 / T + 1;
+    a.BJ = B * a.TPS;
+    if ((size_t)T * J * 2 * K * 2 > 0xffffffffull) return hipErrorInvalidValue;
+  }
   a.range = launch_range_word();
-  static std::atomic<unsigned long long> attr_done{0};   // one bit per device
-  if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(k_qkv_tattn), QT_LDS, attr_done)) return ae;
+  const void* kfn = grp ? reinterpret_cast<const void*>(k_qkv_tattn<true>) : reinterpret_cast<const void*>(k_qkv_tattn<false>);
+  static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};   // one bit per device
+  if (hipError_t ae = lds_optin(kfn, QT_LDS, attr_done[grp ? 1 : 0])) return ae;
   int n_cu = device_cu_count();
   if (n_cu <= 0) return hipErrorUnknown;
   const int tiles = a.BJ * 8;
@@ -697,7 +837,8 @@ hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, cons
       if (hipMalloc(&buf, (size_t)grid * 128) != hipSuccess) return hipErrorOutOfMemory;
       (void)hipMemsetAsync(buf, 0, (size_t)grid * 128, s);
       a.diag = buf;
-      hipLaunchKernelGGL(k_qkv_tattn, dim3(grid), dim3(512), QT_LDS, s, a);
+      if (grp) hipLaunchKernelGGL(k_qkv_tattn<true>, dim3(grid), dim3(512), QT_LDS, s, a);
+      else hipLaunchKernelGGL(k_qkv_tattn<false>, dim3(grid), dim3(512), QT_LDS, s, a);
       (void)hipStreamSynchronize(s);
       std::vector<unsigned long long> h((size_t)grid * 16);
       (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
@@ -720,7 +861,8 @@ hipError_t launch_qkv_tattn(const void* Apair, const void* Wpair_tileorder, cons
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL(k_qkv_tattn, dim3(grid), dim3(512), QT_LDS, s, a);
+  if (grp) hipLaunchKernelGGL(k_qkv_tattn<true>, dim3(grid), dim3(512), QT_LDS, s, a);
+  else hipLaunchKernelGGL(k_qkv_tattn<false>, dim3(grid), dim3(512), QT_LDS, s, a);
   return hipGetLastError();
 }
 

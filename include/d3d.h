@@ -136,6 +136,9 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *   "fused_temporal"  1 (default) / 0: the same for the temporal blocks where the frames of a joint fit one 256-row tile (193 <= T <= 255,
  *                     D = 512, 8 heads): the qkv GEMM of one (batch, joint) group keeps K / V in LDS, exchanges the queries there and runs
  *                     the group's T-key attention in the same kernel (S2S:67 + 73-83 for the per-joint groups) / two kernels.  Bit-identical.
+ *                     T <= 127: the frames of 255 / T joints of one batch element per tile, every query on its own joint's keys -- as
+ *                     accurate as the two-kernel flow but not bit-identical to it (sums grouped by tile position); a batch element's
+ *                     result does not depend on its position in the batch either way.
  *   "fc1_kernel"      1 (default) / 0: fc1 (LayerNorm-folded, GELU) on its own kernel -- the hand-specialised k-loop of the fused kernels
  *                     with the token GEMM's own epilogue function, from two rounds of 256 x 256 tiles on -- / as a form of the token GEMM.
  *                     Bit-identical.

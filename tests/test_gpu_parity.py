@@ -726,7 +726,11 @@ def test_per_kernel_trace_is_reproducible_and_does_not_change_results():
     assert torch.equal(a, plain) and torch.equal(b, plain)
     assert ta == tb and len(ta) >= S * (5 * 2 * cfg.depth + 3)
     kinds = {(t >> 4) & 0xF for t, _ in ta}
-    assert {2, 3, 4, 5, 6, 8} <= kinds                 # qkv, attention, proj, fc1, fc2 + post-norm, head
+    assert {3, 4, 5, 6, 8} <= kinds                    # attention (fused with its qkv GEMM), proj, fc1, fc2 + post-norm, head
+    eng.set_option("fused_temporal", 0)                # the two-kernel flow of the temporal blocks writes (and traces) q / k / v planes
+    eng.ddim_sample(x2d, nz)
+    assert 2 in {(t >> 4) & 0xF for t, _ in eng.trace_read()}
+    eng.set_option("fused_temporal", 1)
     fwds = {(t >> 16) & 0xFFF for t, _ in ta}
     assert len(fwds) == S
     eng.set_trace(32768, 8)                            # eight views per buffer: every view must report the same words

@@ -420,6 +420,62 @@ def test_fused_temporal_blocks_with_another_joint_count():
     assert maxabs(fused, ref) <= GATE, maxabs(fused, ref)
 
 
+@pytest.mark.parametrize("T,B,family,s2f", [(81, 5, "uniform", False), (81, 3, "trainedlike", False), (27, 7, "uniform", True), (27, 4, "trainedlike", False),
+                                            (100, 2, "uniform", False), (9, 3, "uniform", False)])
+def test_fused_temporal_blocks_grouped_form_for_short_sequences(T, B, family, s2f):
+    """T <= 127: the fused temporal kernel takes the frames of 255 / T joints of ONE batch element per tile (k_qkv_tattn<true>): a query sees
+    the keys of its own joint only, and only the key tiles that hold them are computed.  Its softmax sums and key-tile products are
+    grouped differently from the stand-alone attention kernels, so it is NOT bit-identical to the two-kernel flow: within 2e-5 of it
+    (both are ~2e-6 from the oracle), inside the gate against the CPU oracle, deterministic, NaN-filled workspace, and -- which joints
+    share a tile depends on the joint index alone -- every batch element's result bit for bit the one it has when sampled alone."""
+    from oracle import d3d_oracle as orc
+    cfg = cfg_full(T, seq2frame=s2f)
+    seed = 11 if family == "trainedlike" else 5
+    _, diff = _product(cfg, seed, "f16x3", sampling=2, family=family)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(B, T, 83)
+    x2d = inp["x2d"].cuda()
+    nz = (inp["noise"][:, :1] if s2f else inp["noise"]).contiguous().cuda()
+    eng.range_flags(clear=True)
+    eng.set_option("fused_temporal", 1)
+    eng._workspace(B).view(torch.float32).fill_(float("nan"))
+    fused = eng.ddim_sample(x2d, nz).clone()
+    again = eng.ddim_sample(x2d, nz).clone()
+    alone = torch.cat([eng.ddim_sample(x2d[i:i + 1].contiguous(), nz[i:i + 1].contiguous()).clone() for i in range(B)])
+    eng.set_option("fused_temporal", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_temporal", 1)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed, family=family).items()}
+    ref = orc.ddim_sample_loop(sd, orc.diffusion_tables("cosine", 1000), inp["x2d"], nz.cpu(), num_timesteps=1000, sampling_timesteps=2,
+                               depth=cfg.depth, seq2frame=s2f)
+    e_plain, e_ref = maxabs(fused, plain.cpu()), maxabs(fused, ref)
+    print(f"grouped fused temporal T={T} B={B} [{family}{', s2f' if s2f else ''}]: vs two-kernel flow {e_plain:.3e}, vs oracle {e_ref:.3e}")
+    assert torch.isfinite(fused).all() and eng.range_flags() == 0
+    assert torch.equal(fused, again) and torch.equal(fused, alone)
+    assert e_plain <= 2e-5 and e_ref <= GATE
+
+
+def test_fused_temporal_grouped_form_with_another_joint_count():
+    """21 joints at T = 27: 9 joints per tile, three tiles per batch element, the last with three joints (six joint slots of pad rows)."""
+    from oracle import d3d_oracle as orc
+    from diff3dhpe_amd.spec import DenoiserConfig
+    from diff3dhpe_amd.synth import synth_inputs
+    J, T = 21, 27
+    cfg = DenoiserConfig(num_frame=T, num_joints=J, embed_dim=512, depth=2)
+    net, diff = build_product(cfg, 35, sampling=2, precision="f16x3")
+    inp = {k: torch.from_numpy(v) for k, v in synth_inputs(3, T, J, seed=352).items()}
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    eng.set_option("fused_temporal", 1)
+    fused = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_temporal", 0)
+    plain = eng.ddim_sample(x2d, nz).clone()
+    eng.set_option("fused_temporal", 1)
+    ref = orc.ddim_sample_loop(torch_sd(cfg, 35), orc.diffusion_tables("cosine", 1000), inp["x2d"], inp["noise"], num_timesteps=1000,
+                               sampling_timesteps=2, depth=cfg.depth)
+    assert maxabs(fused, plain.cpu()) <= 2e-5 and maxabs(fused, ref) <= GATE, (maxabs(fused, plain.cpu()), maxabs(fused, ref))
+
+
 # ------------------------------------------------------------------------------------------------ dedicated fc1 kernel
 @pytest.mark.parametrize("T,B,family", [(243, 32, "uniform"), (243, 33, "trainedlike"), (81, 96, "uniform")])
 def test_fc1_kernel_is_bit_identical_to_the_template_form(T, B, family):
