@@ -52,6 +52,8 @@ def short(name: str) -> str:
     name = demangle(name)
     if "k_qkv_sattn" in name:
         return "k_qkv_sattn<255 rows x 192 cols persistent, LN-folded qkv GEMM + 17-key attention from LDS> (spatial blocks)"
+    if "k_qkv_tattn<true>" in name or "k_qkv_tattnILb1E" in name:
+        return "k_qkv_tattn<256 rows (the frames of 255 / T joints of a batch element) x 192 cols persistent, LN-folded qkv GEMM + per-joint T-key attention from LDS> (temporal blocks)"
     if "k_qkv_tattn" in name:
         return "k_qkv_tattn<256 rows (the frames of one joint) x 192 cols persistent, LN-folded qkv GEMM + T-key attention from LDS> (temporal blocks)"
     if "k_fc1_x3" in name:
