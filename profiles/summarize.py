@@ -49,7 +49,7 @@ _OUT = {"0": "fp32-out", "1": "planes-out", "2": "pair-out", "3": "bf16-out"}
 
 
 def short(name: str) -> str:
-    name = demangle(name)
+    name = demangle(name).replace("(anonymous namespace)::", "")
     if "k_qkv_sattn" in name:
         return "k_qkv_sattn<255 rows x 192 cols persistent, LN-folded qkv GEMM + 17-key attention from LDS> (spatial blocks)"
     if "k_qkv_tattn<true>" in name or "k_qkv_tattnILb1E" in name:
