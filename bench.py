@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+_T_IMPORT = time.time()      # (startup_s: process creation -> first sampling done; the creation time itself comes from psutil)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -86,6 +88,7 @@ def cpu_baseline(T, S, seed, budget_s=40.0):
     d = min(reps)
     return {"value": round(bestB / (d * S), 4), "unit": "pose-seq/s", "cores": best_th, "kind": "port",
             "spread_max_over_min": round(max(reps) / d, 3),
+            "all_cores_concurrent": cpu_baseline_concurrent(T, S, seed, best_th, avail, per_step[1]),
             "sample": f"fp32 eager CPU oracle (port of the reference op sequence; cross-timed against the imported reference in the "
                       f"build container: profiles/r02_cpu_oracle_vs_reference.json), T={T}: thread sweep on 1 DDIM step at B=1 "
                       f"{ {k: round(v, 2) for k, v in sweep.items()} } s; 1 step at B in {sorted(per_step)}: "
@@ -93,6 +96,69 @@ def cpu_baseline(T, S, seed, budget_s=40.0):
                       f"{budget_s:.0f} s budget); best B={bestB} timed 3x on {n} of {S} steps "
                       f"({', '.join(f'{r:.2f}' for r in reps)} s/step; min reported, scaled to {S} steps); "
                       f"host has {avail} usable CPUs"}
+
+
+def cpu_worker(T, seed, threads, run_s):
+    """Child of cpu_baseline_concurrent (`bench.py --cpu-worker T,seed,threads,seconds`; never touches the GPU): build the oracle's
+    inputs, say "ready", wait for "go" on stdin, run whole DDIM steps at B=1 for ~run_s seconds, print {"steps", "seconds"}."""
+    import torch
+    from oracle import d3d_oracle as orc
+    from diff3dhpe_amd.spec import DenoiserConfig
+    from diff3dhpe_amd.synth import synth_state_dict, synth_inputs
+    torch.set_num_threads(threads)
+    cfg = DenoiserConfig(num_frame=T, embed_dim=512, depth=8)
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed).items()}
+    tabs = orc.diffusion_tables("cosine", 1000)
+    inp = synth_inputs(1, T, seed=42)
+    x2d, nz = torch.from_numpy(inp["x2d"]), torch.from_numpy(inp["noise"])
+    one = lambda: orc.ddim_sample_loop(sd, tabs, x2d, nz, num_timesteps=1000, sampling_timesteps=1, depth=8)
+    print("ready", flush=True)
+    if sys.stdin.readline().strip() != "go":
+        return
+    t0, n = time.time(), 0
+    while n == 0 or time.time() - t0 < run_s:
+        one()
+        n += 1
+    print(json.dumps({"steps": n, "seconds": time.time() - t0}), flush=True)
+
+
+def cpu_baseline_concurrent(T, S, seed, best_th, avail, step_s_alone, run_s=8.0, max_procs=16):
+    """The same oracle on ALL of this node's usable cores at once: k = usable CPUs // best_th processes (capped), each a B=1
+    sampling loop on best_th threads, started together; throughput = whole DDIM steps finished by all of them / wall / S.  This is
+    the figure "the node's own host cores" can deliver for independent windows -- the single-process number above is the
+    reference's own form (one Python process, RUN).  Children are fresh processes that never touch the GPU."""
+    import subprocess
+    k = max(1, min(max_procs, avail // max(best_th, 1)))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{T},{seed},{best_th},{run_s}"]
+    env = dict(os.environ, OMP_NUM_THREADS=str(best_th), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    procs = []
+    try:
+        for _ in range(k):
+            procs.append(subprocess.Popen(cmd, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu worker did not come up")
+        t0 = time.time()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        outs = [json.loads(p.stdout.readline()) for p in procs]
+        wall = time.time() - t0
+        for p in procs:
+            p.wait(timeout=30)
+        steps = sum(o["steps"] for o in outs)
+        return {"value": round(steps / wall / S, 4), "unit": "pose-seq/s", "processes": k, "threads_per_process": best_th,
+                "cores": k * best_th, "steps_finished": steps, "wall_s": round(wall, 2),
+                "one_process_alone_s_per_step": round(step_s_alone, 3),
+                "s_per_step_under_load": round(max(o["seconds"] / o["steps"] for o in outs), 3),
+                "note": f"{k} concurrent B=1 oracle processes x {best_th} threads for ~{run_s:.0f} s each, whole DDIM steps counted, scaled to "
+                        f"{S} steps per sequence; host has {avail} usable CPUs"}
+    except Exception as ex:
+        return {"value": None, "error": str(ex)[:200], "processes": k}
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
 
 
 def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
@@ -131,6 +197,19 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
                                    "(d3d_engine_set_graph_mode), on one stream / as two half-batches on two streams (\"streams\" option)"}
     out["graph_vs_eager"] = {"eager_ms": modes["eager_1stream"], "graph_ms": modes["graph_1stream"],
                              "graph_over_eager": round(modes["graph_1stream"] / modes["eager_1stream"], 4), "bit_identical": same}
+    if a.precision == "f16x3":
+        # cost of reading the range guard the way the Python layer does by default: one one-lane snapshot kernel behind the call + a
+        # wait on ITS event (never the device) -- timed back to back on an idle stream, i.e. with nothing to hide behind
+        torch.cuda.synchronize(dev)
+        n_rt = 200
+        t0 = time.perf_counter()
+        for _ in range(n_rt):
+            eng.take_range(eng.post_range(), block=True)
+        us = (time.perf_counter() - t0) / n_rt * 1e6
+        out["range_guard_read"] = {"us_per_call_post_plus_wait_idle_stream": round(us, 1),
+                                   "frac_of_one_sampling": round(us * 1e-3 / max(modes["eager_2stream"], 1e-9), 6),
+                                   "note": "d3d_engine_range_post + d3d_engine_range_take(block) per call; the timed region above posts "
+                                           "one ticket per sampling and reads it behind the step's own synchronisation"}
     batch = {"inputs_2d": x2d, "inputs_3d": gt[:x2d.shape[0]], "init_noise": noise, "init_noise_flip": noise}
     tv, res = timed(lambda: evaluate(diff, [batch], scale=1.0, device=dev, verbose=False), n=1)
     out["evaluate_equiv_frames_per_s"] = {"value": round(Bl * T / tv, 1), "unit": "frames/s", "windows_per_s": round(Bl / tv, 3),
@@ -193,31 +272,62 @@ def self_launch(n: int) -> int:
         with socket.socket() as sk:           # a free port on the loopback interface
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
+    import signal
     import tempfile
     procs = []
+
+    def end_children(grace=5.0):
+        """terminate() every live child (its whole session: start_new_session below), wait briefly, then kill()."""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                p.terminate()
+        t_end = time.time() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    p.kill()
+                p.wait()
+
+    def on_term(signum, frame):       # a harness that ends only the launcher must not leave ranks waiting in a collective
+        raise KeyboardInterrupt(f"signal {signum}")
+    old_handlers = {sg: signal.signal(sg, on_term) for sg in (signal.SIGTERM, signal.SIGHUP)}
+    first_bad = None
     with tempfile.TemporaryFile() as out0:
-        for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                       MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, D3D_BENCH_LAUNCHER="self")
-            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=out0 if r == 0 else sys.stderr))
-        first_bad = None
-        while any([p.poll() is None for p in procs]):     # (a list: every child is polled each round)
-            for r, p in enumerate(procs):
-                if first_bad is None and p.returncode not in (None, 0):
-                    first_bad = (r, p.returncode)
-                    for q in procs:            # a dead rank leaves the others waiting in a collective: end exactly our children
-                        if q.poll() is None:
-                            q.terminate()
-            time.sleep(0.05)
+        try:
+            for r in range(n):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                           MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, D3D_BENCH_LAUNCHER="self")
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                              stdout=out0 if r == 0 else sys.stderr, start_new_session=True))
+            while any([p.poll() is None for p in procs]):     # (a list: every child is polled each round)
+                for r, p in enumerate(procs):
+                    if first_bad is None and p.returncode not in (None, 0):
+                        first_bad = (r, p.returncode)
+                        end_children()         # a dead rank leaves the others waiting in a collective: end exactly our children
+                time.sleep(0.05)
+        except KeyboardInterrupt as ex:
+            print(f"bench.py self-launch: interrupted ({ex or 'SIGINT'}); ending the rank processes", file=sys.stderr)
+            first_bad = first_bad or (-1, 130)
+        finally:
+            end_children()                     # whatever ends the launcher -- Ctrl-C, SIGTERM, an exception -- no rank outlives it
+            for sg, h in old_handlers.items():
+                signal.signal(sg, h)
         out0.seek(0)
         sys.stdout.write(out0.read().decode(errors="replace"))
         sys.stdout.flush()
     if first_bad is None:
         first_bad = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
     if first_bad is not None:
-        print(f"bench.py self-launch: rank {first_bad[0]} failed with exit code {first_bad[1]}", file=sys.stderr)
+        if first_bad[0] >= 0:
+            print(f"bench.py self-launch: rank {first_bad[0]} failed with exit code {first_bad[1]}", file=sys.stderr)
         return first_bad[1] if 0 < first_bad[1] < 256 else 1
     return 0
 
@@ -227,7 +337,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU (weak scaling: the global batch is --batch x --gpus)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="global batch, split over the ranks by parallel.shard_bounds (ragged allowed; overrides --batch)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch sequences per GPU; strong: the global batch is fixed -- 512 = BASELINE configs[2] exactly "
+                         "unless --global-batch says otherwise -- and split over the ranks (legal at N=1: 34 GB of workspace)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--frames", type=int, default=243)
     ap.add_argument("--sampling", type=int, default=9)
     ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3", "bf16"],
@@ -251,6 +367,17 @@ def main():
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the bitwise batch-vs-pair check (profiling passes: keeps the kernel tables to the timed workload)")
     a = ap.parse_args()
 
+    if a.cpu_worker:                 # child of cpu_baseline_concurrent: CPU only
+        T_, seed_, th_, run_ = a.cpu_worker.split(",")
+        cpu_worker(int(T_), int(seed_), int(th_), float(run_))
+        return
+    if os.environ.get("D3D_BENCH_LAUNCHER") == "self":
+        try:                         # a rank of self_launch(): end with the launcher even if that one is SIGKILLed (PR_SET_PDEATHSIG)
+            import ctypes
+            import signal
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM))
+        except Exception:
+            pass
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher (before torch or HIP are touched)
         sys.exit(self_launch(a.gpus))
@@ -277,7 +404,7 @@ def main():
     from diff3dhpe_amd import parallel
     from diff3dhpe_amd.engine import tta_mpjpe
     from diff3dhpe_amd.spec import DenoiserConfig
-    from diff3dhpe_amd.synth import synth_state_dict, synth_inputs
+    from diff3dhpe_amd.synth import synth_state_dict, synth_inputs_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -302,8 +429,12 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    T, S, Bl = a.frames, a.sampling, a.batch
-    Bg = Bl * world
+    T, S = a.frames, a.sampling
+    Bg = a.global_batch if a.global_batch is not None else (512 if a.scaling == "strong" else a.batch * world)
+    lo, hi = parallel.shard_bounds(Bg, rank, world)
+    Bl = hi - lo                                    # this rank's shard: ranks differ by one row when Bg % world != 0, and a rank
+    if Bg < 1:                                      # beyond a tiny global batch holds NO row (it still joins the collective)
+        raise SystemExit("bench.py: the global batch must hold at least one sequence")
     cfg = DenoiserConfig(num_frame=T, embed_dim=512, depth=8, seq2frame=a.seq2frame, with_time_emb=not a.no_time_emb)
     net = d3d.HPE_model(d3d.S2F_NAME if a.seq2frame else d3d.S2S_NAME)(
         num_frame=T, num_joints=17, in_chans=2, embed_dim=512, depth=8, num_heads=8, mlp_ratio=2., qkv_bias=True,
@@ -313,14 +444,16 @@ def main():
     diff = d3d.GaussianDiffusion(model=net, timesteps=1000, sampling_timesteps=S, loss_type="l2", clip_denoised=True,
                                  beta_schedule="cosine", ddim_sampling_eta=0.0, clipLoss=True).eval().to(dev)
 
-    # global synthetic batch; each rank keeps its contiguous shard resident in HBM before the timed region
-    inp = synth_inputs(Bg, T, seed=42)
-    lo, hi = parallel.shard_bounds(Bg, rank, world)
-    x2d = torch.from_numpy(inp["x2d"][lo:hi]).to(dev)
-    noise = torch.from_numpy(inp["noise"][lo:hi]).to(dev)
-    gt = torch.from_numpy(inp["gt3d"]).to(dev)
+    # synthetic batch: every rank builds ONLY its contiguous shard (row i of the global batch is a function of i alone:
+    # synth.synth_inputs_rows) and keeps it resident in HBM before the timed region; the ground truth every rank needs for the
+    # reduction over the gathered predictions is assembled ONCE, before the timed region, by the same all-gather the path uses
+    inp = synth_inputs_rows(lo, hi, T, seed=42)
+    x2d = torch.from_numpy(inp["x2d"]).to(dev)
+    noise = torch.from_numpy(inp["noise"]).to(dev)
+    gt_local = torch.from_numpy(inp["gt3d"]).to(dev)
     if a.seq2frame:   # one target frame per window (DIFF-S2F): noise / ground truth of the centre frame
-        noise, gt = noise[:, :1].contiguous(), gt[:, T // 2:T // 2 + 1].contiguous()
+        noise, gt_local = noise[:, :1].contiguous(), gt_local[:, T // 2:T // 2 + 1].contiguous()
+    gt = parallel.all_gather_pred(gt_local, Bg) if world > 1 else gt_local
     eng = diff._engine(dev)
     eng.set_option("streams", a.streams)
     for kv in a.option:
@@ -328,8 +461,15 @@ def main():
         eng.set_option(k, int(v))
     ag_events = []                                # (start, end) event pairs around the exchange step of every timed step
 
+    first_done = []                               # wall-clock time at which this rank's first sampling + reduction had completed
+    tickets = []                                  # one F16X3 range-guard ticket per sampling: posted behind it, READ after the
+                                                  # step's own synchronisation (the read-back of the MPJPE sums) -- never a wait of its own
+    guard_on = a.precision == "f16x3"
+
     def step(record=False):
         pred = eng.ddim_sample(x2d, noise)
+        if guard_on:
+            tickets.append(eng.post_range())
         if record and use_dist:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -337,7 +477,10 @@ def main():
         if record and use_dist:
             e1.record()                           # (the current stream waits for the collective before anything behind it)
             ag_events.append((e0, e1))
-        return tta_mpjpe(pred, None, gt if world > 1 else gt[lo:hi], None, 1.0, [], [])
+        res = tta_mpjpe(pred, None, gt, None, 1.0, [], [])          # (reads the two sums back: the step's synchronisation)
+        if not first_done:
+            first_done.append(time.time())
+        return res
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -349,6 +492,7 @@ def main():
         eng.set_graph_mode(True)
     for _ in range(a.warmup):
         step()
+    tickets.clear()
     # ---- timed region: the engine as a user gets it -- per-kernel event timing OFF
     fence()
     t0 = time.perf_counter()
@@ -357,6 +501,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     rank_ms = elapsed / a.steps * 1e3
+    try:                                          # process creation -> first sampling (and its reduction) done on this rank
+        import psutil
+        t_created = psutil.Process().create_time()
+    except Exception:
+        t_created = _T_IMPORT
+    startup_s = (first_done[0] - t_created) if first_done else None
+    range_flags = 0
+    for tk in tickets:                            # the timed samplings' range flags (every snapshot has long run: no wait)
+        range_flags |= eng.take_range(tk, block=True) or 0
     rank_stats = None
     if use_dist:
         cdev = dev if backend == "nccl" else "cpu"
@@ -365,13 +518,21 @@ def main():
         tmin = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         ag_ms = sum(e0.elapsed_time(e1) for e0, e1 in ag_events) / max(len(ag_events), 1)
-        agt = torch.tensor([ag_ms], dtype=torch.float64, device=cdev)
-        dist.all_reduce(agt, op=dist.ReduceOp.MAX)
+        agt = torch.tensor([ag_ms, float(startup_s or 0.0), float(range_flags)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(agt, op=dist.ReduceOp.MAX)       # (flags: the max over ranks is non-zero iff any rank saw one)
+        range_flags_any = int(agt[2])
         rank_stats = {"ms_per_step_min_over_ranks": round(float(tmin[0]) / a.steps * 1e3, 3),
                       "ms_per_step_max_over_ranks": round(float(tmax[0]) / a.steps * 1e3, 3),
                       "this_rank_ms_per_step": round(rank_ms, 3),
                       "allgather_ms_per_step_max_over_ranks": round(float(agt[0]), 4),
                       "allgather_bytes_per_rank": int(noise.numel() * 4),
+                      "startup_s_max_over_ranks": round(float(agt[1]), 2),
+                      "startup_note": "process creation -> this rank's first sampling + reduction done (imports, weight commit, rendezvous, "
+                                      "first-launch code-object loads); max over ranks",
+                      "range_flags": range_flags_any,
+                      "local_batch_min_max": [Bg // world, Bg // world + (1 if Bg % world else 0)],
+                      "data_built_per_rank": "its own shard only (synth_inputs_rows); the ground truth of the gathered batch is assembled once, "
+                                             "before the timed region, by the path's own all-gather",
                       "allgather_note": "event-timed on the launch stream around parallel.all_gather_pred (includes waiting for the slowest rank's sampling)"}
         elapsed = float(tmax[0])
     if a.graph:
@@ -391,7 +552,7 @@ def main():
     # self-check of the timed configuration (no oracle runs at this size): the first two sequences of the batch, sampled
     # again as a batch of two (the small-problem kernels the golden-vector tests cover), must come out bit-identical
     selfcheck = None
-    if not a.no_selfcheck:
+    if not a.no_selfcheck and Bl >= 2:
         pred_big = eng.ddim_sample(x2d, noise)
         pred_two = eng.ddim_sample(x2d[:2].contiguous(), noise[:2].contiguous())
         selfcheck = bool(torch.equal(pred_big[:2], pred_two)) and bool(torch.isfinite(pred_big).all())
@@ -427,6 +588,19 @@ def main():
             if a.precision == "f16x3":
                 roof["note"] = ("achieved = algorithmic (fp32-equivalent) flops; the kernel issues 3 fp16 MFMAs per product, "
                                 f"i.e. {ach * 3:.0f} TFLOP/s of fp16 MFMA work against the 2500 TFLOP/s dense fp16 peak")
+            if prof_fam and d is prof_fam:
+                # what the family figure counts: the GEMMs' 2 M N K AND, for the two fused kernels, the attention products
+                # 4 M keys D they run in the same launch -- both on the fp16 matrix pipe as three MFMAs per product, so the x3 of
+                # `machine_probes.roofline_frac_of_sustained_mfma` applies to all of it; the GEMM-only figure (attention flops left out,
+                # time unchanged: a LOWER bound on the GEMM rate) is given beside it for comparison with earlier rounds' "linear"
+                Mrows, Dw = Bl * T * 17, 512
+                gemm_fl = (prof["linear"]["flops"] + sum(prof[k]["launches"] * 2.0 * Mrows * 3 * Dw * Dw for k in ("qkv_sattn", "qkv_tattn")
+                                                            if prof.get(k, {}).get("launches")))
+                roof["frac_definition"] = ("family = plain GEMM launches + the two fused qkv/attention kernels; flops = GEMM 2MNK + the fused "
+                                           "kernels' attention products (4 M keys D), all issued as 3 fp16 MFMAs per product; "
+                                           "peak = 2500/3 TFLOP/s")
+                roof["gemm_only"] = {"flops_share": round(gemm_fl / d["flops"], 4),
+                                     "frac_lower_bound": round(gemm_fl / (d["ms"] * 1e-3) / 1e12 / peak, 4)}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4)}
@@ -473,17 +647,23 @@ def main():
         line = {
             "metric": "pose_sequences_per_sec", "value": round(value, 3), "unit": "pose-seq/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[a.precision],
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": DTYPE_NAME[a.precision],
             "data": "synthetic",
             "config": {"workload": f"H36M-CPN-shape 2D windows T={T} J=17, MixSTE{'-S2F' if a.seq2frame else ''} D=512 depth=8 "
-                                   f"random-init, {S} DDIM steps, B={Bl}/GPU"
-                                   + (" (BASELINE configs[2] per-GPU shard)" if (T, S, Bl) == (243, 9, 64) and not a.seq2frame else "")
-                                   + ", eta=0, clip_denoised",
+                                   f"random-init, {S} DDIM steps, "
+                                   + (f"B={Bl}/GPU" if Bg == Bl * world else f"global B={Bg} over {world} GPU(s) (this rank {Bl})")
+                                   + (" (BASELINE configs[2] per-GPU shard)" if (T, S, Bl) == (243, 9, 64) and Bg == 64 * world and not a.seq2frame else "")
+                                   + (" (BASELINE configs[2] exactly: B=512)" if (T, S, Bg) == (243, 9, 512) and not a.seq2frame else "")
+                                   + f", eta=0, clip_denoised, {a.scaling} scaling",
                        "global_batch": Bg, "frames": T, "sampling_timesteps": S, "parallelism": f"dp{world}",
                        "precision": a.precision},
             "whole_step_tflops": round(whole, 2),
             "mpjpe_vs_synthetic_gt": round(err / max(cnt, 1), 6),
             "selfcheck_batch_vs_pair_bit_identical": selfcheck,
+            # F16X3 range guard over the timed samplings (OR over steps, max over ranks): must be 0 -- a non-zero word means the timed
+            # results were NOT fp32-accurate (include/d3d.h D3D_RANGE_*); null for precisions without the guard
+            "range_flags": (range_flags_any if use_dist else range_flags) if guard_on else None,
+            "startup_s": round(startup_s, 2) if startup_s is not None else None,
             "headline_under": ("2-stream" if (a.streams == 2 and Bl >= 2) else "eager") + ("+graph" if a.graph else ""),
             "roofline": roof,
         }
@@ -540,8 +720,13 @@ def main():
             except Exception as ex:      # a probe never fails a bench run
                 line["machine_probes"] = {"error": str(ex)[:200]}
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(T, S, 0, a.cpu_budget)
-            line["speedup_vs_cpu_baseline"] = round(value / max(line["cpu_baseline"]["value"], 1e-9), 1)
+            line["cpu_baseline"] = cb = cpu_baseline(T, S, 0, a.cpu_budget)
+            allc = (cb.get("all_cores_concurrent") or {}).get("value")
+            line["speedup_vs_cpu_baseline"] = {
+                "vs_single_process": round(value / max(cb["value"], 1e-9), 1),
+                "vs_all_cores_concurrent": round(value / allc, 1) if allc else None,
+                "note": "single process = the reference's own form (one Python process, its best thread count); all cores = as many "
+                        "concurrent B=1 oracle processes as the node's usable CPUs hold.  A baseline statement, not a kernel-quality claim"}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -76,9 +76,10 @@ __host__ __device__ __forceinline__ size_t pair_col_acc(int c) {
 // exceeds 15.99): |x| > 8188 does not fit (clamped to +-65504 by the row / attention kernels, inf behind the GEMM epilogues'
 // v_fma_mix split).  Every device-side plane writer therefore tracks max |value| per lane and ORs a bit into the sticky word its
 // launcher handed it (launch_range_word(): the launching ENGINE's word) when one left the range (one atomic per lane that saw one:
-// none in a healthy run).  Bits of the word: 1 = a plane value left the range, 2 = a folded LayerNorm met a row with |mean| > 16 sigma.
+// none in a healthy run).  Bits of the word: 1 = a plane value left the range, 2 = a folded LayerNorm met a row with |mean| > 16 sigma,
+// 4 = a timestep index of q_sample / the p_losses tail outside [0, num_timesteps) (not a precision matter: raised in every mode).
 constexpr float X3_HALF_MAX = 65504.0f;
-constexpr unsigned RANGE_BIT_ACT = 1u, RANGE_BIT_STATS = 2u;
+constexpr unsigned RANGE_BIT_ACT = 1u, RANGE_BIT_STATS = 2u, RANGE_BIT_INDEX = 4u;
 __device__ __forceinline__ void range_raise(unsigned* rw, unsigned bit) { if (rw) atomicOr(rw, bit); }
 
 // ---- kernels_gemm.hip -------------------------------------------------------------------------------------------
@@ -245,12 +246,13 @@ struct HeadArgs {
 };
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 
+hipError_t launch_range_snapshot(unsigned* word, unsigned* host_slot_dev, hipStream_t s);   // d3d_engine_range_post
 hipError_t launch_q_sample(const float* x_start, const float* noise, const int32_t* t, const float* sqrt_ac,
-                           const float* somac, float* out, int B, int64_t n, hipStream_t s);
+                           const float* somac, float* out, int B, int64_t n, int nt, hipStream_t s);
 
 // p_losses tail (DIFF:411-418) and the repeat_n tiling / hypothesis mean of forward() (DIFF:433-448); n = elements per batch row
 hipError_t launch_weighted_loss(const float* model_out, const float* target, const int32_t* t, const float* ac, const float* somac,
-                                float* out, int B, int64_t n, int l2, int clip, hipStream_t s);
+                                float* out, int B, int64_t n, int l2, int clip, int nt, hipStream_t s);
 hipError_t launch_repeat_rows(const float* x, float* out, int B, int64_t n, int R, hipStream_t s);
 hipError_t launch_hypothesis_mean(const float* pred, float* out, int B, int64_t n, int R, hipStream_t s);
 

@@ -91,6 +91,13 @@ struct d3d_engine {
   int device = -1;                // ordinal of the device the weights were committed on
   unsigned* range_dev = nullptr;  // F16X3 range guard: THIS engine's sticky word (device memory; every plane-writing kernel launched
                                   // for this engine ORs into it -- d3d_kernels.h LaunchCtx::range_word)
+  // d3d_engine_range_post / _take: snapshots of the word without a blocking synchronisation -- a ring of pinned, device-mapped host
+  // slots (one per ticket), each with the event recorded behind its snapshot kernel
+  static constexpr int RANGE_TICKETS = 256;
+  unsigned* range_host = nullptr;      // hipHostMalloc'ed, RANGE_TICKETS words
+  unsigned* range_host_dev = nullptr;  // the same memory as the device addresses it
+  std::vector<hipEvent_t> range_ev;
+  long long range_posted = 0;          // tickets handed out so far (ticket t lives in slot t % RANGE_TICKETS)
 
   float* arena = nullptr;  // all weights, device
   size_t arena_floats = 0;
@@ -146,6 +153,8 @@ struct d3d_engine {
     drop_graphs();
     (void)hipFree(trace_dev);
     (void)hipFree(range_dev);
+    if (range_host) (void)hipHostFree(range_host);
+    for (auto ev : range_ev) (void)hipEventDestroy(ev);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     if (side_stream) (void)hipStreamDestroy(side_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -719,6 +728,11 @@ int check_ready(const d3d_engine* e, int B, const void* ws, size_t ws_bytes) {
 
 }  // namespace
 
+static inline uint32_t range_bits_to_abi(unsigned w, bool weights_clamped) {
+  return ((w & d3d::RANGE_BIT_ACT) ? D3D_RANGE_ACT : 0u) | (weights_clamped ? D3D_RANGE_WEIGHT : 0u) |
+         ((w & d3d::RANGE_BIT_STATS) ? D3D_RANGE_STATS : 0u) | ((w & d3d::RANGE_BIT_INDEX) ? D3D_RANGE_INDEX : 0u);
+}
+
 // Range-guard sink of launches that belong to no engine (the single-op hooks): one word per device, written, never read.
 unsigned* d3d::range_sink_word() {
   static std::atomic<unsigned*> words[64];
@@ -737,7 +751,7 @@ unsigned* d3d::range_sink_word() {
 extern "C" {
 
 const char* d3d_last_error(void) { return g_err.c_str(); }
-int d3d_version(void) { return 122; }
+int d3d_version(void) { return 130; }
 
 int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out) {
   // torch.linspace(-1, N-1, S+1) in fp32 (two-sided evaluation around the midpoint), .int() truncation, reversed
@@ -862,6 +876,13 @@ int d3d_engine_commit_weights(d3d_engine* e) {
   if (!e->range_dev) {
     HIP_TRY(hipMalloc(&e->range_dev, 256));
     HIP_TRY(hipMemset(e->range_dev, 0, 256));
+  }
+  if (!e->range_host) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->range_host), d3d_engine::RANGE_TICKETS * sizeof(unsigned), hipHostMallocMapped));
+    memset(e->range_host, 0, d3d_engine::RANGE_TICKETS * sizeof(unsigned));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->range_host_dev), e->range_host, 0));
+    e->range_ev.resize(d3d_engine::RANGE_TICKETS, nullptr);
+    for (auto& ev : e->range_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   if (e->cfg.precision == D3D_PREC_F16X3) {
     // fp16 hi/lo pair layout of the four GEMM weights of every block, rows padded to a multiple of 256 (zero rows) so
@@ -1311,7 +1332,8 @@ int d3d_q_sample(d3d_engine* e, const float* x_start, const float* noise, const 
   if (!e || !x_start || !noise || !t_dev || !out) return fail(D3D_EINVAL, "null argument");
   if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set");
   if (!e->has_sqrt_ac) return fail(D3D_ESTATE, "sqrt_alphas_cumprod not supplied (d3d_engine_set_sqrt_alphas_cumprod)");
-  HIP_TRY(launch_q_sample(x_start, noise, t_dev, e->sqrt_ac_dev, e->somac_dev, out, B, n, reinterpret_cast<hipStream_t>(stream)));
+  RangeScope range_scope(e);   // an out-of-table timestep raises D3D_RANGE_INDEX in this engine's word
+  HIP_TRY(launch_q_sample(x_start, noise, t_dev, e->sqrt_ac_dev, e->somac_dev, out, B, n, e->num_timesteps, reinterpret_cast<hipStream_t>(stream)));
   return D3D_OK;
 }
 
@@ -1320,8 +1342,9 @@ int d3d_weighted_loss(d3d_engine* e, const float* model_out, const float* target
   if (!e || !model_out || !target || !t_dev || !out || B < 1 || n < 1) return fail(D3D_EINVAL, "bad argument");
   if (loss_type != 1 && loss_type != 2) return fail(D3D_EINVAL, "loss_type: 1 = l1, 2 = l2 (DIFF:368-375)");
   if (!e->sched_set) return fail(D3D_ESTATE, "schedule not set");
+  RangeScope range_scope(e);
   HIP_TRY(launch_weighted_loss(model_out, target, t_dev, e->ac_dev, e->somac_dev, out, B, n, loss_type == 2, clip_loss != 0,
-                               reinterpret_cast<hipStream_t>(stream)));
+                               e->num_timesteps, reinterpret_cast<hipStream_t>(stream)));
   return D3D_OK;
 }
 
@@ -1426,8 +1449,44 @@ int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* 
   unsigned w = 0;
   HIP_TRY(hipMemcpy(&w, e->range_dev, sizeof(unsigned), hipMemcpyDeviceToHost));
   if (clear && w) HIP_TRY(hipMemset(e->range_dev, 0, sizeof(unsigned)));
-  *flags = ((w & RANGE_BIT_ACT) ? D3D_RANGE_ACT : 0u) | (e->weights_clamped ? D3D_RANGE_WEIGHT : 0u) |
-           ((w & RANGE_BIT_STATS) ? D3D_RANGE_STATS : 0u);
+  *flags = range_bits_to_abi(w, e->weights_clamped);
+  return D3D_OK;
+}
+
+int d3d_engine_range_post(d3d_engine* e, void* stream, int64_t* ticket) {
+  if (!e || !ticket) return fail(D3D_EINVAL, "null argument");
+  if (!e->committed) return fail(D3D_ESTATE, "weights not committed");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  HIP_TRY(hipStreamIsCapturing(s, &cs));
+  if (cs != hipStreamCaptureStatusNone) return fail(D3D_ESTATE, "d3d_engine_range_post inside a stream capture");
+  const long long t = e->range_posted;
+  const int slot = (int)(t % d3d_engine::RANGE_TICKETS);
+  e->range_host[slot] = 0;   // (the slot's previous ticket is RANGE_TICKETS posts old: no longer readable, see _take)
+  HIP_TRY(launch_range_snapshot(e->range_dev, e->range_host_dev + slot, s));
+  HIP_TRY(hipEventRecord(e->range_ev[slot], s));
+  e->range_posted = t + 1;
+  *ticket = t;
+  return D3D_OK;
+}
+
+int d3d_engine_range_take(d3d_engine* e, int64_t ticket, int32_t block, uint32_t* flags, int32_t* ready) {
+  if (!e || !flags || !ready) return fail(D3D_EINVAL, "null argument");
+  if (ticket < 0 || ticket >= e->range_posted) return fail(D3D_EINVAL, "no such range ticket");
+  if (ticket + d3d_engine::RANGE_TICKETS <= e->range_posted) return fail(D3D_EINVAL, "range ticket expired (256 are kept)");
+  const int slot = (int)(ticket % d3d_engine::RANGE_TICKETS);
+  *ready = 0;
+  if (block) {
+    HIP_TRY(hipEventSynchronize(e->range_ev[slot]));
+  } else {
+    const hipError_t q = hipEventQuery(e->range_ev[slot]);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return D3D_OK; }
+    HIP_TRY(q);
+  }
+  const unsigned w = __atomic_load_n(&e->range_host[slot], __ATOMIC_ACQUIRE);
+  if (!(w & 0x80000000u)) return fail(D3D_EHIP, "range snapshot slot not written behind its event");
+  *flags = range_bits_to_abi(w, e->weights_clamped);
+  *ready = 1;
   return D3D_OK;
 }
 

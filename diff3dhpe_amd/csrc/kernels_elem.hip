@@ -550,18 +550,23 @@ hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_q_sample(const float* __restrict__ x_start, const float* __restrict__ noise,
                                                   const int32_t* __restrict__ t, const float* __restrict__ sqrt_ac,
                                                   const float* __restrict__ somac, float* __restrict__ out, int B,
-                                                  int64_t n) {
+                                                  int64_t n, int nt, unsigned* __restrict__ rw) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)B * n) return;
   const int tb = t[gid / n];
+  if (tb < 0 || tb >= nt) {   // the reference's table[t] raises IndexError (DIFF:21-24); here: no table read, a NaN row, a sticky bit
+    out[gid] = __builtin_nanf("");
+    if (gid % n == 0) range_raise(rw, RANGE_BIT_INDEX);
+    return;
+  }
   out[gid] = __fadd_rn(__fmul_rn(sqrt_ac[tb], x_start[gid]), __fmul_rn(somac[tb], noise[gid]));
 }
 
 hipError_t launch_q_sample(const float* x_start, const float* noise, const int32_t* t, const float* sqrt_ac,
-                           const float* somac, float* out, int B, int64_t n, hipStream_t s) {
+                           const float* somac, float* out, int B, int64_t n, int nt, hipStream_t s) {
   const int64_t total = (int64_t)B * n;
   hipLaunchKernelGGL(k_q_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x_start, noise, t, sqrt_ac,
-                     somac, out, B, n);
+                     somac, out, B, n, nt, launch_range_word());
   return hipGetLastError();
 }
 
@@ -571,10 +576,15 @@ hipError_t launch_q_sample(const float* x_start, const float* noise, const int32
 __global__ __launch_bounds__(256) void k_weighted_loss(const float* __restrict__ model_out, const float* __restrict__ target,
                                                        const int32_t* __restrict__ t, const float* __restrict__ ac,
                                                        const float* __restrict__ somac, float* __restrict__ out, int B, int64_t n,
-                                                       int l2, int clip) {
+                                                       int l2, int clip, int nt, unsigned* __restrict__ rw) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)B * n) return;
   const int tb = t[gid / n];
+  if (tb < 0 || tb >= nt) {   // (as in k_q_sample: the reference raises IndexError on alphas_cumprod[t], DIFF:411)
+    out[gid] = __builtin_nanf("");
+    if (gid % n == 0) range_raise(rw, RANGE_BIT_INDEX);
+    return;
+  }
   float coef = __fadd_rn(1.0f, __fdiv_rn(ac[tb], somac[tb]));
   if (clip) coef = fminf(coef, 3.0f);
   const float d = __fadd_rn(model_out[gid], -target[gid]);
@@ -582,10 +592,22 @@ __global__ __launch_bounds__(256) void k_weighted_loss(const float* __restrict__
 }
 
 hipError_t launch_weighted_loss(const float* model_out, const float* target, const int32_t* t, const float* ac, const float* somac,
-                                float* out, int B, int64_t n, int l2, int clip, hipStream_t s) {
+                                float* out, int B, int64_t n, int l2, int clip, int nt, hipStream_t s) {
   const int64_t total = (int64_t)B * n;
   hipLaunchKernelGGL(k_weighted_loss, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, model_out, target, t, ac, somac, out,
-                     B, n, l2, clip);
+                     B, n, l2, clip, nt, launch_range_word());
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ range-guard snapshot
+// d3d_engine_range_post: ONE lane exchanges the engine's sticky word with zero and hands the value to the host through a pinned,
+// device-mapped slot (bit 31 marks the slot as written); the event recorded behind this launch is what the host waits on or polls.
+__global__ void k_range_snapshot(unsigned* __restrict__ word, unsigned* __restrict__ host_slot) {
+  const unsigned w = atomicExch(word, 0u);
+  __hip_atomic_store(host_slot, w | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_range_snapshot(unsigned* word, unsigned* host_slot_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_range_snapshot, dim3(1), dim3(1), 0, s, word, host_slot_dev);
   return hipGetLastError();
 }
 

@@ -556,7 +556,9 @@ hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, cons
   if (n_cu <= 0) return hipErrorUnknown;
   const int tiles = a.mtiles * 8;
   const int grid = tiles < n_cu ? tiles : n_cu;
-  if (g_qs_diag.load() > 0) {   // "qs_diag" option: every 50th launch with stamps, summarised on stderr (synchronises the stream)
+  hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;   // the stamp report allocates, synchronises and copies: illegal inside a
+  (void)hipStreamIsCapturing(s, &cap_st);                          // hipGraph capture (d3d_engine_set_graph_mode) -- plain launch there
+  if (g_qs_diag.load() > 0 && cap_st == hipStreamCaptureStatusNone) {   // "qs_diag" option: every 50th launch with stamps, summarised on stderr (synchronises the stream)
     static std::atomic<int> count{0};
     if (count.fetch_add(1) % 50 == 10) {
       unsigned long long* buf = nullptr;

@@ -9,7 +9,6 @@ The only host arithmetic left here is the init-time fp64 schedule tables (DIFF:1
 from __future__ import annotations
 
 import math
-import os
 import warnings
 from typing import List, Optional
 
@@ -87,14 +86,15 @@ class GaussianDiffusion(nn.Module):
         for name, val in tables.items():  # registered as fp32 in this order (DIFF:149-183)
             self.register_buffer(name, val.to(torch.float32))
         self._sched_sig = {}
-        # debug mode (or D3D_CHECK_RANGE=1): after every sampling ask the engine's F16X3 range guard whether an operand left the
-        # fp16 range of its planes and raise D3DError if so (one stream synchronisation per call; include/d3d.h)
-        self.check_range = os.environ.get("D3D_CHECK_RANGE", "").strip().lower() in ("1", "true", "yes", "on")
+        # The F16X3 range guard is READ after every engine call of this class (sampling, forward_denoise, p_losses) unless the model's
+        # range_check is off (D3D_CHECK_RANGE=0): nets._MixSTEDenoiser._guarded -- precision "auto" repeats a flagged call on the
+        # exact-fp32 engine, "f16x3" raises D3DError.
 
     # ------------------------------------------------------------------ engine plumbing
-    def _engine(self, device: torch.device):
-        eng = self.model.engine_for(device)
-        sig = (id(eng), self.model._engine_sig.get(device.index if device.index is not None else torch.cuda.current_device()),
+    def _engine(self, device: torch.device, fallback: bool = False):
+        eng = self.model.engine_for(device, fallback)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        sig = (id(eng), (self.model._engine_sig_fb if fallback else self.model._engine_sig).get(idx),
                self.sampling_timesteps, float(self.ddim_sampling_eta), bool(self.clip_denoised),
                self.alphas_cumprod.data_ptr(), self.alphas_cumprod._version)
         key = id(eng)
@@ -136,19 +136,16 @@ class GaussianDiffusion(nn.Module):
     @torch.no_grad()
     def ddim_sample_loop(self, x_in, target_shape, init_noise=None, step_noise=None):
         dev, init_noise, step_noise = self._draw(x_in, target_shape, init_noise, step_noise)
-        eng = self._engine(dev)
-        y0 = eng.ddim_sample(x_in, init_noise, step_noise)
-        if self.check_range:
-            eng.check_range()
+        y0 = self.model._guarded(lambda fb: self._engine(dev, fb), lambda eng: eng.ddim_sample(x_in, init_noise, step_noise),
+                                 "ddim_sample_loop")
         return y0.to(x_in.device)
 
     @torch.no_grad()
     def ddim_sample_loop_ouput_reverse_diffusion(self, x_in, target_shape, init_noise=None, step_noise=None):
         dev, init_noise, step_noise = self._draw(x_in, target_shape, init_noise, step_noise)
-        eng = self._engine(dev)
-        y0, rev, x0s = eng.ddim_sample(x_in, init_noise, step_noise, trajectory=True)
-        if self.check_range:
-            eng.check_range()
+        y0, rev, x0s = self.model._guarded(lambda fb: self._engine(dev, fb),
+                                           lambda eng: eng.ddim_sample(x_in, init_noise, step_noise, trajectory=True),
+                                           "ddim_sample_loop_ouput_reverse_diffusion")
         if self.seq2frame:  # DIFF-S2F:319 records the initial noise as trajectory entry 0
             rev = torch.cat([init_noise.to(rev.device).unsqueeze(-1), rev], dim=-1)
         return y0.to(x_in.device), rev.to(x_in.device), x0s.to(x_in.device)
@@ -188,17 +185,20 @@ class GaussianDiffusion(nn.Module):
     def p_losses(self, x_start, pose_2d, noise=None, t=None):
         """Forward-only weighted loss (DIFF:392-419): q_sample and the denoiser run in the engine; no autograd."""
         b = x_start.shape[0]
-        if t is None:
+        own_t = t is None
+        if own_t:
             t = torch.randint(0, self.num_timesteps, (b,), device=x_start.device).long()
         if noise is None:
             noise = torch.randn_like(x_start)
-        x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
-        dev = self.model._compute_device(pose_2d, self.betas)
-        eng = self._engine(dev)
-        model_out = eng.denoise(pose_2d, x_noisy, t)                                     # y broadcast over T for seq2frame
         self.loss_fn                                                                     # (ValueError on an unknown loss_type, DIFF:375)
-        # the variable loss weight 1 + k_t, its clamp and the loss itself (DIFF:411-418) are one engine kernel (d3d_weighted_loss)
-        return eng.weighted_loss(model_out, x_start, t, self.loss_type, self.clipLoss).to(x_start.device)
+        dev = self.model._compute_device(pose_2d, self.betas)
+
+        def run(eng):
+            x_noisy = eng.q_sample(x_start, t, noise, check_t=not own_t)
+            model_out = eng.denoise(pose_2d, x_noisy, t)                                 # y broadcast over T for seq2frame
+            # the variable loss weight 1 + k_t, its clamp and the loss itself (DIFF:411-418) are one engine kernel (d3d_weighted_loss)
+            return eng.weighted_loss(model_out, x_start, t, self.loss_type, self.clipLoss, check_t=False)
+        return self.model._guarded(lambda fb: self._engine(dev, fb), run, "p_losses").to(x_start.device)
 
     # ------------------------------------------------------------------ forward (DIFF:421-449)
     def forward(self, clean_3d_pose, noisy_2d_pose, noise=None, output_reverse_diffusion_3d=False, output_loss=True,

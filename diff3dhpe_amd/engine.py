@@ -36,6 +36,7 @@ class Engine:
         self._ws: Optional[torch.Tensor] = None
         self._ws_B = 0
         self.sampling_timesteps = None
+        self.num_timesteps = None
         self.weights_version = None
 
     def __del__(self):
@@ -90,6 +91,7 @@ class Engine:
                 sa = np.ascontiguousarray(sqrt_alphas_cumprod.detach().cpu().numpy(), dtype=np.float32)
                 _lib.check(_lib.lib().d3d_engine_set_sqrt_alphas_cumprod(self._h, sa.ctypes.data_as(C.c_void_p), sa.size))
         self.sampling_timesteps = int(sampling_timesteps)
+        self.num_timesteps = int(ac.size)
         self.eta = float(eta)
 
     # ---------------------------------------------------------------- compute
@@ -177,15 +179,36 @@ class Engine:
             _lib.check(_lib.lib().d3d_engine_range_flags(self._h, C.byref(f), int(clear), self._stream()))
         return int(f.value)
 
+    @staticmethod
+    def describe_range_flags(f: int) -> str:
+        what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"),
+                               (_lib.RANGE_WEIGHT, "a non-finite (or beyond ~1e9: unrepresentable) GEMM weight"),
+                               (_lib.RANGE_STATS, "a LayerNorm input row with |mean| > 16 standard deviations (one-pass statistics)"),
+                               (_lib.RANGE_INDEX, "a timestep index outside [0, num_timesteps)")) if f & b]
+        return " and ".join(what) if what else "nothing"
+
     def check_range(self) -> None:
-        """Raise D3DError if the F16X3 range guard fired since the last check (use precision='fp32' then)."""
+        """Raise D3DError if the F16X3 range guard fired since the last check (use precision='fp32' then).  Synchronises the stream;
+        the Python classes use post_range() / take_range() instead."""
         f = self.range_flags(clear=True)
         if f:
-            what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"), (_lib.RANGE_WEIGHT, "a non-finite (or beyond ~1e9: unrepresentable) GEMM weight"),
-                                   (_lib.RANGE_STATS, "a LayerNorm input row with |mean| > 16 standard deviations (one-pass statistics)"))
-                    if f & b]
-            raise _lib.D3DError("F16X3 operand range exceeded by " + " and ".join(what) +
+            raise _lib.D3DError("F16X3 operand range exceeded by " + self.describe_range_flags(f) +
                                 ": results are not fp32-accurate for this checkpoint/input -- use precision='fp32'")
+
+    def post_range(self) -> int:
+        """Enqueue a snapshot (and reset) of this engine's range word behind everything on the current stream; returns its ticket
+        (include/d3d.h d3d_engine_range_post).  No synchronisation."""
+        t = C.c_int64(-1)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_engine_range_post(self._h, self._stream(), C.byref(t)))
+        return int(t.value)
+
+    def take_range(self, ticket: int, block: bool = True) -> Optional[int]:
+        """Flags of a ticket; block=True waits for THAT snapshot's event only, block=False returns None while it has not run."""
+        f, ready = C.c_uint32(0), C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().d3d_engine_range_take(self._h, int(ticket), int(bool(block)), C.byref(f), C.byref(ready)))
+        return int(f.value) if ready.value else None
 
     def set_trace(self, capacity: int, views: int = 1) -> None:
         """Debug trace: checksum every buffer the block-flow kernels write (0 turns it off); views: see include/d3d.h."""
@@ -236,10 +259,23 @@ class Engine:
             _lib.check(_lib.lib().d3d_op_time_embedding(self._h, _ptr(t), n, _ptr(out), _ptr(scratch), self._stream()))
         return out
 
-    def q_sample(self, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    def _timesteps(self, t: torch.Tensor, B: int, check: bool = True) -> torch.Tensor:
+        """(B,) integer timesteps for the table gathers of q_sample / the p_losses tail, checked like the reference's `table[t]`
+        (extract, DIFF:21-24: IndexError outside the table; a short t cannot be broadcast).  Cold path: one tiny reduction."""
+        t = t.detach().reshape(-1)
+        if t.numel() != B:
+            raise IndexError(f"timestep tensor has {t.numel()} entries for a batch of {B}")
+        n = self.num_timesteps
+        if B and n is not None and check:       # (check=False: t was drawn by p_losses itself -- in range by construction; the kernels
+            lo, hi = int(t.min()), int(t.max())
+            if lo < 0 or hi >= n:
+                raise IndexError(f"timestep index out of range: [{lo}, {hi}] outside [0, {n})")   # still bound-check every gather)
+        return t.to(device=self.device, dtype=torch.int32).contiguous()
+
+    def q_sample(self, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, check_t: bool = True) -> torch.Tensor:
         B = x_start.shape[0]
         xs, nz = _f32c(x_start, self.device), _f32c(noise, self.device)
-        ti = t.detach().to(device=self.device, dtype=torch.int32).contiguous()
+        ti = self._timesteps(t, B, check_t)
         out = torch.empty_like(xs)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().d3d_q_sample(self._h, _ptr(xs), _ptr(nz), _ptr(ti), _ptr(out), B, xs.numel() // B,
@@ -247,12 +283,13 @@ class Engine:
         return out
 
 
-    def weighted_loss(self, model_out: torch.Tensor, target: torch.Tensor, t: torch.Tensor, loss_type: str, clip_loss: bool) -> torch.Tensor:
+    def weighted_loss(self, model_out: torch.Tensor, target: torch.Tensor, t: torch.Tensor, loss_type: str, clip_loss: bool,
+                      check_t: bool = True) -> torch.Tensor:
         """p_losses tail (DIFF:411-418): loss_fn(model_out, target, 'none') * min(1 + ac[t] / sqrt(1 - ac)[t], 3 if clip_loss)."""
         B = target.shape[0]
         mo, tg = _f32c(model_out, self.device), _f32c(target, self.device)
         assert mo.shape == tg.shape, (mo.shape, tg.shape)
-        ti = t.detach().to(device=self.device, dtype=torch.int32).contiguous()
+        ti = self._timesteps(t, B, check_t)
         out = torch.empty_like(tg)
         if B == 0:
             return out

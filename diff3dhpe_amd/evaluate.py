@@ -53,26 +53,42 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
         torch.cuda.synchronize(dev)
         t0 = time.time()
         shape = gt[sl].shape
-        pred_f = None
-        if hi == lo:        # fewer windows than ranks: nothing to sample on this rank (forward() cannot take an empty batch)
-            pred = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
-            pred_f = pred.clone() if test_time_augmentation else None
-        else:
-            _, pred = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d[sl].to(dev), output_loss=False,
-                                      init_noise=None if batch.get("init_noise") is None else batch["init_noise"][sl])
-        if test_time_augmentation and hi > lo:
-            _, pred_f = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d_f[sl].to(dev), output_loss=False,
-                                        init_noise=None if batch.get("init_noise_flip") is None else batch["init_noise_flip"][sl])
-        gsl = sl
-        if world > 1:   # the ONE exchange step: all-gather the predicted sequences; every rank then reduces the full batch
-            if pred_f is not None:   # the TTA pair travels together: (b, 2, T, J, 3) shards, one collective per batch
-                both = parallel.all_gather_pred(torch.stack([pred, pred_f], dim=1), B)
-                pred, pred_f = both[:, 0], both[:, 1]
+
+        def run_batch():
+            pred_f = None
+            if hi == lo:        # fewer windows than ranks: nothing to sample on this rank (forward() cannot take an empty batch)
+                pred = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+                pred_f = pred.clone() if test_time_augmentation else None
             else:
-                pred = parallel.all_gather_pred(pred, B)
-            gsl = slice(0, B)
-        err, cnt = tta_mpjpe(pred, pred_f, gt[gsl].to(dev), None if mask is None else mask[gsl].to(dev), scale,
-                             list(joints_left), list(joints_right))
+                _, pred = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d[sl].to(dev), output_loss=False,
+                                          init_noise=None if batch.get("init_noise") is None else batch["init_noise"][sl])
+            if test_time_augmentation and hi > lo:
+                _, pred_f = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d_f[sl].to(dev), output_loss=False,
+                                            init_noise=None if batch.get("init_noise_flip") is None else batch["init_noise_flip"][sl])
+            gsl = sl
+            if world > 1:   # the ONE exchange step: all-gather the predicted sequences; every rank then reduces the full batch (the
+                # reduction is redundant x world: 3 MB per rank at cfg3, one kernel -- cheaper than a second collective for the sums)
+                if pred_f is not None:   # the TTA pair travels together: (b, 2, T, J, 3) shards, one collective per batch
+                    both = parallel.all_gather_pred(torch.stack([pred, pred_f], dim=1), B)
+                    pred, pred_f = both[:, 0], both[:, 1]
+                else:
+                    pred = parallel.all_gather_pred(pred, B)
+                gsl = slice(0, B)
+            return tta_mpjpe(pred, pred_f, gt[gsl].to(dev), None if mask is None else mask[gsl].to(dev), scale,
+                             list(joints_left), list(joints_right))     # (reads the two sums back: the batch's one synchronisation)
+
+        net = getattr(getattr(model_diffusion, "module", model_diffusion), "model", None)
+        if world == 1 and hasattr(net, "deferred_range_checks"):
+            # the range guard of the two samplings is read HERE, behind the synchronisation the batch makes anyway (no wait of its
+            # own); a flagged batch is repeated on the model's exact-fp32 engine (precision "auto") or raises D3DError ("f16x3")
+            rng = torch.cuda.get_rng_state(dev)          # (a repeated batch draws the same noise: the reference's generator sequence)
+            with net.deferred_range_checks() as pending:
+                err, cnt = run_batch()
+            if pending.resolve():
+                torch.cuda.set_rng_state(rng, dev)
+                err, cnt = run_batch()
+        else:   # several ranks: a rank must know its own flags BEFORE its shard enters the all-gather -- each sampling waits on its ticket
+            err, cnt = run_batch()
         torch.cuda.synchronize(dev)
         secs += time.time() - t0
         tot_err += err

@@ -8,6 +8,9 @@ the HIP engine (libd3d_hip.so) and fails loudly when there is no HIP device.
 """
 from __future__ import annotations
 
+import os
+import warnings
+from contextlib import contextmanager
 from typing import Dict, Optional
 
 import torch
@@ -53,9 +56,18 @@ class _BlockParams(_Holder):
 
 class _MixSTEDenoiser(nn.Module):
     _seq2frame = False
-    # engine arithmetic mode ("f16x3": fp32-accurate GEMMs/temporal attention from 3 fp16 MFMAs on hi/lo operand
-    # splits; "fp32": fp32 MFMA).  Both pass the 1e-4 parity gate; override per instance before first use.
-    precision = "f16x3"
+    # engine arithmetic mode; override per instance (or on the class) at any time:
+    #   "auto"  (default) the F16X3 engine, with its range guard READ after every call (see _guarded below): when a checkpoint / input
+    #           leaves the range in which F16X3 is fp32-accurate, the call is repeated on a lazily created exact-fp32 engine, a one-time
+    #           warning names the flag, and the model stays on the fp32 engine until its weights change (or reset_precision_fallback())
+    #   "f16x3" fp32-accurate GEMMs / attention from 3 fp16 MFMAs on hi/lo operand splits; a set range flag RAISES D3DError
+    #   "fp32"  exact fp32 MFMA everywhere
+    #   "bf16"  second-class (bf16 operands; cannot meet the 1e-4 gate; BASELINE configs[1])
+    # "auto", "f16x3" and "fp32" pass the 1e-4 parity gate.  The reference loads arbitrary checkpoints (RUN:226-235): results that
+    # are silently not fp32-accurate are not an option, hence the guard is on by default (D3D_CHECK_RANGE=0 or range_check = False
+    # turns the read off: one ~2 us kernel + one event wait per call).
+    precision = "auto"
+    range_check = os.environ.get("D3D_CHECK_RANGE", "1").strip().lower() not in ("0", "false", "no", "off")
     # One process per GPU is the supported multi-GPU form (torchrun; parallel.py).  nn.DataParallel over SEVERAL devices in one
     # process (RUN:216-218 with --gpu_id 0,1,...) would need one engine per device driven from DataParallel's worker threads:
     # that path has never run on hardware, so it fails loudly instead of being trusted.  Flip this to try it anyway.
@@ -94,6 +106,11 @@ class _MixSTEDenoiser(nn.Module):
         # engines are shared (by reference) with DataParallel replicas, keyed by device index
         self._engines: Dict[int, Engine] = {}
         self._engine_sig: Dict[int, object] = {}
+        self._engines_fb: Dict[int, Engine] = {}       # "auto": the exact-fp32 engines the guard falls back to, made on first need
+        self._engine_sig_fb: Dict[int, object] = {}
+        # guard state, one dict shared (by reference) with DataParallel replicas: "fallback" = weights signature for which the guard
+        # fired ("auto" then runs the fp32 engine directly), "warned", "deferred" = open list of Pending checks (evaluate.py), "stats"
+        self._guard = {"fallback": None, "warned": False, "deferred": None, "posted": 0, "flagged": 0, "reruns": 0}
         self._src_sig = None
 
     # ------------------------------------------------------------------ engine management
@@ -117,7 +134,11 @@ class _MixSTEDenoiser(nn.Module):
         replica._src_sig = self._param_signature()
         return replica
 
-    def engine_for(self, device: torch.device) -> Engine:
+    def _primary_precision(self) -> str:
+        return "f16x3" if self.precision == "auto" else self.precision
+
+    def engine_for(self, device: torch.device, fallback: bool = False) -> Engine:
+        """The engine of this model on `device`; fallback=True: the exact-fp32 engine precision="auto" repeats a flagged call on."""
         if device.type != "cuda":
             raise _lib.D3DError("engine_for() needs a HIP device")
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -127,22 +148,88 @@ class _MixSTEDenoiser(nn.Module):
             if moved:   # the module itself was moved (.to('cuda:1') after running on cuda:0): one device at a time -- release the
                 self._engines.clear()         # stale engine (its weights, tables and workspace live on the old device)
                 self._engine_sig.clear()
+                self._engines_fb.clear()
+                self._engine_sig_fb.clear()
             else:
                 raise _lib.D3DError(
                     f"this model already runs on cuda:{next(iter(self._engines))} and is now asked to run on cuda:{idx}: diff3dhpe_amd "
                     "supports ONE device per process (launch one process per GPU: `python bench.py --gpus N`, torchrun --nproc-per-node "
                     "N, or pass one id to --gpu_id); nn.DataParallel over several devices in one process is untested -- set "
                     "allow_multi_device = True on the model class to try it (moving the whole module with .to() is fine)")
-        eng = self._engines.get(idx)
-        if eng is None or eng.precision != self.precision:
-            eng = Engine(self.cfg, precision=self.precision, device=torch.device("cuda", idx))
-            self._engines[idx] = eng
-            self._engine_sig[idx] = None
+        engines, sigs = (self._engines_fb, self._engine_sig_fb) if fallback else (self._engines, self._engine_sig)
+        want = "fp32" if fallback else self._primary_precision()
+        eng = engines.get(idx)
+        if eng is None or eng.precision != want:
+            eng = Engine(self.cfg, precision=want, device=torch.device("cuda", idx))
+            engines[idx] = eng
+            sigs[idx] = None
         sig = self._src_sig if self._src_sig is not None else self._param_signature()
-        if self._engine_sig.get(idx) != sig:
+        if sigs.get(idx) != sig:
             eng.load_weights(self._named_tensors())
-            self._engine_sig[idx] = sig
+            sigs[idx] = sig
         return eng
+
+    # ------------------------------------------------------------------ the range guard, read by default
+    def reset_precision_fallback(self) -> None:
+        """precision="auto": go back to the F16X3 engine after the guard moved this model to the fp32 engine."""
+        self._guard["fallback"] = None
+
+    def _weights_sig(self):
+        return self._src_sig if self._src_sig is not None else self._param_signature()
+
+    def _on_fallback(self) -> bool:
+        return self.precision == "auto" and self._guard["fallback"] is not None and self._guard["fallback"] == self._weights_sig()
+
+    def _flagged(self, flags: int, what: str) -> None:
+        """A range flag was read for a call of this model: "auto" moves the model to the fp32 engine (the caller repeats the call);
+        every other precision raises."""
+        self._guard["flagged"] += 1
+        msg = Engine.describe_range_flags(flags)
+        if self.precision != "auto":
+            raise _lib.D3DError(f"{what}: F16X3 operand range exceeded by {msg}: the result is not fp32-accurate for this checkpoint / "
+                                "input -- use precision='auto' (repeats such calls on the exact-fp32 engine) or precision='fp32'")
+        self._guard["fallback"] = self._weights_sig()
+        if not self._guard["warned"]:
+            self._guard["warned"] = True
+            warnings.warn(f"diff3dhpe_amd: {what}: the F16X3 range guard fired ({msg}); precision='auto' repeats the call on the "
+                          "exact-fp32 engine and keeps this model there until its weights change (reset_precision_fallback() to retry)",
+                          RuntimeWarning, stacklevel=4)
+
+    def _guarded(self, get_engine, fn, what: str):
+        """Run fn(engine) on the model's engine and READ the F16X3 range guard for it (no device-wide synchronisation: one one-lane
+        kernel behind the call, one wait on ITS event).  get_engine(fallback) -> a ready engine.  With an open deferred list
+        (deferred_range_checks(): evaluate() resolves it at its own per-batch synchronisation) the read is postponed."""
+        if self._on_fallback():
+            return fn(get_engine(True))
+        eng = get_engine(False)
+        res = fn(eng)
+        if not self.range_check or eng.precision != "f16x3":
+            return res
+        ticket = eng.post_range()
+        self._guard["posted"] += 1
+        pend = self._guard["deferred"]
+        if pend is not None:
+            pend.append((eng, ticket, what))
+            return res
+        flags = eng.take_range(ticket, block=True)
+        if not flags:
+            return res
+        self._flagged(flags, what)              # raises unless "auto"
+        self._guard["reruns"] += 1
+        return fn(get_engine(True))
+
+    @contextmanager
+    def deferred_range_checks(self):
+        """Inside: guarded calls only POST their range tickets.  The yielded object's resolve() -- call it behind a synchronisation
+        the caller makes anyway -- reads them all: False = every call was in range; True = precision="auto" has moved the model to
+        its fp32 engine and the caller must repeat the work of the block; other precisions raise D3DError."""
+        outer = self._guard["deferred"]
+        box = _Deferred(self)
+        self._guard["deferred"] = box.items
+        try:
+            yield box
+        finally:
+            self._guard["deferred"] = outer
 
     def _compute_device(self, *tensors) -> torch.device:
         for t in tensors:
@@ -160,13 +247,35 @@ class _MixSTEDenoiser(nn.Module):
     def forward_denoise(self, x: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
         """x: (B,T,J,in_chans+3) = cat([2D pose, noisy 3D pose], -1); time: (B,) long|float -> (B,T,J,3) [(B,1,J,3) S2F]."""
         dev = self._compute_device(x)
-        eng = self.engine_for(dev)
         c = self.cfg.in_chans
-        out = eng.denoise(x[..., :c], x[..., c:], time if self.cfg.with_time_emb else None)
+        out = self._guarded(lambda fb: self.engine_for(dev, fb),
+                            lambda eng: eng.denoise(x[..., :c], x[..., c:], time if self.cfg.with_time_emb else None), "forward_denoise")
         return out.to(x.device)
 
     def forward(self, x, time):
         return self.forward_denoise(x, time)
+
+
+class _Deferred:
+    """Range tickets posted inside _MixSTEDenoiser.deferred_range_checks()."""
+
+    def __init__(self, net: _MixSTEDenoiser):
+        self.net = net
+        self.items = []
+
+    def resolve(self) -> bool:
+        flags, what = 0, None
+        for eng, ticket, w in self.items:
+            f = eng.take_range(ticket, block=True)
+            if f:
+                flags |= f
+                what = what or w
+        self.items.clear()
+        if not flags:
+            return False
+        self.net._flagged(flags, what)          # raises unless "auto"
+        self.net._guard["reruns"] += 1
+        return True
 
 
 class ConditionalDiffusionMixSTES2SGRANDLinLift(_MixSTEDenoiser):

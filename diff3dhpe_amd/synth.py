@@ -110,6 +110,16 @@ def synth_inputs(B: int, T: int, J: int = 17, seed: int = 42, cpn_jitter: bool =
     return {"x2d": x2d, "noise": noise, "gt3d": gt}
 
 
+def synth_inputs_rows(lo: int, hi: int, T: int, J: int = 17, seed: int = 42, cpn_jitter: bool = True):
+    """Rows lo..hi-1 of an unbounded synthetic batch in which row i is `synth_inputs(1, T, J, seed = hash(seed, i))` -- the recipe of
+    SURVEY.md section 8d applied per sequence, so that a rank of a multi-GPU run builds ITS shard in O(shard) host work and any
+    sharding of the batch yields the same rows (bench.py)."""
+    rows = [synth_inputs(1, T, J, seed=(int(seed) * 1000003 + i) & 0x7FFFFFFF, cpn_jitter=cpn_jitter) for i in range(lo, hi)]
+    if not rows:
+        return {"x2d": np.zeros((0, T, J, 2), np.float32), "noise": np.zeros((0, T, J, 3), np.float32), "gt3d": np.zeros((0, T, J, 3), np.float32)}
+    return {k: np.concatenate([r[k] for r in rows], axis=0) for k in rows[0]}
+
+
 # ---------------------------------------------------------------------------------------------- synthetic mocap data set
 SYNTH_JOINTS_LEFT = [4, 5, 6, 11, 12, 13]      # 17-joint skeleton sides (what the reference's H36M skeleton has after remove_joints)
 SYNTH_JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]

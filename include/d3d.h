@@ -148,8 +148,9 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
  *                     +2.9 % at T=243 / B=64, neutral at T=81 / T=27).  Per-kernel profiling and the trace force one stream.
  * Process-wide diagnostics (e may be NULL): "gemm_diag", "attn_diag" 0 / 1: the op hooks print in-kernel stamp reports to stderr
- * (attn_diag needs a -DD3D_ATTN_DIAG_BUILD library); "qs_diag" 0 / 1: every 50th launch of the fused spatial kernel runs with
- * per-step stamps and prints their summary to stderr (that launch synchronises its stream).  Unknown key: D3D_EINVAL. */
+ * (attn_diag needs a -DD3D_ATTN_DIAG_BUILD library); "qs_diag" / "qt_diag" 0 / 1: every 50th launch of the fused spatial / fused temporal kernel
+ * runs with per-step stamps and prints their summary to stderr (that launch synchronises its stream; launches inside a hipGraph capture
+ * are never stamped).  The diagnostic switches are PROCESS-wide: they act on every engine.  Unknown key: D3D_EINVAL. */
 int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value);
 
 /* q_sample (DIFF:360-366, extract DIFF:21-24): out = sqrt_ac[t_b] * x_start + sqrt(1-ac)[t_b] * noise, per row b.
@@ -250,7 +251,23 @@ const char* d3d_kernel_class_name(int32_t kernel_class);
 #define D3D_RANGE_ACT 1u
 #define D3D_RANGE_WEIGHT 2u
 #define D3D_RANGE_STATS 4u
+/* not a precision matter, raised in every mode: a timestep handed to d3d_q_sample / d3d_weighted_loss was outside [0, num_timesteps)
+ * (the reference raises IndexError on table[t], DIFF:21-24, 411): the row's output is NaN, no table entry was read */
+#define D3D_RANGE_INDEX 8u
 int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* stream);
+
+/* The guard WITHOUT a blocking synchronisation (ABI version 130) -- what the Python layer does by default after every compute call
+ * (RUN:226-235 loads arbitrary checkpoints, so the default precision has to notice when one is outside its range by itself).
+ * d3d_engine_range_post enqueues on `stream`, behind everything already there, ONE one-lane kernel that exchanges this engine's
+ * word with zero and stores the value into a pinned host slot the engine owns, then records an event; *ticket names that snapshot.
+ * d3d_engine_range_take returns the flags of a ticket (same bits as d3d_engine_range_flags; D3D_RANGE_WEIGHT is sticky):
+ *   block == 0  never waits: *ready = 0 while the snapshot kernel has not run yet (flags untouched), 1 once it has
+ *   block != 0  waits for the ticket's event (NOT for the whole stream or device)
+ * The flags of a ticket cover every kernel launched for this engine on `stream` since the previous post (or read with clear).
+ * 256 tickets are kept; an older one: D3D_EINVAL.  Not legal while `stream` is capturing (D3D_ESTATE).  Measured cost of a post per
+ * d3d_ddim_sample at T = 243 / B = 64: one ~2 us launch in 477 ms. */
+int d3d_engine_range_post(d3d_engine* e, void* stream, int64_t* ticket);
+int d3d_engine_range_take(d3d_engine* e, int64_t ticket, int32_t block, uint32_t* flags, int32_t* ready);
 
 /* ---- debug trace: while on (capacity > 0 slots), every kernel of the F16X3 block flow and the head is followed on `stream`
  * by a checksum launch over the rows it has just written (64-bit position-weighted word sums, order-independent), so two runs

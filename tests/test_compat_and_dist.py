@@ -116,3 +116,37 @@ def test_bench_self_launch_propagates_a_failing_rank():
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     run = _bench(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0", "D3D_BENCH_LAUNCH_CHECK": ""})
     assert run.returncode != 0 and "WORLD_SIZE=3" in (run.stderr + run.stdout)
+
+
+def test_bench_self_launch_eight_rank_processes():
+    """The N = 8 launch the driver makes at round end, without a GPU (launch-check mode): eight rank processes, ONE JSON line on stdout."""
+    import json
+    run = _bench(["--gpus", "8"], {"D3D_BENCH_LAUNCH_CHECK": "1"})
+    assert run.returncode == 0, run.stderr
+    out = [json.loads(l) for l in run.stdout.splitlines() if l.startswith("{")]
+    err = [json.loads(l) for l in run.stderr.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["world_size"] == 8 and sorted(e["rank"] for e in err) == list(range(1, 8))
+
+
+def test_bench_self_launch_ends_its_ranks_when_the_launcher_is_terminated():
+    """a harness that ends only the launcher (SIGTERM) must not orphan rank processes that wait in a collective -- the
+    launcher terminates its children (their own sessions), waits, kills, and exits non-zero."""
+    import signal
+    import time
+    import psutil
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"D3D_BENCH_LAUNCH_CHECK": "1", "D3D_BENCH_LAUNCH_CHECK_FAIL": "99"})     # no rank is 99: every rank sleeps 30 s
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True)
+    kids = []
+    t0 = time.time()
+    while len(kids) < 3 and time.time() - t0 < 20:
+        kids = psutil.Process(p.pid).children()
+        time.sleep(0.1)
+    assert len(kids) == 3
+    time.sleep(0.5)
+    p.send_signal(signal.SIGTERM)
+    _, err = p.communicate(timeout=20)
+    assert p.returncode not in (0, None) and "ending the rank processes" in err
+    gone, alive = psutil.wait_procs(kids, timeout=5)
+    assert not alive

@@ -90,6 +90,7 @@ def test_range_guard_row_statistics_bit(off, expect):
                                       qkv_bias=True, qk_scale=None, drop_path_rate=0.1)
     net.load_state_dict(sd, strict=True)
     net.precision = "f16x3"
+    net.range_check = False              # the raw word is read below (the default reading: tests/test_gpu_round5.py)
     net = net.cuda()
     dev = torch.device("cuda", torch.cuda.current_device())
     eng = net.engine_for(dev)

@@ -1,0 +1,307 @@
+"""Round-5 evidence on the MI355X, through the product API / the C ABI:
+  * the F16X3 range guard is READ BY DEFAULT (no environment variable): precision "auto" -- the default -- repeats a flagged call on
+    the exact-fp32 engine and matches the oracle, "f16x3" raises D3DError; forward_denoise, the sampling loops, p_losses and
+    evaluate() (whose read rides on the batch's own synchronisation) are all covered,
+  * the non-blocking ticket ABI underneath (d3d_engine_range_post / _take),
+  * timestep indices outside the schedule tables: IndexError in Python, NaN rows + D3D_RANGE_INDEX at the C ABI."""
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import cfg_full, inputs, maxabs, torch_sd
+import diff3dhpe_amd as d3d
+from diff3dhpe_amd import _lib
+from diff3dhpe_amd.evaluate import evaluate
+from diff3dhpe_amd.spec import DenoiserConfig
+
+pytestmark = pytest.mark.gpu
+GATE = 1e-4
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _outlier_channel(sd):
+    """A checkpoint with ONE massive channel in the residual stream (|x| ~ 1e4 > 8188: outside the fp16 plane range); fp32 arithmetic
+    handles it (row std ~ 440, no cancellation), so the exact-fp32 engine and the oracle agree to the usual distance."""
+    sd["fusion_layer.bias"][7] += 1.0e4
+
+
+def _all_channels(sd):
+    """Every channel at ~1e4: out of range for F16X3 -- and ill-conditioned for ANY fp32 implementation (LayerNorm of 1e4 + O(1)), so
+    this one is only compared with the product's own fp32 engine, bit for bit."""
+    sd["fusion_layer.bias"] += 1.0e4
+
+
+def _forty_sigma(sd):
+    for k in ("Spatial_norm.bias", "Temporal_norm.bias"):
+        sd[k] = sd[k] + 40.0 * sd[k.replace("bias", "weight")].abs().mean()
+
+
+def _model(cfg, seed, mutate, precision=None, sampling=3):
+    sd = torch_sd(cfg, seed)
+    mutate(sd)
+    net = d3d.HPE_model(d3d.S2F_NAME if cfg.seq2frame else d3d.S2S_NAME)(
+        num_frame=cfg.num_frame, num_joints=17, in_chans=2, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=8, mlp_ratio=2.0,
+        qkv_bias=True, qk_scale=None, drop_path_rate=0.1, with_time_emb=cfg.with_time_emb)
+    net.load_state_dict(sd, strict=True)
+    if precision is not None:
+        net.precision = precision
+    diff = d3d.GaussianDiffusion(model=net, timesteps=1000, sampling_timesteps=sampling, loss_type="l2", clip_denoised=True,
+                                 beta_schedule="cosine", ddim_sampling_eta=0.0, clipLoss=True).eval().cuda()
+    return sd, net, diff
+
+
+def test_default_precision_is_auto_and_the_guard_is_on_without_any_environment_variable():
+    assert "D3D_CHECK_RANGE" not in os.environ
+    net = d3d.HPE_model(d3d.S2S_NAME)(num_frame=9, embed_dim=512, depth=1)
+    assert net.precision == "auto" and net.range_check is True
+    net.load_state_dict(torch_sd(DenoiserConfig(num_frame=9, embed_dim=512, depth=1), 3))
+    eng = net.cuda().engine_for(_dev())
+    assert eng.precision == "f16x3"                      # the engine "auto" starts on
+    assert not net._engines_fb                           # the fp32 engine exists only once the guard has fired
+
+
+@pytest.mark.parametrize("mutate,vs_oracle", [(_outlier_channel, True), (_forty_sigma, True), (_all_channels, False)],
+                         ids=["outlier_channel", "forty_sigma", "all_channels"])
+def test_auto_precision_repeats_flagged_calls_on_the_fp32_engine(mutate, vs_oracle):
+    """The state dicts of test_f16x3_range_guard / test_range_guard_row_statistics_bit through the DEFAULT precision, no env var:
+    forward_denoise, a whole sampling (with trajectories) and p_losses come out as the exact-fp32 engine computes them -- within
+    1e-4 of the oracle where fp32 itself is well-conditioned -- with ONE warning; the same calls with precision "f16x3" raise."""
+    from oracle import d3d_oracle as orc
+    cfg = cfg_full(9)
+    B, S = 3, 3
+    inp = inputs(B, 9, 557)
+    xcat = torch.cat([inp["x2d"], inp["noise"]], dim=-1)
+    t = torch.tensor([999, 400, 3])
+    gt = inp["gt3d"] * 0.5
+    tabs = orc.diffusion_tables("cosine", 1000)
+
+    sd, net, diff = _model(cfg, 77, mutate, sampling=S)                     # precision left at its default
+    with warnings.catch_warnings(record=True) as wlog:
+        warnings.simplefilter("always")
+        out = net.forward_denoise(xcat.cuda(), t.cuda())
+        _, y0, rev, x0s = diff(clean_3d_pose=torch.zeros(B, 9, 17, 3).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False,
+                               init_noise=inp["noise"].cuda(), output_reverse_diffusion_3d=True)
+        _, y0b = diff(clean_3d_pose=torch.zeros(B, 9, 17, 3).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False,
+                      init_noise=inp["noise"].cuda())
+        loss = diff.p_losses(gt.cuda(), inp["x2d"].cuda(), noise=inp["noise"].cuda(), t=t.cuda())
+    ours = [w for w in wlog if "range guard fired" in str(w.message)]
+    assert len(ours) == 1 and issubclass(ours[0].category, RuntimeWarning), [str(w.message) for w in wlog]
+    g = net._guard
+    assert g["flagged"] == 1 and g["reruns"] == 1 and net._on_fallback()     # first call flagged; the later ones went straight to fp32
+    assert list(net._engines_fb) == [torch.cuda.current_device()]
+    assert torch.equal(y0, y0b)
+
+    _, net32, diff32 = _model(cfg, 77, mutate, precision="fp32", sampling=S)
+    out32 = net32.forward_denoise(xcat.cuda(), t.cuda())
+    _, y32, rev32, x0s32 = diff32(clean_3d_pose=torch.zeros(B, 9, 17, 3).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False,
+                                  init_noise=inp["noise"].cuda(), output_reverse_diffusion_3d=True)
+    loss32 = diff32.p_losses(gt.cuda(), inp["x2d"].cuda(), noise=inp["noise"].cuda(), t=t.cuda())
+    for a, b in ((out, out32), (y0, y32), (rev, rev32), (x0s, x0s32), (loss, loss32)):
+        assert torch.equal(a, b)                                             # "auto" after a flag IS the fp32 engine
+    if vs_oracle:
+        ref = orc.forward_denoise(sd, xcat, t, depth=cfg.depth)
+        ref_y = orc.ddim_sample_loop(sd, tabs, inp["x2d"], inp["noise"], num_timesteps=1000, sampling_timesteps=S, depth=cfg.depth)
+        ref_l = orc.p_losses(sd, tabs, gt, inp["x2d"], t, inp["noise"], depth=cfg.depth, clip_loss=True)
+        # the weighted loss is coef * (x0 - target)^2, coef <= 3: an error of the denoiser output arrives multiplied by 2 coef |x0 - target|,
+        # so it is gated relative to the largest loss value (the outputs themselves: the absolute 1e-4 gate)
+        lscale = max(1.0, float(ref_l.abs().max()))
+        e = (maxabs(out, ref), maxabs(y0, ref_y), maxabs(loss, ref_l) / lscale)
+        print(f"auto precision on a flagged checkpoint vs oracle: denoise {e[0]:.2e} sampling {e[1]:.2e} p_losses {e[2]:.2e} (relative to "
+              f"the largest loss value {lscale:.1f})")
+        assert max(e) <= GATE
+
+    # the explicit F16X3 precision keeps raising -- by default, every entry point
+    _, netx, diffx = _model(cfg, 77, mutate, precision="f16x3", sampling=S)
+    with pytest.raises(_lib.D3DError, match="range"):
+        netx.forward_denoise(xcat.cuda(), t.cuda())
+    with pytest.raises(_lib.D3DError, match="range"):
+        diffx(clean_3d_pose=torch.zeros(B, 9, 17, 3).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False, init_noise=inp["noise"].cuda())
+    with pytest.raises(_lib.D3DError, match="range"):
+        diffx(clean_3d_pose=torch.zeros(B, 9, 17, 3).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False, init_noise=inp["noise"].cuda(),
+              output_reverse_diffusion_3d=True)
+    with pytest.raises(_lib.D3DError, match="range"):
+        diffx.p_losses(gt.cuda(), inp["x2d"].cuda(), noise=inp["noise"].cuda(), t=t.cuda())
+    assert not netx._engines_fb
+
+
+def test_auto_precision_stays_on_f16x3_for_a_healthy_checkpoint_and_returns_after_new_weights():
+    cfg = cfg_full(9)
+    inp = inputs(2, 9, 11)
+    xcat = torch.cat([inp["x2d"], inp["noise"]], dim=-1).cuda()
+    t = torch.tensor([500, 20]).cuda()
+    sd, net, diff = _model(cfg, 5, lambda sd: None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        a = net.forward_denoise(xcat, t)
+        diff(clean_3d_pose=torch.zeros(2, 9, 17, 3).cuda(), noisy_2d_pose=inp["x2d"].cuda(), output_loss=False, init_noise=inp["noise"].cuda())
+    assert net._guard["posted"] == 2 and net._guard["flagged"] == 0 and not net._engines_fb and not net._on_fallback()
+    _, netx, _ = _model(cfg, 5, lambda sd: None, precision="f16x3")
+    assert torch.equal(a, netx.forward_denoise(xcat, t))                     # "auto" on a healthy checkpoint IS the F16X3 engine
+    # a flagged checkpoint moves the model to fp32; loading healthy weights brings it back
+    bad = torch_sd(cfg, 5)
+    _outlier_channel(bad)
+    net.load_state_dict(bad)
+    with pytest.warns(RuntimeWarning, match="range guard fired"):
+        net.forward_denoise(xcat, t)
+    assert net._on_fallback()
+    net.load_state_dict(sd)
+    assert not net._on_fallback()
+    assert torch.equal(a, net.forward_denoise(xcat, t))
+    # range_check = False: nothing is posted, nothing is read (the caller has taken the responsibility)
+    net.range_check = False
+    n = net._guard["posted"]
+    net.forward_denoise(xcat, t)
+    assert net._guard["posted"] == n
+
+
+@pytest.mark.parametrize("precision", ["auto", "f16x3"])
+def test_evaluate_reads_the_guard_at_its_own_synchronisation(precision):
+    """evaluate() posts the tickets of its two samplings and reads them behind the batch's own synchronisation (the read-back of the
+    two MPJPE sums): a flagged batch is repeated on the fp32 engine ("auto": MPJPE equal to the fp32 model's) or raises ("f16x3")."""
+    cfg = cfg_full(9)
+    B = 4
+    inp = inputs(B, 9, 21)
+    batch = {"inputs_2d": inp["x2d"].cuda(), "inputs_3d": inp["gt3d"].cuda(), "init_noise": inp["noise"].cuda(),
+             "init_noise_flip": inp["noise"].cuda()}
+    _, net, diff = _model(cfg, 9, _outlier_channel, precision=precision)
+    if precision == "f16x3":
+        with pytest.raises(_lib.D3DError, match="range"):
+            evaluate(diff, [batch], verbose=False)
+        return
+    with pytest.warns(RuntimeWarning, match="range guard fired"):
+        res = evaluate(diff, [batch, batch], verbose=False)
+    assert net._guard["reruns"] == 1 and net._guard["posted"] == 2          # batch 1: two tickets, repeated; batch 2: fp32 directly
+    _, _, diff32 = _model(cfg, 9, _outlier_channel, precision="fp32")
+    ref = evaluate(diff32, [batch, batch], verbose=False)
+    assert res["mpjpe_mm"] == ref["mpjpe_mm"] and res["frames"] == ref["frames"] == 2 * B * 9
+    # a healthy model: tickets posted, none flagged, no fp32 engine
+    _, neth, diffh = _model(cfg, 9, lambda sd: None)
+    evaluate(diffh, [batch], verbose=False)
+    assert neth._guard["posted"] == 2 and neth._guard["flagged"] == 0 and not neth._engines_fb
+
+
+def test_range_ticket_abi():
+    """d3d_engine_range_post / d3d_engine_range_take at the C ABI: a ticket covers the launches since the previous post, reading it
+    waits for ITS event only, a poll never blocks, 256 tickets are kept."""
+    cfg = DenoiserConfig(num_frame=27, embed_dim=512, depth=1)
+    inp = inputs(2, 27, 3)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    _, net, diff = _model(cfg, 8, _all_channels, precision="f16x3", sampling=2)
+    net.range_check = False
+    _, neth, diffh = _model(cfg, 8, lambda sd: None, precision="f16x3", sampling=2)
+    neth.range_check = False
+    eb, eh = diff._engine(_dev()), diffh._engine(_dev())
+    eb.range_flags(clear=True)
+    t_empty = eb.post_range()
+    assert eb.take_range(t_empty) == 0
+    eb.ddim_sample(x2d, nz)
+    eh.ddim_sample(x2d, nz)
+    tb, th = eb.post_range(), eh.post_range()
+    polled = eb.take_range(tb, block=False)                  # never blocks: None (not run yet) or the flags
+    assert polled is None or polled & _lib.RANGE_ACT
+    assert eb.take_range(tb) & _lib.RANGE_ACT and eh.take_range(th) == 0
+    assert eb.take_range(tb) & _lib.RANGE_ACT                # a ticket can be read again ...
+    assert eb.range_flags() == 0                             # ... and its snapshot has reset the engine's word
+    t2 = eb.post_range()
+    assert eb.take_range(t2) == 0                            # nothing launched since tb
+    L = _lib.lib()
+    f, r = C.c_uint32(0), C.c_int32(0)
+    assert L.d3d_engine_range_take(eb._h, 10 ** 6, 1, C.byref(f), C.byref(r)) == _lib_code("EINVAL")
+    assert L.d3d_engine_range_take(eb._h, -1, 1, C.byref(f), C.byref(r)) == _lib_code("EINVAL")
+    for _ in range(256):
+        last = eb.post_range()
+    assert eb.take_range(last) == 0
+    assert L.d3d_engine_range_take(eb._h, t2, 1, C.byref(f), C.byref(r)) == _lib_code("EINVAL") and b"expired" in L.d3d_last_error()
+    # the sticky weight flag travels with every ticket
+    _, netw, diffw = _model(cfg, 8, lambda sd: sd["STEblocks.0.mlp.fc1.weight"].__setitem__((3, 5), float("inf")), precision="f16x3", sampling=2)
+    netw.range_check = False
+    ew = diffw._engine(_dev())
+    assert ew.take_range(ew.post_range()) & _lib.RANGE_WEIGHT
+
+
+def _lib_code(name):
+    return {"EINVAL": -1, "ESTATE": -2}[name]
+
+
+def test_timestep_indices_outside_the_tables():
+    """q_sample / the p_losses tail gather schedule tables by a caller-supplied timestep.  Python raises IndexError like
+    the reference's table[t] (DIFF:21-24, 411); at the C ABI the row comes out NaN, no table entry is read and D3D_RANGE_INDEX rises."""
+    cfg = DenoiserConfig(num_frame=9, embed_dim=512, depth=1)
+    _, net, diff = _model(cfg, 4, lambda sd: None, sampling=2)
+    inp = inputs(3, 9, 5)
+    gt, x2d, nz = inp["gt3d"].cuda(), inp["x2d"].cuda(), inp["noise"].cuda()
+    for bad in ([0, 1000, 5], [-1, 3, 5]):
+        with pytest.raises(IndexError):
+            diff.q_sample(gt, torch.tensor(bad).cuda(), nz)
+        with pytest.raises(IndexError):
+            diff.p_losses(gt, x2d, noise=nz, t=torch.tensor(bad).cuda())
+    with pytest.raises(IndexError):
+        diff.p_losses(gt, x2d, noise=nz, t=torch.tensor([1, 2]).cuda())      # a short t
+    ok = diff.q_sample(gt, torch.tensor([0, 999, 5]).cuda(), nz)
+    assert torch.isfinite(ok).all()
+    eng = diff._engine(_dev())
+    eng.range_flags(clear=True)
+    t = torch.tensor([0, 10 ** 6, -7])
+    out = eng.q_sample(gt, t, nz, check_t=False)
+    assert torch.isfinite(out[0]).all() and torch.isnan(out[1:]).all()
+    assert eng.range_flags() == _lib.RANGE_INDEX
+    lo = eng.weighted_loss(gt, gt * 0.5, t, "l2", True, check_t=False)
+    assert torch.isfinite(lo[0]).all() and torch.isnan(lo[1:]).all()
+    assert eng.take_range(eng.post_range()) == _lib.RANGE_INDEX
+
+
+# ------------------------------------------------------------------------------------------------ many ranks, ragged global batches
+def _bench(args, env, timeout=900):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, cwd=ROOT, timeout=timeout)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "D3D_FORCE_DIST",
+                                                             "D3D_BENCH_ONE_DEVICE", "D3D_DIST_BACKEND")}
+    env.update(extra)
+    return env
+
+
+SMALL = ["--steps", "1", "--warmup", "0", "--frames", "27", "--sampling", "3", "--no-cpu-baseline", "--no-extras", "--profile-steps", "0",
+         "--no-selfcheck"]
+
+
+@pytest.mark.parametrize("gb", [7, 4])
+def test_bench_self_launch_five_ranks_on_one_device_ragged_global_batch(gb):
+    """The unattended multi-GPU run, rehearsed as far as a one-GPU box allows (its process guard admits SIX processes on the card: this
+    test process + FIVE ranks; the eight-process launch itself is exercised without a GPU in tests/test_compat_and_dist.py):
+    `python bench.py --gpus 5 --global-batch 7` -> shards of 2,2,1,1,1 rows; `--global-batch 4` -> 1,1,1,1 and a rank with NO row that
+    still joins the collective.  One JSON line, MPJPE equal to the one-rank value for the same global batch, start-up time and range
+    flags reported over ranks, every rank building only its shard."""
+    many = _bench(["--gpus", "5", "--global-batch", str(gb)] + SMALL, _env(D3D_BENCH_ONE_DEVICE="1", D3D_DIST_BACKEND="gloo"))
+    one = _bench(["--gpus", "1", "--global-batch", str(gb)] + SMALL, _env())
+    assert many["n_gpus"] == 5 and many["config"]["global_batch"] == gb == one["config"]["global_batch"]
+    assert many["mpjpe_vs_synthetic_gt"] == one["mpjpe_vs_synthetic_gt"]
+    r = many["ranks"]
+    assert r["local_batch_min_max"] == [gb // 5, gb // 5 + 1] and r["range_flags"] == 0 and many["range_flags"] == 0 == one["range_flags"]
+    assert 0 < r["startup_s_max_over_ranks"] < 600 and one["startup_s"] > 0
+    assert many["dist"]["launcher"] == "self" and many["dist"]["world_size"] == 5
+    print(f"5 ranks on one device, global batch {gb}: start-up (max over ranks) {r['startup_s_max_over_ranks']} s; one rank: {one['startup_s']} s")
+
+
+def test_bench_strong_scaling_mode_names_itself():
+    """--scaling strong fixes the GLOBAL batch (512 = BASELINE configs[2] unless --global-batch) and splits it over the ranks."""
+    line = _bench(["--gpus", "1", "--scaling", "strong", "--global-batch", "6"] + SMALL, _env())
+    assert line["scaling"] == "strong" and line["config"]["global_batch"] == 6 and "strong scaling" in line["config"]["workload"]
+    weak = _bench(["--gpus", "1", "--batch", "6"] + SMALL, _env())
+    assert weak["scaling"] == "weak" and weak["mpjpe_vs_synthetic_gt"] == line["mpjpe_vs_synthetic_gt"]
