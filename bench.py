@@ -36,6 +36,39 @@ def flops_per_seq_step(T, D=512, J=17):
     return J * T * (256 * D * D + 544 * D + 32 * T * D)       # F(T)
 
 
+def usable_cpus():
+    """(CPUs this process may run on, CPUs its cgroup's CFS quota pays for or None): a GPU box of the pool shows every host CPU in
+    the affinity mask while its container is paid a fraction of them -- more runnable threads than the quota only get throttled."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    cands = ["/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"]
+    try:
+        for ln in open("/proc/self/cgroup").read().splitlines():
+            _, ctrl, path = ln.split(":", 2)
+            if ctrl == "":
+                cands.insert(0, "/sys/fs/cgroup" + path.rstrip("/") + "/cpu.max")
+            elif "cpu" in ctrl.split(","):
+                cands.insert(0, "/sys/fs/cgroup/cpu" + path.rstrip("/") + "/cpu.cfs_quota_us")
+    except Exception:
+        pass
+    for c in cands:
+        try:
+            txt = open(c).read().split()
+            if c.endswith("cpu.max"):
+                q = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                per = float(open(c.replace("cfs_quota_us", "cfs_period_us")).read())
+                q = None if float(txt[0]) <= 0 else float(txt[0]) / per
+            if q is not None:
+                quota = q if quota is None else min(quota, q)
+        except Exception:
+            continue
+    return aff, quota
+
+
 def cpu_baseline(T, S, seed, budget_s=40.0):
     """The oracle (port of the reference's eager op sequence) on the host cores, bounded to ~budget_s of CPU work.
 
@@ -49,10 +82,7 @@ def cpu_baseline(T, S, seed, budget_s=40.0):
     from oracle import d3d_oracle as orc
     from diff3dhpe_amd.spec import DenoiserConfig
     from diff3dhpe_amd.synth import synth_state_dict, synth_inputs
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    avail, quota = usable_cpus()
     cfg = DenoiserConfig(num_frame=T, embed_dim=512, depth=8)
     sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed).items()}
     tabs = orc.diffusion_tables("cosine", 1000)
@@ -88,7 +118,8 @@ def cpu_baseline(T, S, seed, budget_s=40.0):
     d = min(reps)
     return {"value": round(bestB / (d * S), 4), "unit": "pose-seq/s", "cores": best_th, "kind": "port",
             "spread_max_over_min": round(max(reps) / d, 3),
-            "all_cores_concurrent": cpu_baseline_concurrent(T, S, seed, best_th, avail, per_step[1]),
+            "host_cpus": {"affinity": avail, "cgroup_quota": quota},
+            "all_cores_concurrent": cpu_baseline_concurrent(T, S, seed, best_th, avail, per_step[1], quota=quota),
             "sample": f"fp32 eager CPU oracle (port of the reference op sequence; cross-timed against the imported reference in the "
                       f"build container: profiles/r02_cpu_oracle_vs_reference.json), T={T}: thread sweep on 1 DDIM step at B=1 "
                       f"{ {k: round(v, 2) for k, v in sweep.items()} } s; 1 step at B in {sorted(per_step)}: "
@@ -122,13 +153,13 @@ def cpu_worker(T, seed, threads, run_s):
     print(json.dumps({"steps": n, "seconds": time.time() - t0}), flush=True)
 
 
-def cpu_baseline_concurrent(T, S, seed, best_th, avail, step_s_alone, run_s=8.0, max_procs=16):
+def cpu_baseline_concurrent(T, S, seed, best_th, avail, step_s_alone, run_s=8.0, max_procs=16, quota=None):
     """The same oracle on ALL of this node's usable cores at once: k = usable CPUs // best_th processes (capped), each a B=1
     sampling loop on best_th threads, started together; throughput = whole DDIM steps finished by all of them / wall / S.  This is
     the figure "the node's own host cores" can deliver for independent windows -- the single-process number above is the
     reference's own form (one Python process, RUN).  Children are fresh processes that never touch the GPU."""
     import subprocess
-    k = max(1, min(max_procs, avail // max(best_th, 1)))
+    k = max(1, min(max_procs, avail // max(best_th, 1)))     # the affinity mask decides how many are STARTED; what the cgroup quota
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{T},{seed},{best_th},{run_s}"]
     env = dict(os.environ, OMP_NUM_THREADS=str(best_th), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     procs = []
@@ -149,10 +180,11 @@ def cpu_baseline_concurrent(T, S, seed, best_th, avail, step_s_alone, run_s=8.0,
         steps = sum(o["steps"] for o in outs)
         return {"value": round(steps / wall / S, 4), "unit": "pose-seq/s", "processes": k, "threads_per_process": best_th,
                 "cores": k * best_th, "steps_finished": steps, "wall_s": round(wall, 2),
-                "one_process_alone_s_per_step": round(step_s_alone, 3),
+                "one_process_alone_s_per_step": round(step_s_alone, 3), "cgroup_cpu_quota": quota,
                 "s_per_step_under_load": round(max(o["seconds"] / o["steps"] for o in outs), 3),
                 "note": f"{k} concurrent B=1 oracle processes x {best_th} threads for ~{run_s:.0f} s each, whole DDIM steps counted, scaled to "
-                        f"{S} steps per sequence; host has {avail} usable CPUs"}
+                        f"{S} steps per sequence; {avail} CPUs in the affinity mask, cgroup CFS quota {quota} (a quota below processes x threads "
+                        "throttles them: the figure is what THIS container is given, not what the bare node could do)"}
     except Exception as ex:
         return {"value": None, "error": str(ex)[:200], "processes": k}
     finally:

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libd3d_hip.so")
 
 PREC_FP32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 KC_COUNT = 13
-RANGE_ACT, RANGE_WEIGHT, RANGE_STATS, RANGE_INDEX = 1, 2, 4, 8
+RANGE_ACT, RANGE_WEIGHT, RANGE_STATS, RANGE_INDEX, RANGE_RECOMPUTE = 1, 2, 4, 8, 16
+RANGE_PRECISION = RANGE_ACT | RANGE_WEIGHT | RANGE_STATS        # the bits that mean "not fp32-accurate in F16X3"
 PRECISIONS = {"fp32": PREC_FP32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}
 
 # every symbol include/d3d.h declares (tests/test_abi.py checks the library exports all of them)
@@ -24,7 +25,7 @@ ABI_SYMBOLS = [
     "d3d_engine_profile_read", "d3d_kernel_class_name", "d3d_op_linear_bench", "d3d_op_linear_postnorm", "d3d_engine_set_graph_mode", "d3d_num_windows", "d3d_window_gather",
     "d3d_engine_set_trace", "d3d_engine_trace_read", "d3d_engine_range_flags", "d3d_op_head", "d3d_engine_set_option",
     "d3d_weighted_loss", "d3d_repeat_batch", "d3d_hypothesis_mean", "d3d_engine_get_info", "d3d_probe_machine",
-    "d3d_engine_range_post", "d3d_engine_range_take",
+    "d3d_engine_range_post", "d3d_engine_range_take", "d3d_window_gather_s2f",
 ]
 
 
@@ -71,6 +72,7 @@ def _bind(lib: C.CDLL) -> None:
         "d3d_engine_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "d3d_num_windows": (C.c_int, [i32, i32]),
         "d3d_window_gather": (C.c_int, [vp, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), i32, vp, vp, vp]),
+        "d3d_window_gather_s2f": (C.c_int, [vp, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), i32, i32, i32, vp, vp]),
         "d3d_engine_range_flags": (C.c_int, [vp, C.POINTER(C.c_uint32), i32, vp]),
         "d3d_engine_range_post": (C.c_int, [vp, vp, C.POINTER(i64)]),
         "d3d_engine_range_take": (C.c_int, [vp, i64, i32, C.POINTER(C.c_uint32), C.POINTER(i32)]),

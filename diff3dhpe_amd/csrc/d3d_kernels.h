@@ -77,9 +77,10 @@ __host__ __device__ __forceinline__ size_t pair_col_acc(int c) {
 // v_fma_mix split).  Every device-side plane writer therefore tracks max |value| per lane and ORs a bit into the sticky word its
 // launcher handed it (launch_range_word(): the launching ENGINE's word) when one left the range (one atomic per lane that saw one:
 // none in a healthy run).  Bits of the word: 1 = a plane value left the range, 2 = a folded LayerNorm met a row with |mean| > 16 sigma,
-// 4 = a timestep index of q_sample / the p_losses tail outside [0, num_timesteps) (not a precision matter: raised in every mode).
+// 4 = a timestep index of q_sample / the p_losses tail outside [0, num_timesteps) (not a precision matter: raised in every mode),
+// 8 = the head kernel's duplicated dot product disagreed with itself (kernels_elem.hip k_head: repaired by a third evaluation).
 constexpr float X3_HALF_MAX = 65504.0f;
-constexpr unsigned RANGE_BIT_ACT = 1u, RANGE_BIT_STATS = 2u, RANGE_BIT_INDEX = 4u;
+constexpr unsigned RANGE_BIT_ACT = 1u, RANGE_BIT_STATS = 2u, RANGE_BIT_INDEX = 4u, RANGE_BIT_RECOMPUTE = 8u;
 __device__ __forceinline__ void range_raise(unsigned* rw, unsigned bit) { if (rw) atomicOr(rw, bit); }
 
 // ---- kernels_gemm.hip -------------------------------------------------------------------------------------------
@@ -243,6 +244,8 @@ struct HeadArgs {
   const float* noise;    // nullable (rows,3)
   float alpha, alpha_next, somac, eta;
   float* traj_rev; float* traj_x0; int traj_rev_stride, traj_x0_stride, traj_idx;   // nullable
+  unsigned* range;       // filled in by launch_head: the launching engine's guard word (RANGE_BIT_RECOMPUTE)
+  int inject;            // tests only ("head_inject" option): perturb the first evaluation of row 0
 };
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 
@@ -263,6 +266,8 @@ hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const flo
 
 hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const JointPerm& perm, int n, int T, int J, int C,
                                 int flip, hipStream_t s);
+hipError_t launch_window_gather_s2f(const float* seq, float* out, const JointPerm& perm, int n, int T, int J, int C, int first, int count,
+                                    int flip, hipStream_t s);
 
 // debug trace: *out += position-weighted 64-bit sum of the buffer's 32-bit words (order-independent)
 hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, int rot, hipStream_t s);

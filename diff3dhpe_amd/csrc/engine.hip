@@ -86,6 +86,9 @@ struct d3d_engine {
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
+  // "head_inject" (tests only): the head kernel perturbs the FIRST of its two evaluations of row 0's dot products, so that its
+  // run-time fence -- compare, third evaluation, D3D_RANGE_RECOMPUTE -- can be seen working (kernels_elem.hip k_head)
+  int opt_head_inject = 0;
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int device = -1;                // ordinal of the device the weights were committed on
@@ -698,6 +701,7 @@ int head_rows(const d3d_engine* e, int B) { return e->cfg.seq2frame ? B * e->J :
 // fills X / rows for the head (runs the seq2frame frame reduce first when needed)
 int prep_head(d3d_engine* e, HeadArgs& h, int B, const Workspace& w, hipStream_t s) {
   h.g = e->hd_g; h.b = e->hd_b; h.eps = 1e-5f; h.Wh = e->hd_w; h.bh = e->hd_bias; h.D = e->D;
+  h.inject = e->opt_head_inject;
   h.rows = head_rows(e, B);
   if (e->cfg.seq2frame) {
     Prof p(e, D3D_KC_OTHER, 2.0 * B * e->T * e->J * e->D, 4.0 * B * e->T * e->J * e->D, s);
@@ -730,7 +734,8 @@ int check_ready(const d3d_engine* e, int B, const void* ws, size_t ws_bytes) {
 
 static inline uint32_t range_bits_to_abi(unsigned w, bool weights_clamped) {
   return ((w & d3d::RANGE_BIT_ACT) ? D3D_RANGE_ACT : 0u) | (weights_clamped ? D3D_RANGE_WEIGHT : 0u) |
-         ((w & d3d::RANGE_BIT_STATS) ? D3D_RANGE_STATS : 0u) | ((w & d3d::RANGE_BIT_INDEX) ? D3D_RANGE_INDEX : 0u);
+         ((w & d3d::RANGE_BIT_STATS) ? D3D_RANGE_STATS : 0u) | ((w & d3d::RANGE_BIT_INDEX) ? D3D_RANGE_INDEX : 0u) |
+         ((w & d3d::RANGE_BIT_RECOMPUTE) ? D3D_RANGE_RECOMPUTE : 0u);
 }
 
 // Range-guard sink of launches that belong to no engine (the single-op hooks): one word per device, written, never read.
@@ -1311,6 +1316,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   else if (k == "fused_temporal") e->opt_fused_temporal = value != 0;
   else if (k == "fc1_kernel") e->opt_fc1_kernel = value != 0;
   else if (k == "proj_kernel") e->opt_proj_kernel = value != 0;
+  else if (k == "head_inject") e->opt_head_inject = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
     e->opt_streams = (int)value;
@@ -1438,6 +1444,24 @@ int d3d_window_gather(const float* seq, int32_t n_frames, int32_t T, int32_t J, 
       perm.p[jr[i]] = jl[i];
     }
   HIP_TRY(launch_window_gather(seq, out, mask, perm, n_frames, T, J, C, flip ? 1 : 0, s));
+  return D3D_OK;
+}
+
+int d3d_window_gather_s2f(const float* seq, int32_t n_frames, int32_t T, int32_t J, int32_t C, int32_t flip, const int32_t* jl,
+                          const int32_t* jr, int32_t n_lr, int32_t first, int32_t count, float* out, void* stream) {
+  if (!seq || !out || n_frames < 1 || T < 1 || J < 1 || C < 1) return fail(D3D_EINVAL, "bad argument");
+  if (!(T & 1)) return fail(D3D_EINVAL, "seq2frame windows need an odd number of frames (pad = (T - 1) / 2 on each side)");
+  if (first < 0 || count < 1 || first + (int64_t)count > n_frames) return fail(D3D_EINVAL, "window range outside the sequence");
+  if (J > JointPerm::MAXJ) return fail(D3D_EUNSUP, "more than 64 joints");
+  JointPerm perm{};
+  for (int j = 0; j < J; ++j) perm.p[j] = j;
+  if (flip)
+    for (int i = 0; i < n_lr; ++i) {
+      if (!jl || !jr || jl[i] < 0 || jl[i] >= J || jr[i] < 0 || jr[i] >= J) return fail(D3D_EINVAL, "joint index out of range");
+      perm.p[jl[i]] = jr[i];
+      perm.p[jr[i]] = jl[i];
+    }
+  HIP_TRY(launch_window_gather_s2f(seq, out, perm, n_frames, T, J, C, first, count, flip ? 1 : 0, reinterpret_cast<hipStream_t>(stream)));
   return D3D_OK;
 }
 

@@ -476,29 +476,64 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
       v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
     }
     ln_row<NV>(v, D, lane, a.g, a.b, a.eps);
-    float o[3] = {0.f, 0.f, 0.f};
+    // The three dot products of the row, as a function of the weight pointer so that they can be evaluated TWICE from independently
+    // loaded fragments (below).  One weight fragment loaded and consumed at a time, and the three sums kept out of packed (v_pk_*)
+    // register pairs by an opaque barrier after every update.  This is the instruction stream that never deviated on a GPU shared
+    // with a second process (0 of ~900 traced samplings); the compiler's free schedule -- three loads in flight behind counted waits,
+    // o[0] / o[1] in v_pk_fma_f32 pairs -- returned ONE wrong o[0] in about 1 launch of 60 there.  The mechanism below the
+    // instruction stream is not identified (experiments/NOTES.md); tests/test_abi_host.py checks the built kernel's ISA for these
+    // two properties in EVERY evaluation (the one-fragment-at-a-time waits at every width, the unpacked sums at the production
+    // width), and the default GPU suite repeats a two-process sampling (tests/test_gpu_round4.py) as the run-time cross-check.
+    typedef const float __attribute__((address_space(1))) * gfp;   // (a laundered pointer stays a GLOBAL pointer: global_load, not flat_load)
+    auto dot3 = [&](gfp Wh, float (&o)[3], float poke) {
+      o[0] = poke; o[1] = 0.f; o[2] = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = 4 * (lane + 64 * i);
-      if (c < D) {
-        // One weight fragment loaded and consumed at a time, and the three sums kept out of packed (v_pk_*) register pairs by an
-        // opaque barrier after every update.  This is the instruction stream that never deviated on a GPU shared with a second
-        // process (0 of ~900 traced samplings); the compiler's free schedule -- three loads in flight behind counted waits,
-        // o[0] / o[1] in v_pk_fma_f32 pairs -- returned ONE wrong o[0] in about 1 launch of 60 there.  The mechanism below the
-        // instruction stream is not identified (experiments/NOTES.md); tests/test_abi_host.py checks the built kernel's ISA
-        // for these two properties (the one-fragment-at-a-time waits at every width, the unpacked sums at the production width),
-        // and the default GPU suite repeats a two-process sampling (tests/test_gpu_round4.py) as the run-time cross-check.
+      for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < D) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float4 w = *reinterpret_cast<const float4*>(a.Wh + (size_t)k * D + c);
-          o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
-          asm volatile("" : "+v"(o[k]));
-          __builtin_amdgcn_sched_barrier(0);   // the next fragment's load stays behind this one's use (every NV)
+          for (int k = 0; k < 3; ++k) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v w = *reinterpret_cast<const f4v __attribute__((address_space(1)))*>(Wh + (size_t)k * D + c);
+            o[k] += (v[i].x * w.x + v[i].y * w.y) + (v[i].z * w.z + v[i].w * w.w);
+            asm volatile("" : "+v"(o[k]));
+            __builtin_amdgcn_sched_barrier(0);   // the next fragment's load stays behind this one's use (every NV)
+          }
         }
       }
-    }
+      // the three wave reductions one after the other, each sum's own adds only: the opaque statements tie the INPUT of the next
+      // reduction to the RESULT of the previous one, so the vectoriser cannot pair adds of different sums into v_pk_* here either
+      o[0] = wave_sum(o[0]);
+      asm volatile("" : "+v"(o[0]), "+v"(o[1]));
+      o[1] = wave_sum(o[1]);
+      asm volatile("" : "+v"(o[1]), "+v"(o[2]));
+      o[2] = wave_sum(o[2]);
+      asm volatile("" : "+v"(o[2]));
+    };
+    // RUN-TIME FENCE (round 5): the sums are formed twice -- the second time from fragments loaded again through a pointer the
+    // compiler cannot see through -- and compared bit for bit.  They have to agree: same instruction stream, same inputs.  If they
+    // do not (the signature of the two-process deviation, whatever its cause), a third evaluation decides by majority and the
+    // engine's D3D_RANGE_RECOMPUTE bit is raised, so that a toolchain or driver change that brings the deviation back is REPORTED
+    // by the default guard read instead of silently moving a pose.  Cost: the weight fragments come from L1 / L2 (6 KB), the row is
+    // already in registers -- measured +0.03 ms per launch of 0.21.  a.inject (tests only) perturbs the
+    // first evaluation of row 0.
+    float o[3], o2[3];
+    dot3((gfp)a.Wh, o, (a.inject && row == 0 && lane == 0) ? 1.0f : 0.0f);
+    gfp Wh2 = (gfp)a.Wh;
+    asm volatile("" : "+s"(Wh2));
+    dot3(Wh2, o2, 0.0f);
+    const bool same = ((__float_as_uint(o[0]) ^ __float_as_uint(o2[0])) | (__float_as_uint(o[1]) ^ __float_as_uint(o2[1])) |
+                       (__float_as_uint(o[2]) ^ __float_as_uint(o2[2]))) == 0u;
+    if (!same) {                                      // wave-uniform: wave_sum hands every lane the same value
+      float o3[3];
+      gfp Wh3 = (gfp)a.Wh;
+      asm volatile("" : "+s"(Wh3));
+      dot3(Wh3, o3, 0.0f);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) o[k] = wave_sum(o[k]);
+      for (int k = 0; k < 3; ++k)
+        o[k] = (__float_as_uint(o3[k]) == __float_as_uint(o2[k])) ? o2[k] : ((__float_as_uint(o3[k]) == __float_as_uint(o[k])) ? o[k] : o3[k]);
+      if (lane == 0) range_raise(a.range, RANGE_BIT_RECOMPUTE);
+    }
     if (lane < 3) so[lr * 3 + lane] = (lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]));
   }
   __syncthreads();
@@ -533,7 +568,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
   }
 }
 
-hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
+hipError_t launch_head(const HeadArgs& a_in, hipStream_t s) {
+  HeadArgs a = a_in;
+  a.range = launch_range_word();
   if (a.rows <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
   const int grid = (a.rows + HEAD_ROWS - 1) / HEAD_ROWS;
   if (a.D <= 256)
@@ -714,6 +751,35 @@ hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, con
   const long long total = (long long)nc * T * J;
   hipLaunchKernelGGL(k_window_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, seq, out, mask, perm, n, T, J, C,
                      nc, flip);
+  return hipGetLastError();
+}
+
+// Seq2frame windows (ChunkedGenerator / ChunkedGenerator_3dhp with out_all=False, chunk_length = stride = 1, GEN:402-420 pair table,
+// :492-512 slicing): window w belongs to target frame f = first + w and holds frames f - pad .. f + pad (T = 2 pad + 1), edge-replicated
+// at both ends of the sequence (np.pad(..., 'edge')).  Optionally the horizontally flipped copy.
+__global__ __launch_bounds__(256) void k_window_gather_s2f(const float* __restrict__ seq, float* __restrict__ out, JointPerm perm,
+                                                           int n, int T, int J, int C, int first, int count, int flip) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)count * T * J;
+  if (gid >= total) return;
+  const int j = (int)(gid % J);
+  const int t = (int)((gid / J) % T);
+  const int w = (int)(gid / ((long long)J * T));
+  int f = first + w - (T - 1) / 2 + t;
+  f = f < 0 ? 0 : (f > n - 1 ? n - 1 : f);
+  const int js = flip ? perm.p[j] : j;
+  const float* sp = seq + ((size_t)f * J + js) * C;
+  float* op = out + (size_t)gid * C;
+  for (int k = 0; k < C; ++k) op[k] = (flip && k == 0) ? -sp[k] : sp[k];
+}
+
+hipError_t launch_window_gather_s2f(const float* seq, float* out, const JointPerm& perm, int n, int T, int J, int C, int first, int count,
+                                    int flip, hipStream_t s) {
+  if (n < 1 || T < 1 || !(T & 1) || J < 1 || C < 1 || J > JointPerm::MAXJ || first < 0 || count < 1 || first + count > n)
+    return hipErrorInvalidValue;
+  const long long total = (long long)count * T * J;
+  hipLaunchKernelGGL(k_window_gather_s2f, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, seq, out, perm, n, T, J, C, first,
+                     count, flip);
   return hipGetLastError();
 }
 

@@ -191,3 +191,141 @@ def load_h36m(root_path: str, keypoints_name: str = "cpn_ft_h36m_dbb", subjects_
     ds = Human36mDataset(f"{root_path}/data_3d_h36m.npz")
     return load_eval_npz(ds, root_path, "h36m", keypoints_name, subjects_test.split(","), number_of_frames,
                          None if actions == "*" else actions.split(","), downsample)
+
+
+# ---------------------------------------------------------------------------------------------- MPI-INF-3DHP (BASELINE configs[4])
+MPI3DHP_SIDES = ([5, 6, 7, 11, 12, 13], [2, 3, 4, 8, 9, 10])      # kps / joints left, right (common/mpiinf3dhp_dataset.py:16-17)
+MPI3DHP_ROOT = 14                                                  # the joint the 3D poses are centred on (mpiinf3dhp_dataset.py:43,63)
+
+
+class EvalData3DHP:
+    """Test split of MPI-INF-3DHP as the reference's 3DHP runner evaluates it: what ``BaseMPIINF3DHPDataset(..., train=False)``
+    (common/mpiinf3dhp_dataset.py:56-83) + ``load_Dataset_3dhp(..., split='test')`` (data/load_noisy_data.py:293-441) +
+    ``ChunkedGenerator_3dhp`` (common/nosiy_generators.py:341-656) + DataLoader(shuffle=False) hand to its evaluate()
+    (run_..._3dhp.py:479-533), for both window tables:
+
+      out_all=True   sequence-to-sequence: non-overlapping T-frame windows, last one shifted, its overlap masked (GEN:356-389, 577-
+                     589), the mask ANDed with the frames' `valid` flags (GEN:627-628) -- the reference's shipped 3DHP command lines
+      out_all=False  sequence-to-frame (the ...S2F... models): stride 1, ONE window per target frame f holding the 2D frames f - pad ..
+                     f + pad, pad = (T - 1) // 2, edge-replicated; target = 3D frame f, shape (1, J, 3); mask = valid[f] (GEN:402-420,
+                     492-552; LOAD:312-316)
+
+    test_data    dict of data_test_3dhp.npz: [seq] -> {'data_3d' (n, 17, 3) mm, 'data_2d' (n, 17, 2) pixels, 'valid' (n,)}
+    train_data   dict of data_train_3dhp.npz ([seq][0][cam] -> {'data_3d', 'data_2d'}): only its 3D extremes enter -- the
+                 normalisation scale is max |root-centred coordinate| over BOTH files, every sequence (mpiinf3dhp_dataset.py:85-88,
+                 96-112; LOAD:306-313); pass pos_3d_extremes=(min, max) instead when they are known.
+    The caller's arrays are not modified (the reference centres and normalises them in place).
+    A sequence shorter than T (none exists in the data set) is edge-padded with its `valid` flags padded alike; the reference's
+    seq2seq generator fails on it (GEN:608-617 leaves the mask unset)."""
+
+    def __init__(self, test_data: Dict, subjects_test: Sequence[str], number_of_frames: int, out_all: bool = False, stride: Optional[int] = None,
+                 train_data: Optional[Dict] = None, pos_3d_extremes=None):
+        self.T = int(number_of_frames)
+        self.out_all = bool(out_all)
+        self.stride = int(stride) if stride is not None else (self.T if out_all else 1)
+        if self.out_all and self.stride != self.T:
+            raise ValueError("out_all=True: the window (stride) must equal number_of_frames (LOAD:312-314: pad = 0)")
+        if not self.out_all and self.stride != 1:
+            raise NotImplementedError("seq2frame evaluation uses stride 1 (one target frame per window: the S2F model returns (B, 1, J, 3))")
+        if not self.out_all and not (self.T & 1):
+            raise ValueError("seq2frame needs an odd number_of_frames")
+        self.pad = 0 if self.out_all else (self.T - 1) // 2
+        self.kps_left, self.kps_right = list(MPI3DHP_SIDES[0]), list(MPI3DHP_SIDES[1])
+        self.joints_left, self.joints_right = list(MPI3DHP_SIDES[0]), list(MPI3DHP_SIDES[1])
+        lo, hi = np.inf, -np.inf
+        self.sequences: List = []       # (seq, poses_2d (n, 17, 2) f32, poses_3d (n, 17, 3) f32, valid (n,) bool)
+        for seq, anim in test_data.items():
+            p3 = np.array(anim["data_3d"])
+            p3 = (p3 - p3[:, MPI3DHP_ROOT:MPI3DHP_ROOT + 1]).astype("float32")
+            lo, hi = min(lo, float(p3.min())), max(hi, float(p3.max()))
+            if seq not in subjects_test:
+                continue
+            w, h = (1920, 1080) if seq in ("TS5", "TS6") else (2048, 2048)          # mpiinf3dhp_dataset.py:72-77
+            p2 = np.array(anim["data_2d"])
+            p2[..., :2] = normalize_screen_coordinates(p2[..., :2], w=w, h=h)
+            self.sequences.append((seq, p2.astype("float32"), p3, np.asarray(anim["valid"]).reshape(p3.shape[0], -1)[:, 0].astype(bool)))
+        if train_data is not None:
+            for seq in train_data.keys():
+                for cam in train_data[seq][0].keys():
+                    p3 = np.array(train_data[seq][0][cam]["data_3d"])
+                    p3 = (p3 - p3[:, MPI3DHP_ROOT:MPI3DHP_ROOT + 1]).astype("float32")
+                    lo, hi = min(lo, float(p3.min())), max(hi, float(p3.max()))
+        if pos_3d_extremes is not None:
+            lo, hi = float(pos_3d_extremes[0]), float(pos_3d_extremes[1])
+        self.scale = float(abs(hi) if abs(hi) >= abs(lo) else abs(lo))
+        self._by_name = {s[0]: s for s in self.sequences}
+
+    def sequence(self, name: str):
+        return self._by_name[name]
+
+    def _flip2d(self, w: np.ndarray) -> np.ndarray:
+        w = w.copy()
+        w[:, :, 0] *= -1
+        w[:, self.kps_left + self.kps_right] = w[:, self.kps_right + self.kps_left]
+        return w
+
+    def num_items(self, seq_filter: Optional[str] = None) -> int:
+        tot = 0
+        for name, p2, _, _ in self.sequences:
+            if seq_filter is None or name == seq_filter:
+                tot += (p2.shape[0] + self.stride - 1) // self.stride
+        return tot
+
+    def __len__(self) -> int:
+        return self.num_items()
+
+    def items(self, seq_filter: Optional[str] = None) -> Iterator[Dict[str, np.ndarray]]:
+        """One evaluation item at a time in the reference's `pairs` order (LOAD:388-441 __getitem__); seq_filter = the per-sequence data
+        sets run_evaluation() builds (run_..._3dhp.py:596-604)."""
+        T = self.T
+        for name, p2, p3, valid in self.sequences:
+            if seq_filter is not None and name != seq_filter:
+                continue
+            n = p2.shape[0]
+            if self.out_all:
+                nc = (n + T - 1) // T
+                for c in range(nc):
+                    start = c * T if c < nc - 1 else n - T
+                    idx = np.clip(np.arange(start, start + T), 0, n - 1)
+                    mask = np.full(T, True, dtype=bool)
+                    if n >= T and c == nc - 1:
+                        mask[: nc * T - n] = False
+                    mask &= valid[idx]
+                    w2 = p2[idx]
+                    gt = p3[idx].copy()
+                    yield {"key": name, "inputs_3d": gt, "inputs_3d_norm": gt / np.float32(self.scale), "inputs_2d": w2.copy(),
+                           "inputs_2d_flip": self._flip2d(w2), "target_mask": mask}
+            else:
+                for f in range(n):
+                    idx = np.clip(np.arange(f - self.pad, f + self.pad + 1), 0, n - 1)
+                    w2 = p2[idx]
+                    gt = p3[f:f + 1].copy()
+                    yield {"key": name, "inputs_3d": gt, "inputs_3d_norm": gt / np.float32(self.scale), "inputs_2d": w2.copy(),
+                           "inputs_2d_flip": self._flip2d(w2), "target_mask": valid[f:f + 1].copy()}
+
+    def batches(self, batch_size: int, seq_filter: Optional[str] = None) -> Iterator[Dict[str, torch.Tensor]]:
+        """DataLoader(shuffle=False, drop_last=False) batches (run_..._3dhp.py:601-603) as the dicts evaluate() takes."""
+        buf: List[Dict[str, np.ndarray]] = []
+
+        def flush():
+            return {k: torch.from_numpy(np.stack([b[k] for b in buf])) for k in ("inputs_2d", "inputs_2d_flip", "inputs_3d",
+                                                                                  "inputs_3d_norm", "target_mask")}
+        for it in self.items(seq_filter):
+            buf.append(it)
+            if len(buf) == batch_size:
+                yield flush()
+                buf = []
+        if buf:
+            yield flush()
+
+
+def load_3dhp(root_path: str, subjects_test: str = "TS1,TS2,TS3,TS4,TS5,TS6", number_of_frames: int = 27, out_all: bool = False,
+              stride: Optional[int] = None, with_train_extremes: bool = True) -> EvalData3DHP:
+    """EvalData3DHP from `root_path/data_test_3dhp.npz` (+ `data_train_3dhp.npz` for the normalisation scale, as
+    MPIINF3DHPDataset does: mpiinf3dhp_dataset.py:96-105)."""
+    import os
+    test = np.load(os.path.join(root_path, "data_test_3dhp.npz"), allow_pickle=True)["data"].item()
+    train = None
+    if with_train_extremes:
+        train = np.load(os.path.join(root_path, "data_train_3dhp.npz"), allow_pickle=True)["data"].item()
+    return EvalData3DHP(test, subjects_test.split(","), number_of_frames, out_all=out_all, stride=stride, train_data=train)

@@ -184,7 +184,9 @@ class Engine:
         what = [n for b, n in ((_lib.RANGE_ACT, "an activation (|x| > 8188)"),
                                (_lib.RANGE_WEIGHT, "a non-finite (or beyond ~1e9: unrepresentable) GEMM weight"),
                                (_lib.RANGE_STATS, "a LayerNorm input row with |mean| > 16 standard deviations (one-pass statistics)"),
-                               (_lib.RANGE_INDEX, "a timestep index outside [0, num_timesteps)")) if f & b]
+                               (_lib.RANGE_INDEX, "a timestep index outside [0, num_timesteps)"),
+                               (_lib.RANGE_RECOMPUTE, "the head kernel's two evaluations of a row disagreeing (repaired by a third; "
+                                                      "a machine / toolchain fault indicator, experiments/NOTES.md section 1.4)")) if f & b]
         return " and ".join(what) if what else "nothing"
 
     def check_range(self) -> None:
@@ -465,3 +467,23 @@ def window_gather(seq: torch.Tensor, T: int, flip: bool = False, joints_left=(),
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(_lib.lib().d3d_window_gather(_ptr(sq), n, T, J, Cc, int(flip), jl, jr, len(joints_left), _ptr(out), _ptr(mask), st))
     return (out, mask.bool()) if want_mask else out
+
+
+def window_gather_s2f(seq: torch.Tensor, T: int, flip: bool = False, joints_left=(), joints_right=(), first: int = 0,
+                      count: Optional[int] = None) -> torch.Tensor:
+    """(n, J, C) device tensor -> (count, T, J, C) seq2frame windows: one per target frame first .. first + count - 1, frames
+    f - (T-1)/2 .. f + (T-1)/2 edge-replicated (GEN:402-420, 492-512 with out_all=False, stride 1)."""
+    dev = seq.device
+    n, J, Cc = seq.shape
+    count = n - first if count is None else count
+    sq = _f32c(seq, dev)
+    out = torch.empty((count, T, J, Cc), dtype=torch.float32, device=dev)
+    if count == 0:
+        return out
+    jl = (C.c_int32 * len(joints_left))(*joints_left)
+    jr = (C.c_int32 * len(joints_right))(*joints_right)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().d3d_window_gather_s2f(_ptr(sq), n, T, J, Cc, int(flip), jl, jr, len(joints_left), int(first), int(count),
+                                                    _ptr(out), st))
+    return out

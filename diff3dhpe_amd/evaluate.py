@@ -1,4 +1,5 @@
-"""evaluate()-equivalent harness (reference RUN:535-654) on top of the engine, for synthetic or user-supplied loaders.
+"""evaluate()-equivalent harness (reference RUN:535-654; the 3DHP runner's run_..._3dhp.py:479-579) on top of the engine, for
+synthetic or user-supplied loaders -- sequence-to-sequence and sequence-to-frame (...S2F...: (B, 1, J, 3) targets) models alike.
 
 Per batch it reproduces the reference's data flow: two full DDIM samplings (normal + horizontally flipped 2D input,
 RUN:577-582), un-flip/average/de-normalise/mask (RUN:583-590) and the frame-weighted MPJPE running mean
@@ -15,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import parallel
-from .engine import tta_mpjpe, window_gather
+from .engine import tta_mpjpe, window_gather, window_gather_s2f
 
 H36M_JOINTS_LEFT = [4, 5, 6, 11, 12, 13]     # after remove_joints (reference common/h36m_dataset.py:20-21,288)
 H36M_JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]
@@ -32,9 +33,14 @@ def flip_2d(x2d: torch.Tensor, joints_left: Sequence[int], joints_right: Sequenc
 @torch.no_grad()
 def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, scale: float = 1.0,
              joints_left: Sequence[int] = H36M_JOINTS_LEFT, joints_right: Sequence[int] = H36M_JOINTS_RIGHT,
-             test_time_augmentation: bool = True, device: Optional[torch.device] = None, verbose: bool = True):
-    """batches yield dicts with inputs_2d (B,T,J,2), inputs_3d (B,T,J,3) [ground truth, metres], optional
-    inputs_2d_flip, target_mask (B,T) bool, init_noise / init_noise_flip.  Returns a dict with MPJPE (mm), frames, seconds."""
+             test_time_augmentation: bool = True, device: Optional[torch.device] = None, verbose: bool = True,
+             output_loss: bool = False, unit_scale: float = 1000.0):
+    """batches yield dicts with inputs_2d (B,T,J,2), inputs_3d (B,T',J,3) [ground truth in the data set's unit; T' = T, or 1 for a
+    seq2frame model], optional inputs_2d_flip, target_mask (B,T') bool, init_noise / init_noise_flip (B,T',J,3), inputs_3d_norm.
+    output_loss=True is the 3DHP runner's call shape (run_..._3dhp.py:517-520 leaves forward()'s default): every sampling is preceded
+    by the forward-only p_losses on the normalised ground truth (its flipped copy for the flipped input, :497-500) -- the value is
+    discarded there and here; it matters for the generator draws it consumes.  unit_scale multiplies the reported error (1000: H36M
+    ground truth in metres -> mm; 1: 3DHP ground truth already in mm).  Returns a dict with MPJPE, frames, seconds."""
     model_diffusion.eval()
     dev = device or torch.device("cuda", torch.cuda.current_device())
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -56,14 +62,21 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
 
         def run_batch():
             pred_f = None
+            clean = gt[sl].to(dev)
+            clean_f = clean
+            if output_loss and hi > lo:     # p_losses reads the values: the normalised ground truth, and its mirror image for the flipped input
+                clean = (batch["inputs_3d_norm"][sl].to(dev) if batch.get("inputs_3d_norm") is not None else clean / scale)
+                clean_f = clean.clone()
+                clean_f[..., 0] *= -1
+                clean_f[:, :, list(joints_left) + list(joints_right)] = clean_f[:, :, list(joints_right) + list(joints_left)]
             if hi == lo:        # fewer windows than ranks: nothing to sample on this rank (forward() cannot take an empty batch)
                 pred = torch.empty(tuple(shape), dtype=torch.float32, device=dev)
                 pred_f = pred.clone() if test_time_augmentation else None
             else:
-                _, pred = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d[sl].to(dev), output_loss=False,
+                _, pred = model_diffusion(clean_3d_pose=clean, noisy_2d_pose=x2d[sl].to(dev), output_loss=output_loss,
                                           init_noise=None if batch.get("init_noise") is None else batch["init_noise"][sl])
             if test_time_augmentation and hi > lo:
-                _, pred_f = model_diffusion(clean_3d_pose=gt[sl].to(dev), noisy_2d_pose=x2d_f[sl].to(dev), output_loss=False,
+                _, pred_f = model_diffusion(clean_3d_pose=clean_f, noisy_2d_pose=x2d_f[sl].to(dev), output_loss=output_loss,
                                             init_noise=None if batch.get("init_noise_flip") is None else batch["init_noise_flip"][sl])
             gsl = sl
             if world > 1:   # the ONE exchange step: all-gather the predicted sequences; every rank then reduces the full batch (the
@@ -94,7 +107,7 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
         tot_err += err
         tot_cnt += cnt
         frames += cnt // shape[2]
-    e1 = tot_err / max(tot_cnt, 1) * 1000.0
+    e1 = tot_err / max(tot_cnt, 1) * unit_scale
     if verbose and rank == 0:
         print('eval_frame:', frames)
         print('inference_time:', secs / 60, 'min')
@@ -108,18 +121,35 @@ def evaluate_sequence(model_diffusion, poses_2d: torch.Tensor, poses_3d: torch.T
                       joints_left: Sequence[int] = H36M_JOINTS_LEFT, joints_right: Sequence[int] = H36M_JOINTS_RIGHT,
                       kps_left: Optional[Sequence[int]] = None, kps_right: Optional[Sequence[int]] = None,
                       test_time_augmentation: bool = True, batch_size: int = 512, device: Optional[torch.device] = None,
-                      init_noise=None, init_noise_flip=None):
+                      init_noise=None, init_noise_flip=None, valid: Optional[torch.Tensor] = None, seq2frame: Optional[bool] = None,
+                      output_loss: bool = False, unit_scale: float = 1000.0):
     """A whole video 2D-in -> MPJPE-out without host round trips: the window table, edge
-    padding, target mask and the flipped 2D copy (GEN:27-48, 247-276; LOAD:243-261) are built on the device, every
-    window goes through the DDIM loop (twice with TTA), and merge + masked MPJPE run in one kernel (RUN:583-606).
-    poses_2d (n, J, 2) normalised screen coordinates, poses_3d (n, J, 3) ground truth divided by `scale` upstream or
-    in metres with scale = 1."""
+    padding, target mask and the flipped 2D copy are built on the device, every window goes through the DDIM loop (twice with TTA),
+    and merge + masked MPJPE run in one kernel (RUN:583-606).  Two window tables:
+      seq2seq   (GEN:27-48, 247-276; LOAD:243-261) non-overlapping T-frame windows, the last one shifted and its overlap masked
+      seq2frame (GEN:402-420, 492-552; LOAD:312-316; chosen by the model's class, or seq2frame=True) ONE window per frame f -- the 2D
+                frames f - pad .. f + pad, edge-replicated -- with the single 3D frame f as target: (n, 1, J, 3)
+    poses_2d (n, J, 2) normalised screen coordinates, poses_3d (n, J, 3) ground truth divided by `scale` upstream or in the data
+    set's unit with scale = its normalisation scale; valid (n,) optional per-frame flags ANDed into the mask (3DHP, GEN:627-628)."""
     dev = device or torch.device("cuda", torch.cuda.current_device())
     kl = list(kps_left if kps_left is not None else joints_left)
     kr = list(kps_right if kps_right is not None else joints_right)
-    x2d, mask = window_gather(poses_2d.to(dev), num_frames)
-    gt = window_gather(poses_3d.to(dev), num_frames, want_mask=False)
-    x2d_f = window_gather(poses_2d.to(dev), num_frames, True, kl, kr, want_mask=False) if test_time_augmentation else None
+    if seq2frame is None:
+        seq2frame = bool(getattr(getattr(model_diffusion, "module", model_diffusion), "seq2frame", False))
+    p2, p3 = poses_2d.to(dev), poses_3d.to(dev)
+    n = p2.shape[0]
+    if seq2frame:
+        x2d = window_gather_s2f(p2, num_frames)
+        x2d_f = window_gather_s2f(p2, num_frames, True, kl, kr) if test_time_augmentation else None
+        gt = p3.to(torch.float32).reshape(n, 1, p3.shape[1], 3)
+        mask = torch.ones((n, 1), dtype=torch.bool, device=dev) if valid is None else valid.to(dev).reshape(n, 1).bool()
+    else:
+        x2d, mask = window_gather(p2, num_frames)
+        gt = window_gather(p3, num_frames, want_mask=False)
+        x2d_f = window_gather(p2, num_frames, True, kl, kr, want_mask=False) if test_time_augmentation else None
+        if valid is not None:     # the frames' own flags, through the same window table (edge-clamped like the poses)
+            vw = window_gather(valid.to(dev).to(torch.float32).reshape(n, 1, 1), num_frames, want_mask=False)
+            mask = mask & (vw.reshape(mask.shape) != 0)
     batches = []
     for lo in range(0, x2d.shape[0], batch_size):
         sl = slice(lo, lo + batch_size)
@@ -132,4 +162,5 @@ def evaluate_sequence(model_diffusion, poses_2d: torch.Tensor, poses_3d: torch.T
             b["init_noise_flip"] = init_noise_flip[sl]
         batches.append(b)
     return evaluate(model_diffusion, batches, scale=scale, joints_left=joints_left, joints_right=joints_right,
-                    test_time_augmentation=test_time_augmentation, device=dev, verbose=False)
+                    test_time_augmentation=test_time_augmentation, device=dev, verbose=False, output_loss=output_loss,
+                    unit_scale=unit_scale)

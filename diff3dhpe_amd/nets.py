@@ -180,9 +180,17 @@ class _MixSTEDenoiser(nn.Module):
     def _on_fallback(self) -> bool:
         return self.precision == "auto" and self._guard["fallback"] is not None and self._guard["fallback"] == self._weights_sig()
 
-    def _flagged(self, flags: int, what: str) -> None:
-        """A range flag was read for a call of this model: "auto" moves the model to the fp32 engine (the caller repeats the call);
-        every other precision raises."""
+    def _flagged(self, flags: int, what: str) -> bool:
+        """A range flag was read for a call of this model: "auto" moves the model to the fp32 engine (True: the caller repeats the
+        call); every other precision raises.  False: nothing to repeat (only the head kernel's self-repaired recompute bit)."""
+        if flags & _lib.RANGE_RECOMPUTE:        # repaired inside the kernel: a fault indicator, not a precision matter -- say so, once
+            self._guard["recomputes"] = self._guard.get("recomputes", 0) + 1
+            if not self._guard.get("warned_recompute"):
+                self._guard["warned_recompute"] = True
+                warnings.warn(f"diff3dhpe_amd: {what}: " + Engine.describe_range_flags(_lib.RANGE_RECOMPUTE), RuntimeWarning, stacklevel=4)
+            flags &= ~_lib.RANGE_RECOMPUTE
+            if not flags:
+                return False
         self._guard["flagged"] += 1
         msg = Engine.describe_range_flags(flags)
         if self.precision != "auto":
@@ -194,6 +202,7 @@ class _MixSTEDenoiser(nn.Module):
             warnings.warn(f"diff3dhpe_amd: {what}: the F16X3 range guard fired ({msg}); precision='auto' repeats the call on the "
                           "exact-fp32 engine and keeps this model there until its weights change (reset_precision_fallback() to retry)",
                           RuntimeWarning, stacklevel=4)
+        return True
 
     def _guarded(self, get_engine, fn, what: str):
         """Run fn(engine) on the model's engine and READ the F16X3 range guard for it (no device-wide synchronisation: one one-lane
@@ -203,7 +212,7 @@ class _MixSTEDenoiser(nn.Module):
             return fn(get_engine(True))
         eng = get_engine(False)
         res = fn(eng)
-        if not self.range_check or eng.precision != "f16x3":
+        if not self.range_check:
             return res
         ticket = eng.post_range()
         self._guard["posted"] += 1
@@ -214,7 +223,8 @@ class _MixSTEDenoiser(nn.Module):
         flags = eng.take_range(ticket, block=True)
         if not flags:
             return res
-        self._flagged(flags, what)              # raises unless "auto"
+        if not self._flagged(flags, what):      # raises unless "auto"
+            return res
         self._guard["reruns"] += 1
         return fn(get_engine(True))
 
@@ -273,7 +283,8 @@ class _Deferred:
         self.items.clear()
         if not flags:
             return False
-        self.net._flagged(flags, what)          # raises unless "auto"
+        if not self.net._flagged(flags, what):  # raises unless "auto"
+            return False
         self.net._guard["reruns"] += 1
         return True
 

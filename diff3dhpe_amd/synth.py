@@ -173,3 +173,42 @@ def write_synth_mocap(root: str, seed: int = 0, dataset: str = "h36m", keypoints
     np.savez(os.path.join(root, f"data_2d_{dataset}_{keypoints_name}.npz"), positions_2d=np.array(keypoints, dtype=object),
              metadata=np.array(meta, dtype=object))
     return positions, cameras, keypoints, meta
+
+
+def synth_mocap_3dhp(seed: int = 0):
+    """A tiny MPI-INF-3DHP-SHAPED data set (tests/golden/dataset_3dhp_eval.npz; tests of diff3dhpe_amd.data.EvalData3DHP), in the
+    layout of the data_{train,test}_3dhp.npz files the reference's 3DHP runner reads (common/mpiinf3dhp_dataset.py:21-88):
+      test  = {seq: {'data_3d' (n, 17, 3) float64 mm, 'data_2d' (n, 17, 2) float64 pixels, 'valid' (n,) float64 0/1}}
+      train = {'S1 Seq1': [{cam: {'data_3d', 'data_2d'}}]}
+    TS5 exercises the 1920 x 1080 branch of the screen normalisation; sequence lengths give ragged last windows, an exact
+    multiple of the window and invalid frames at both ends and inside."""
+    rng = np.random.RandomState(2000 + seed)
+    test = {}
+    for seq, n in (("TS1", 70), ("TS5", 54), ("TS3", 31)):
+        root = np.cumsum(rng.normal(0.0, 20.0, (n, 1, 3)), axis=0) + rng.uniform(-1000.0, 1000.0, (1, 1, 3)) + np.array([0.0, 0.0, 4000.0])
+        body = rng.uniform(-800.0, 800.0, (1, 17, 3)) + np.cumsum(rng.normal(0.0, 8.0, (n, 17, 3)), axis=0)
+        wh = (1920.0, 1080.0) if seq == "TS5" else (2048.0, 2048.0)
+        px = rng.uniform(0.2, 0.8, (1, 17, 2)) * np.array(wh) + np.cumsum(rng.normal(0.0, 3.0, (n, 17, 2)), axis=0)
+        valid = (rng.uniform(0.0, 1.0, n) > 0.25).astype(np.float64)
+        valid[0], valid[-1] = 0.0, 1.0
+        test[seq] = {"data_3d": root + body, "data_2d": px, "valid": valid}
+    train = {}
+    for seq, n in (("S1 Seq1", 40), ("S2 Seq2", 25)):
+        cams = {}
+        for cam in ("0", "2"):
+            root = np.cumsum(rng.normal(0.0, 20.0, (n, 1, 3)), axis=0) + np.array([0.0, 0.0, 4500.0])
+            body = rng.uniform(-900.0, 900.0, (1, 17, 3)) + np.cumsum(rng.normal(0.0, 8.0, (n, 17, 3)), axis=0)
+            cams[cam] = {"data_3d": root + body, "data_2d": rng.uniform(0.0, 2048.0, (n, 17, 2))}
+        train[seq] = [cams]
+    return test, train
+
+
+def write_synth_3dhp(root: str, seed: int = 0):
+    """Write data_test_3dhp.npz / data_train_3dhp.npz as the reference's MPIINF3DHPDataset reads them ('data' = one pickled dict)."""
+    import copy
+    import os
+    test, train = synth_mocap_3dhp(seed)
+    os.makedirs(root, exist_ok=True)
+    np.savez(os.path.join(root, "data_test_3dhp.npz"), data=np.array(copy.deepcopy(test), dtype=object))
+    np.savez(os.path.join(root, "data_train_3dhp.npz"), data=np.array(copy.deepcopy(train), dtype=object))
+    return test, train

@@ -143,6 +143,8 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *                     with the token GEMM's own epilogue function, from two rounds of 256 x 256 tiles on -- / as a form of the token GEMM.
  *                     Bit-identical.
  *   "proj_kernel"     1 (default) / 0: the same for proj (192 x 256 tiles; rows behind the last whole tile through the token GEMM).
+ *   "head_inject"     0 (default) / 1, tests only: the head kernel perturbs the first of its two evaluations of row 0 -- the fence must
+ *                     repair the row (result unchanged) and raise D3D_RANGE_RECOMPUTE
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
@@ -201,6 +203,16 @@ int d3d_window_gather(const float* seq_dev, int32_t n_frames, int32_t T, int32_t
                       const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr, float* out_dev,
                       uint8_t* mask_dev, void* stream);
 
+/* The seq2frame window table (BASELINE configs[4]: ...S2F... models): ChunkedGenerator / ChunkedGenerator_3dhp with out_all=False and
+ * chunk_length = stride = 1 (common/nosiy_generators.py:402-420 pair table, :492-512 slicing; data/load_noisy_data.py:312-316
+ * pad = (T - 1) // 2): ONE window per target frame f, holding frames f - pad .. f + pad, edge-replicated at both ends of the sequence.
+ * Writes the windows of target frames first .. first + count - 1: out (count, T, J, C).  The window's 3D target is frame f of the
+ * 3D sequence itself and its mask the frame's `valid` flag: neither needs a kernel.  T must be odd; flip as in d3d_window_gather.
+ * Asynchronous on `stream`. */
+int d3d_window_gather_s2f(const float* seq_dev, int32_t n_frames, int32_t T, int32_t J, int32_t C, int32_t flip,
+                          const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr, int32_t first, int32_t count,
+                          float* out_dev, void* stream);
+
 /* ---- per-kernel-class timing (HIP events recorded on the launch stream around every kernel of d3d_denoise /
  * d3d_ddim_sample while enabled; used by bench.py for the roofline figures).  flops / bytes are the ALGORITHMIC counts
  * of the launches timed, total_ms the sum of their event-pair durations. ------------------------ */
@@ -254,6 +266,13 @@ const char* d3d_kernel_class_name(int32_t kernel_class);
 /* not a precision matter, raised in every mode: a timestep handed to d3d_q_sample / d3d_weighted_loss was outside [0, num_timesteps)
  * (the reference raises IndexError on table[t], DIFF:21-24, 411): the row's output is NaN, no table entry was read */
 #define D3D_RANGE_INDEX 8u
+/* not a precision matter either, raised in every mode: the head kernel (S2S:217-220 + the DDIM update) forms the three dot products of
+ * every row TWICE, from independently loaded weight fragments, and the two evaluations disagreed bit for bit.  They cannot on a healthy
+ * machine; this is the signature of the one run-to-run deviation ever seen in this library (one wrong o[0] in ~1 launch of 60, only
+ * beside a second process on the GPU, only with an instruction schedule that is pinned out by an ISA test -- mechanism unidentified,
+ * experiments/NOTES.md).  The kernel repairs the row by a third evaluation (majority) and raises this bit so that a toolchain or
+ * driver change that brings the deviation back is reported by the default guard read instead of silently moving a pose. */
+#define D3D_RANGE_RECOMPUTE 16u
 int d3d_engine_range_flags(d3d_engine* e, uint32_t* flags, int32_t clear, void* stream);
 
 /* The guard WITHOUT a blocking synchronisation (ABI version 130) -- what the Python layer does by default after every compute call

@@ -343,3 +343,51 @@ def gather_windows(seq: Tensor, T: int, flip: bool = False, left=None, right=Non
         w[..., 0] *= -1
         w[:, :, list(left) + list(right)] = w[:, :, list(right) + list(left)]
     return w, torch.from_numpy(mask)
+
+
+# --------------------------------------------------------------------------- seq2frame windows (GEN:402-420, 492-552; LOAD:312-316)
+
+def chunk_index_s2f(n_frames: int, stride: int = 1):
+    """Pair table of ChunkedGenerator_3dhp(out_all=False) for one sequence (GEN:402-420): n_chunks = ceil(n / stride) chunks of
+    `stride` target frames, centred by offset = (n_chunks * stride - n) // 2; returns the (start_3d, end_3d) bounds."""
+    import numpy as np
+    n_chunks = (n_frames + stride - 1) // stride
+    offset = (n_chunks * stride - n_frames) // 2
+    bounds = np.arange(n_chunks + 1) * stride - offset
+    return bounds[:-1], bounds[1:]
+
+
+def gather_windows_s2f(seq2d: Tensor, seq3d: Tensor, valid, T: int, flip: bool = False, left=None, right=None, stride: int = 1):
+    """Seq2frame evaluation items of one sequence (get_batch_seq2frame, GEN:492-552, test split): per chunk the 2D frames
+    [start - pad, end + pad) with pad = (T - 1) // 2, edge-padded (np.pad 'edge'); the 3D target frames [start, end) (edge-padded
+    when the centred chunk table reaches beyond the sequence); target_mask = valid[start:end] as bool (None without `valid`).
+    -> (windows_2d (nc, stride + 2 pad, J, C), targets_3d (nc, stride, J, 3), mask (nc, stride) bool | None)."""
+    import numpy as np
+    n = seq2d.shape[0]
+    pad = (T - 1) // 2
+    s3, e3 = chunk_index_s2f(n, stride)
+    idx2 = np.clip((s3 - pad)[:, None] + np.arange(stride + 2 * pad)[None, :], 0, n - 1)
+    idx3 = np.clip(s3[:, None] + np.arange(stride)[None, :], 0, n - 1)
+    w = seq2d[torch.from_numpy(idx2)].clone()
+    g = seq3d[torch.from_numpy(idx3)].clone()
+    if flip:
+        w[..., 0] *= -1
+        w[:, :, list(left) + list(right)] = w[:, :, list(right) + list(left)]
+    m = None
+    if valid is not None:
+        m = torch.from_numpy(np.asarray(valid).reshape(n, -1)[:, 0][idx3].astype(bool))
+    return w, g, m
+
+
+def evaluate_batch(sd, tables, x2d: Tensor, x2d_flip: Tensor, gt: Tensor, target_mask: Tensor, noise: Tensor, noise_flip: Tensor, *,
+                   scale: float, depth: int, sampling_timesteps: int, num_timesteps: int = 1000, seq2frame: bool = False,
+                   joints_left=H36M_JOINTS_LEFT, joints_right=H36M_JOINTS_RIGHT):
+    """One batch of the reference's evaluate() (RUN:575-606 / RUN3DHP:510-533): two samplings (normal + flipped 2D input), un-flip /
+    average / de-normalise / mask, MPJPE.  -> (mpjpe over the valid frames, number of valid frames)."""
+    kw = dict(num_timesteps=num_timesteps, sampling_timesteps=sampling_timesteps, depth=depth, seq2frame=seq2frame)
+    p = ddim_sample_loop(sd, tables, x2d, noise, **kw)
+    pf = ddim_sample_loop(sd, tables, x2d_flip, noise_flip, **kw)
+    merged = merge_flip_tta(p, pf, scale, target_mask, joints_left, joints_right)
+    J = gt.shape[2]
+    g = gt.reshape(-1, J, 3)[target_mask.reshape(-1) == True, :, :].unsqueeze(1)  # noqa: E712
+    return mpjpe(merged, g), g.shape[0]

@@ -519,10 +519,125 @@ def gen_round4():
     save("ddim_s2f_notemb_T27_S7", seed=np.int32(6), input_seed=np.int32(700), B=np.int32(3), S=np.int32(7), y0=y0.numpy())
 
 
+def gen_round5():
+    """BASELINE configs[4] (MPI-INF-3DHP, T=27, seq2frame) end to end, from the reference itself:
+      chunks_s2f        window tables of ChunkedGenerator_3dhp (out_all False, stride 1; out_all True with `valid` flags)
+      dataset_3dhp_eval MPIINF3DHPDataset + load_Dataset_3dhp(split='test') on the synthetic 3DHP-shaped files of diff3dhpe_amd.synth:
+                        every evaluation item in `pairs` order, both window tables; diff3dhpe_amd.data.EvalData3DHP must be bit-equal
+      evaluate_3dhp_s2f the data flow of the 3DHP runner's evaluate() (run_..._3dhp.py:510-533: output_loss=True default, flipped clean
+                        pose, un-flip / average / de-normalise / mask / mpjpe) on two DataLoader batches of that data set with the
+                        reference S2F model WITHOUT time embedding (Experiments.sh:15-17) -- per-batch MPJPE and frame counts"""
+    import tempfile
+    from types import SimpleNamespace
+    from common.nosiy_generators import ChunkedGenerator_3dhp
+    from common.mpiinf3dhp_dataset import MPIINF3DHPDataset
+    from data.load_noisy_data import load_Dataset_3dhp
+    from diff3dhpe_amd.synth import write_synth_3dhp
+    from diff3dhpe_amd.data import EvalData3DHP
+
+    # ---- window tables
+    out = {}
+    kl, kr = [5, 6, 7, 11, 12, 13], [2, 3, 4, 8, 9, 10]
+    for n, T in [(100, 27), (27, 27), (5, 27), (1, 9), (40, 9)]:
+        rng = np.random.RandomState(n * 977 + T)
+        p2 = rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32)
+        p3 = rng.uniform(-1, 1, (n, 17, 3)).astype(np.float32)
+        valid = (rng.uniform(0, 1, n) > 0.3).astype(np.float64)
+        gen = ChunkedGenerator_3dhp(1, None, {"TS1": p3}, {"TS1": p2}, 1, pad=(T - 1) // 2, kps_left=kl, kps_right=kr, joints_left=kl,
+                                    joints_right=kr, out_all=False, valid_frame={"TS1": valid}, split="test")
+        wins, flips, gts, masks = [], [], [], []
+        for (seq, s3, e3, fl, rv) in gen.pairs:
+            _, g3, w2, m, *_ = gen.get_batch_seq2frame(seq, int(s3), int(e3), False, False)
+            _, _, w2f, _, *_ = gen.get_batch_seq2frame(seq, int(s3), int(e3), True, False)
+            wins.append(w2); flips.append(w2f); gts.append(g3); masks.append(m)
+        w, g, m = orc.gather_windows_s2f(torch.from_numpy(p2), torch.from_numpy(p3), valid, T)
+        wf, _, _ = orc.gather_windows_s2f(torch.from_numpy(p2), torch.from_numpy(p3), valid, T, True, kl, kr)
+        assert np.array_equal(w.numpy(), np.stack(wins)) and np.array_equal(wf.numpy(), np.stack(flips)), (n, T)
+        assert np.array_equal(g.numpy(), np.stack(gts)) and np.array_equal(m.numpy(), np.stack(masks)), (n, T)
+        tag = f"s2f_n{n}_T{T}"
+        out[tag + "/mask"] = np.stack(masks)
+        out[tag + "/win_checksum"] = np.float64((np.stack(wins).astype(np.float64) * (np.arange(1, T * 34 + 1).reshape(T, 17, 2) % 97)).sum())
+        out[tag + "/flip_checksum"] = np.float64((np.stack(flips).astype(np.float64) * (np.arange(1, T * 34 + 1).reshape(T, 17, 2) % 89)).sum())
+        print(f"  chunks s2f n={n} T={T}: {len(gen.pairs)} windows, oracle == reference")
+    save("chunks_s2f", **out)
+
+    # ---- the data set through the reference's loaders
+    out, ev = {}, {}
+    with tempfile.TemporaryDirectory() as root:
+        test, train = write_synth_3dhp(root, seed=0)
+        for oa, T in ((False, 27), (True, 27), (False, 9)):
+            opt = SimpleNamespace(dataset="3dhp", keypoints="gt", subjects_train="S1,S2", subjects_test="TS1,TS5", actions="*", downsample=1,
+                                  subset=1, stride=(T if oa else 1), test_time_augmentation=True, number_of_frames=T, out_all=oa,
+                                  batch_size=4, data_augmentation=False)
+            ds = MPIINF3DHPDataset(opt, root_path=root)
+            ref = load_Dataset_3dhp(opt, ds._test, pos_3d_min=ds._pos_3d_min, pos_3d_max=ds._pos_3d_max, split="test")
+            items = [ref[i] for i in range(len(ref))]
+            g3 = np.stack([it[1] for it in items]); g3n = np.stack([it[2] for it in items]); x2 = np.stack([it[3] for it in items])
+            x2f = np.stack([it[4] for it in items]); tm = np.stack([it[5] for it in items])
+            ed = EvalData3DHP(test, ["TS1", "TS5"], T, out_all=oa, train_data=train)
+            mine = list(ed.items())
+            assert len(mine) == len(items) == len(ed), (len(mine), len(items))
+            for nm, refa, key in (("3d", g3, "inputs_3d"), ("3dn", g3n, "inputs_3d_norm"), ("2d", x2, "inputs_2d"), ("2df", x2f, "inputs_2d_flip"),
+                                  ("mask", tm, "target_mask")):
+                m = np.stack([it[key] for it in mine])
+                assert m.dtype == refa.dtype and m.shape == refa.shape and np.array_equal(m, refa), (oa, T, nm, m.dtype, refa.dtype, m.shape, refa.shape)
+            assert np.float32(ed.scale) == np.float32(ref.scale), (ed.scale, ref.scale)
+            tag = f"{'s2s' if oa else 's2f'}_T{T}"
+            if T == 27:
+                out[tag + "/inputs_3d"] = g3; out[tag + "/inputs_2d"] = x2
+            for nm, arr in (("inputs_3d", g3), ("inputs_3d_norm", g3n), ("inputs_2d", x2), ("inputs_2d_flip", x2f)):
+                wts = np.arange(1, arr.size + 1, dtype=np.float64).reshape(arr.shape) % 9973.0
+                out[f"{tag}/{nm}_checksum"] = np.float64((arr.astype(np.float64) * wts).sum())
+            out[tag + "/target_mask"] = tm; out[tag + "/scale"] = np.float32(ref.scale)
+            print(f"  3dhp {tag}: {len(items)} items, scale {float(ref.scale):.3f}: diff3dhpe_amd.data.EvalData3DHP == reference (bit-equal)")
+
+            if (oa, T) != (False, 27):
+                continue
+            # ---- evaluate(): the 3DHP runner's data flow on DataLoader batches of this data set, seq_filter='TS1' as run_evaluation() does
+            cfg = cfg_full(27, seq2frame=True, with_time_emb=False)
+            S = 3
+            net, diff, sd = build_ref(cfg, 11, sampling=S)
+            refq = load_Dataset_3dhp(opt, ds._test, pos_3d_min=ds._pos_3d_min, pos_3d_max=ds._pos_3d_max, split="test", seq_filter="TS1")
+            loader = torch.utils.data.DataLoader(refq, batch_size=32, shuffle=False, num_workers=0, drop_last=False)
+            jl, jr = ds.joints_left, ds.joints_right
+            tabs = orc.diffusion_tables("cosine", 1000)
+            errs, cnts = [], []
+            for bi, (_, inputs_3d, inputs_3d_norm, inputs_2d, inputs_2d_flip, target_mask, *_rest) in enumerate(loader):
+                B = inputs_2d.shape[0]
+                noise = torch.from_numpy(hash_uniform(f"eval3dhp/noise/{bi}", B * 17 * 3, 5).astype(np.float32).reshape(B, 1, 17, 3)) * 1.7
+                noise_f = torch.from_numpy(hash_uniform(f"eval3dhp/noise_flip/{bi}", B * 17 * 3, 5).astype(np.float32).reshape(B, 1, 17, 3)) * 1.7
+                tmask = target_mask.view(-1)
+                n3f = inputs_3d_norm.clone()
+                n3f[:, :, :, 0] *= -1
+                n3f[:, :, jl + jr] = n3f[:, :, jr + jl]
+                with torch.no_grad():
+                    with inject_noise(noise):
+                        _, pred = diff(clean_3d_pose=inputs_3d_norm, noisy_2d_pose=inputs_2d)              # output_loss=True: the default
+                    with inject_noise(noise_f):
+                        _, pred_f = diff(clean_3d_pose=n3f, noisy_2d_pose=inputs_2d_flip)
+                pred_f[:, :, :, 0] *= -1
+                pred_f[:, :, jl + jr] = pred_f[:, :, jr + jl]
+                p = (pred + pred_f) / 2.0
+                p = refq.reverse_norm_3d_pose(p)
+                p = p.view(-1, 17, 3)[tmask == True, :, :].unsqueeze(1)  # noqa: E712
+                g = inputs_3d.view(-1, 17, 3)[tmask == True, :, :].unsqueeze(1)  # noqa: E712
+                e = ref_mpjpe(p, g)
+                oe, on = orc.evaluate_batch(sd, tabs, inputs_2d, inputs_2d_flip, inputs_3d, target_mask, noise, noise_f, scale=float(refq.scale),
+                                            depth=8, sampling_timesteps=S, seq2frame=True, joints_left=jl, joints_right=jr)
+                assert on == g.shape[0]
+                check(f"3dhp evaluate batch {bi} mpjpe (mm)", oe, e, 2e-3)
+                errs.append(float(e)); cnts.append(int(g.shape[0]))
+            ev = dict(seed=np.int32(11), S=np.int32(S), batch_size=np.int32(32), mpjpe_per_batch=np.asarray(errs, np.float64),
+                      frames_per_batch=np.asarray(cnts, np.int32), scale=np.float32(refq.scale))
+            print(f"  3dhp evaluate(): {len(errs)} batches, {sum(cnts)} valid frames, MPJPE {np.dot(errs, cnts) / sum(cnts):.4f} mm")
+    save("dataset_3dhp_eval", **out)
+    save("evaluate_3dhp_s2f", **ev)
+
+
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
-    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4,
+    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5,
 }
 
 if __name__ == "__main__":

@@ -260,13 +260,16 @@ def test_head_kernel_instruction_stream_is_the_one_that_is_stable_on_a_shared_gp
                 ops.append("M")
             else:
                 ops.append(None)
-        # The last 16-byte loads of the kernel are weight fragments: all six of them at D = 512 (NV = 2, the production width, where
-        # the two-process experiments ran); at the other widths the compiler sinks some LayerNorm-vector loads between them,
-        # so only the last fragment's three are identified by position.
-        idx = [i for i, o in enumerate(ops) if o == "L"][-(6 if nv == 2 else 3):]
-        dpp = next((i for i in range(idx[-1], len(text)) if "_dpp" in text[i]), len(text))   # the wave reduction behind the dot product
+        # The kernel evaluates the dot products up to three times (round 5: run-time fence -- twice, and a third time on a mismatch); the
+        # last 16-byte loads of the kernel are their weight fragments: all 3 x 6 of them at D = 512 (NV = 2, the production width, where
+        # the two-process experiments ran); at the other widths the compiler sinks some LayerNorm-vector loads between the FIRST
+        # evaluation's fragments, so of that one only the last fragment's three are identified by position.
+        n_tail = 18 if nv == 2 else 6 * nv + 3
+        idx = [i for i, o in enumerate(ops) if o == "L"][-n_tail:]
+        assert len(idx) == n_tail, (nv, len(idx))
         for n, i in enumerate(idx):
-            end = idx[n + 1] if n + 1 < len(idx) else dpp
+            dpp = next((j for j in range(i, len(text)) if "_dpp" in text[j]), len(text))   # the wave reduction behind an evaluation
+            end = min(idx[n + 1], dpp) if n + 1 < len(idx) else dpp
             seg_ops = [o for o in ops[i + 1:end] if o]
             assert "W0" in seg_ops, (nv, seg_ops)                                        # (a) waited for before anything else loads
             assert not any(o == "L" for o in seg_ops)

@@ -60,3 +60,81 @@ def test_coordinate_helpers():
     X = np.arange(12, dtype=np.float32).reshape(2, 2, 3)
     t = np.array([1.0, 2.0, 3.0], dtype=np.float32)
     assert np.allclose(world_to_camera(X, q, t), X - t)
+
+
+# ---------------------------------------------------------------------------------------------- MPI-INF-3DHP (BASELINE configs[4])
+def _data3dhp(T, out_all, **kw):
+    from diff3dhpe_amd.data import EvalData3DHP
+    from diff3dhpe_amd.synth import synth_mocap_3dhp
+    test, train = synth_mocap_3dhp(0)
+    return EvalData3DHP(test, ["TS1", "TS5"], T, out_all=out_all, train_data=train, **kw), test, train
+
+
+def test_3dhp_items_equal_the_reference_loader_bit_for_bit():
+    """EvalData3DHP against what MPIINF3DHPDataset + load_Dataset_3dhp(split='test') + ChunkedGenerator_3dhp produced on the same
+    synthetic files (oracle/gen_golden.py::gen_round5), for the seq2frame table (stride 1, pad 13 / 4) and the seq2seq one."""
+    g = gold("dataset_3dhp_eval")
+    for tag, T, oa in (("s2f_T27", 27, False), ("s2s_T27", 27, True), ("s2f_T9", 9, False)):
+        ed, _, _ = _data3dhp(T, oa)
+        items = list(ed.items())
+        assert len(items) == len(ed) == g[f"{tag}/target_mask"].shape[0]
+        assert np.float32(ed.scale) == g[f"{tag}/scale"]
+        assert np.array_equal(np.stack([it["target_mask"] for it in items]), g[f"{tag}/target_mask"])
+        for nm in ("inputs_3d", "inputs_3d_norm", "inputs_2d", "inputs_2d_flip"):
+            arr = np.stack([it[nm] for it in items])
+            assert arr.dtype == np.float32
+            wts = np.arange(1, arr.size + 1, dtype=np.float64).reshape(arr.shape) % 9973.0
+            assert np.float64((arr.astype(np.float64) * wts).sum()) == g[f"{tag}/{nm}_checksum"], (tag, nm)
+            if f"{tag}/{nm}" in g:
+                assert np.array_equal(arr, g[f"{tag}/{nm}"]), (tag, nm)
+        exp = (1, 17, 3) if not oa else (T, 17, 3)
+        assert items[0]["inputs_3d"].shape == exp and items[0]["inputs_2d"].shape == (T, 17, 2)
+
+
+def test_3dhp_adaptor_details(tmp_path):
+    from diff3dhpe_amd.data import EvalData3DHP, load_3dhp
+    from diff3dhpe_amd.synth import write_synth_3dhp
+    ed, test, train = _data3dhp(27, False)
+    # per-sequence data sets (run_evaluation(): seq_filter) and DataLoader batches
+    assert ed.num_items("TS1") == 70 and ed.num_items("TS5") == 54 and len(ed) == 124
+    bs = list(ed.batches(32, seq_filter="TS1"))
+    assert [b["inputs_2d"].shape[0] for b in bs] == [32, 32, 6] and bs[0]["inputs_3d"].shape == (32, 1, 17, 3)
+    assert bs[0]["target_mask"].shape == (32, 1) and bs[0]["target_mask"].dtype == torch.bool and not bs[0]["target_mask"][0, 0]
+    # edge replication at both ends: window 0 repeats frame 0 thirteen times on the left, the last window the last frame on the right
+    first, last = next(ed.items("TS1")), list(ed.items("TS1"))[-1]
+    assert all(np.array_equal(first["inputs_2d"][i], first["inputs_2d"][13]) for i in range(13))
+    assert all(np.array_equal(last["inputs_2d"][i], last["inputs_2d"][13]) for i in range(14, 27))
+    # the caller's arrays stay untouched (the reference centres / normalises in place); 3D is centred on joint 14
+    assert test["TS1"]["data_3d"][:, 14].any() and not ed.sequence("TS1")[2][:, 14].any()
+    # without the training file the scale comes from the test sequences alone (every one of them, listed or not)
+    ed2 = EvalData3DHP(test, ["TS1"], 27)
+    assert ed2.scale <= ed.scale and len(ed2) == 70
+    assert EvalData3DHP(test, ["TS1"], 27, pos_3d_extremes=(-5.0, 3.0)).scale == 5.0
+    # the npz route
+    write_synth_3dhp(str(tmp_path), seed=0)
+    ed3 = load_3dhp(str(tmp_path), "TS1,TS5", 27)
+    assert ed3.scale == ed.scale and len(ed3) == len(ed)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        EvalData3DHP(test, ["TS1"], 27, out_all=False, stride=27)
+    with pytest.raises(ValueError):
+        EvalData3DHP(test, ["TS1"], 27, out_all=True, stride=9)
+
+
+def test_oracle_seq2frame_windows_against_the_reference_generator():
+    """oracle.gather_windows_s2f against the checksums / masks ChunkedGenerator_3dhp(out_all=False) produced (chunks_s2f.npz)."""
+    from oracle import d3d_oracle as orc
+    g = gold("chunks_s2f")
+    kl, kr = [5, 6, 7, 11, 12, 13], [2, 3, 4, 8, 9, 10]
+    for n, T in [(100, 27), (27, 27), (5, 27), (1, 9), (40, 9)]:
+        rng = np.random.RandomState(n * 977 + T)
+        p2 = rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32)
+        p3 = rng.uniform(-1, 1, (n, 17, 3)).astype(np.float32)
+        valid = (rng.uniform(0, 1, n) > 0.3).astype(np.float64)
+        w, gt, m = orc.gather_windows_s2f(torch.from_numpy(p2), torch.from_numpy(p3), valid, T)
+        wf, _, _ = orc.gather_windows_s2f(torch.from_numpy(p2), torch.from_numpy(p3), valid, T, True, kl, kr)
+        tag = f"s2f_n{n}_T{T}"
+        assert w.shape == (n, T, 17, 2) and gt.shape == (n, 1, 17, 3) and np.array_equal(gt[:, 0].numpy(), p3)
+        assert np.array_equal(m.numpy(), g[tag + "/mask"])
+        assert np.float64((w.numpy().astype(np.float64) * (np.arange(1, T * 34 + 1).reshape(T, 17, 2) % 97)).sum()) == g[tag + "/win_checksum"]
+        assert np.float64((wf.numpy().astype(np.float64) * (np.arange(1, T * 34 + 1).reshape(T, 17, 2) % 89)).sum()) == g[tag + "/flip_checksum"]

@@ -305,3 +305,136 @@ def test_bench_strong_scaling_mode_names_itself():
     assert line["scaling"] == "strong" and line["config"]["global_batch"] == 6 and "strong scaling" in line["config"]["workload"]
     weak = _bench(["--gpus", "1", "--batch", "6"] + SMALL, _env())
     assert weak["scaling"] == "weak" and weak["mpjpe_vs_synthetic_gt"] == line["mpjpe_vs_synthetic_gt"]
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: seq2frame evaluation
+@pytest.mark.parametrize("n,T", [(100, 27), (27, 27), (5, 27), (1, 9), (40, 9)])
+def test_seq2frame_window_gather_matches_the_oracle_bit_for_bit(n, T):
+    """d3d_window_gather_s2f (one window per target frame, pad = (T - 1) / 2, edge replication; GEN:402-420, 492-512) against the oracle's
+    restatement -- itself pinned on ChunkedGenerator_3dhp's output (chunks_s2f.npz, CPU suite) -- incl. the flipped copy and sub-ranges."""
+    from oracle import d3d_oracle as orc
+    from diff3dhpe_amd.engine import window_gather_s2f
+    kl, kr = [5, 6, 7, 11, 12, 13], [2, 3, 4, 8, 9, 10]
+    rng = np.random.RandomState(n * 977 + T)
+    p2 = torch.from_numpy(rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32))
+    p3 = torch.from_numpy(rng.uniform(-1, 1, (n, 17, 3)).astype(np.float32))
+    w, _, _ = orc.gather_windows_s2f(p2, p3, None, T)
+    wf, _, _ = orc.gather_windows_s2f(p2, p3, None, T, True, kl, kr)
+    assert torch.equal(window_gather_s2f(p2.cuda(), T).cpu(), w)
+    assert torch.equal(window_gather_s2f(p2.cuda(), T, True, kl, kr).cpu(), wf)
+    if n >= 5:
+        assert torch.equal(window_gather_s2f(p2.cuda(), T, first=2, count=3).cpu(), w[2:5])
+    L = _lib.lib()
+    out = torch.empty((n, T, 17, 2), device="cuda")
+    z = (C.c_int32 * 0)()
+    a = (C.c_void_p(p2.cuda().data_ptr()), n, T, 17, 2, 0, z, z, 0)
+    assert L.d3d_window_gather_s2f(*a, 0, n + 1, C.c_void_p(out.data_ptr()), None) == -1          # range outside the sequence
+    assert L.d3d_window_gather_s2f(C.c_void_p(p2.cuda().data_ptr()), n, T + 1, 17, 2, 0, z, z, 0, 0, n, C.c_void_p(out.data_ptr()), None) == -1
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "auto"])
+def test_evaluate_seq2frame_3dhp_call_shape_against_the_reference(prec):
+    """BASELINE configs[4] end to end: the 3DHP runner's evaluate() (run_..._3dhp.py:479-533) with an ...S2F... model WITHOUT time
+    embedding (Experiments.sh:15-17), output_loss=True (forward()'s default there), flip-TTA, (B, 1, J, 3) targets and the frames'
+    `valid` flags as mask -- on the DataLoader batches of sequence TS1 of the synthetic 3DHP-shaped data set, against the per-batch
+    MPJPE the REFERENCE itself produced on those batches (evaluate_3dhp_s2f.npz; oracle == reference there)."""
+    from conftest import gold
+    from diff3dhpe_amd.data import EvalData3DHP
+    from diff3dhpe_amd.synth import synth_mocap_3dhp, hash_uniform
+    g = gold("evaluate_3dhp_s2f")
+    cfg = cfg_full(27, seq2frame=True, with_time_emb=False)
+    S, bs = int(g["S"]), int(g["batch_size"])
+    _, net, diff = _model(cfg, int(g["seed"]), lambda sd: None, precision=prec, sampling=S)
+    test, train = synth_mocap_3dhp(0)
+    ed = EvalData3DHP(test, ["TS1", "TS5"], 27, out_all=False, train_data=train)
+    assert np.float32(ed.scale) == g["scale"]
+    batches = []
+    for bi, b in enumerate(ed.batches(bs, seq_filter="TS1")):
+        B = b["inputs_2d"].shape[0]
+        b["init_noise"] = torch.from_numpy(hash_uniform(f"eval3dhp/noise/{bi}", B * 17 * 3, 5).astype(np.float32).reshape(B, 1, 17, 3)) * 1.7
+        b["init_noise_flip"] = torch.from_numpy(hash_uniform(f"eval3dhp/noise_flip/{bi}", B * 17 * 3, 5).astype(np.float32).reshape(B, 1, 17, 3)) * 1.7
+        batches.append(b)
+    kw = dict(scale=ed.scale, joints_left=ed.joints_left, joints_right=ed.joints_right, output_loss=True, unit_scale=1.0, verbose=False)
+    worst = 0.0
+    for bi, b in enumerate(batches):
+        r = evaluate(diff, [b], **kw)
+        assert r["frames"] == int(g["frames_per_batch"][bi])
+        worst = max(worst, abs(r["mpjpe_mm"] - float(g["mpjpe_per_batch"][bi])))
+    whole = evaluate(diff, batches, **kw)
+    ref = float(np.dot(g["mpjpe_per_batch"], g["frames_per_batch"]) / g["frames_per_batch"].sum())
+    print(f"3DHP seq2frame evaluate() [{prec}]: MPJPE {whole['mpjpe_mm']:.4f} mm (reference {ref:.4f}), worst batch deviation {worst:.2e} mm "
+          f"at scale {ed.scale:.0f} mm")
+    assert whole["frames"] == int(g["frames_per_batch"].sum())
+    # 1e-4 on the normalised poses is 1e-4 * scale in mm; a mean of joint distances moves by no more than that
+    assert worst <= GATE * ed.scale and abs(whole["mpjpe_mm"] - ref) <= GATE * ed.scale
+    assert net._guard["flagged"] == 0
+
+
+def test_evaluate_sequence_seq2frame_equals_the_batched_route():
+    """evaluate_sequence() on a seq2frame model builds the per-frame windows, the flipped copy, the (n, 1, J, 3) targets and the
+    `valid` mask on the device: same MPJPE as evaluate() over the host adaptor's DataLoader batches, bit for bit; a seq2seq model on
+    the same 3DHP sequence takes the shifted-window table with `valid` ANDed in and agrees with ITS batched route."""
+    from diff3dhpe_amd.data import EvalData3DHP
+    from diff3dhpe_amd.evaluate import evaluate_sequence
+    from diff3dhpe_amd.synth import synth_mocap_3dhp, hash_uniform
+    test, train = synth_mocap_3dhp(0)
+    for s2f in (True, False):
+        cfg = cfg_full(27, seq2frame=s2f, with_time_emb=False)
+        _, net, diff = _model(cfg, 11, lambda sd: None, sampling=2)
+        ed = EvalData3DHP(test, ["TS1", "TS5"], 27, out_all=not s2f, train_data=train)
+        name, p2, p3, valid = ed.sequence("TS5")
+        items = ed.num_items("TS5")
+        To = 1 if s2f else 27
+        nz = torch.from_numpy(hash_uniform("evalseq/nz", items * To * 17 * 3, 3).astype(np.float32).reshape(items, To, 17, 3))
+        nzf = torch.from_numpy(hash_uniform("evalseq/nzf", items * To * 17 * 3, 3).astype(np.float32).reshape(items, To, 17, 3))
+        kw = dict(scale=ed.scale, joints_left=ed.joints_left, joints_right=ed.joints_right, unit_scale=1.0)
+        a = evaluate_sequence(diff, torch.from_numpy(p2), torch.from_numpy(p3), num_frames=27, batch_size=20, init_noise=nz.cuda(),
+                              init_noise_flip=nzf.cuda(), valid=torch.from_numpy(valid), **kw)
+        batches = []
+        for bi, b in enumerate(ed.batches(20, seq_filter="TS5")):
+            b["init_noise"], b["init_noise_flip"] = nz[20 * bi:20 * bi + 20], nzf[20 * bi:20 * bi + 20]
+            batches.append(b)
+        r = evaluate(diff, batches, verbose=False, **kw)
+        assert a["frames"] == r["frames"] > 0 and a["mpjpe_mm"] == r["mpjpe_mm"], (s2f, a, r)
+
+
+# ------------------------------------------------------------------------------------------------ the head kernel's run-time fence
+@pytest.mark.parametrize("prec", ["f16x3", "fp32", "auto"])
+def test_head_kernel_recompute_fence(prec):
+    """k_head forms every row's three dot products TWICE from independently loaded weight fragments and compares them bit for bit (the
+    one run-to-run deviation this library ever showed -- a wrong o[0] in ~1 launch of 60 beside a second process, with a schedule that is
+    pinned out at build time; mechanism unidentified -- would show exactly there).  "head_inject" perturbs the FIRST evaluation of row 0:
+    the kernel must repair the row by its third evaluation (results unchanged, whole sampling), raise D3D_RANGE_RECOMPUTE in EVERY
+    precision, and the Python layer must report it once without raising or changing engines."""
+    cfg = cfg_full(27)
+    cfgd = type(cfg)(num_frame=27, embed_dim=512, depth=2)
+    _, net, diff = _model(cfgd, 6, lambda sd: None, precision=prec, sampling=3)
+    inp = inputs(3, 27, 41)
+    z, x2d, nz = torch.zeros(3, 27, 17, 3).cuda(), inp["x2d"].cuda(), inp["noise"].cuda()
+    eng = diff._engine(_dev())
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, clean = diff(clean_3d_pose=z, noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+        assert eng.take_range(eng.post_range()) == 0
+        raw = eng.ddim_sample(x2d, nz)
+    eng.set_option("head_inject", 1)
+    try:
+        poked = eng.ddim_sample(x2d, nz)
+        assert eng.take_range(eng.post_range()) == _lib.RANGE_RECOMPUTE          # seen ...
+        assert torch.equal(poked, raw)                                            # ... and repaired
+        with pytest.warns(RuntimeWarning, match="two evaluations of a row disagreeing"):
+            _, again = diff(clean_3d_pose=z, noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+        assert torch.equal(again, clean)
+        g = net._guard
+        assert g.get("recomputes") == 1 and g["flagged"] == 0 and g["reruns"] == 0 and not net._on_fallback()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                                        # reported once per model
+            diff(clean_3d_pose=z, noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
+        assert g.get("recomputes") == 2
+    finally:
+        eng.set_option("head_inject", 0)
+    assert eng.take_range(eng.post_range()) == 0
+    # the single-op hook runs the same kernel (rows that are not a multiple of the 32-row workgroup included)
+    X = torch.randn(77, 512, device="cuda")
+    a = eng.head(X)
+    assert torch.isfinite(a).all()
