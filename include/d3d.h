@@ -39,7 +39,9 @@ extern "C" {
 #define D3D_PREC_FP32 0     /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 everywhere (parity mode) */
 #define D3D_PREC_F16X3 1    /* fp32-accurate GEMMs and attention from 3 fp16 MFMAs per product on hi/lo operand splits; the
                              * residual stream lives in the GEMM operand layout and norm1/norm2 are folded into the qkv/fc1
-                             * GEMMs.  Same 1e-4 parity gate as FP32; the default of the Python layer. */
+                             * GEMMs.  Same 1e-4 parity gate as FP32 INSIDE its operand range (range guard below); the engine the
+                             * Python layer's default precision "auto" starts on -- it reads the guard after every call and repeats a flagged
+                             * call on a D3D_PREC_FP32 engine. */
 #define D3D_PREC_BF16 2     /* SECOND-CLASS precision (BASELINE configs[1]): bf16 operands for the block GEMMs
                              * and both attention products (one MFMA per product), everything else fp32 (residual stream, LayerNorm /
                              * softmax statistics, GELU, time vectors, embedding, head, DDIM update).  It CANNOT meet the 1e-4 parity
@@ -168,7 +170,9 @@ int d3d_weighted_loss(d3d_engine* e, const float* model_out_dev, const float* ta
 
 /* repeat_n hypotheses of forward() (DIFF:433-448): d3d_repeat_batch writes out[r * B + b, :] = x[b, :] for r < repeat_n
  * (noisy_2d_pose.repeat(repeat_n, 1, 1, 1)); d3d_hypothesis_mean writes out[b, :] = (pred[b, :] + pred[B + b, :] + ...) / repeat_n
- * (torch.mean(pred.view(repeat_n, b, f, p, -1), dim=0)).  n = fp32 values per batch row. */
+ * (torch.mean(pred.view(repeat_n, b, f, p, -1), dim=0)) -- in the operation order of the reference's CPU path: the hypotheses added in
+ * order, ONE fp32 division by repeat_n.  (torch.mean on a GPU tensor multiplies the sum by a precomputed 1 / repeat_n instead: one ulp apart
+ * for repeat_n not a power of two; parity is defined against the CPU path.)  n = fp32 values per batch row. */
 int d3d_repeat_batch(const float* x_dev, float* out_dev, int32_t B, int64_t n, int32_t repeat_n, void* stream);
 int d3d_hypothesis_mean(const float* pred_dev, float* out_dev, int32_t B, int64_t n, int32_t repeat_n, void* stream);
 
