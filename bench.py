@@ -159,7 +159,13 @@ def cpu_baseline_concurrent(T, S, seed, best_th, avail, step_s_alone, run_s=8.0,
     the figure "the node's own host cores" can deliver for independent windows -- the single-process number above is the
     reference's own form (one Python process, RUN).  Children are fresh processes that never touch the GPU."""
     import subprocess
-    k = max(1, min(max_procs, avail // max(best_th, 1)))     # the affinity mask decides how many are STARTED; what the cgroup quota
+    eff = avail if not quota else max(1, min(avail, int(quota)))        # CPUs this container is PAID for (cgroup CFS quota), not just shown
+    k = max(1, min(max_procs, eff // max(best_th, 1)))
+    if k == 1:     # the quota (or the mask) holds one such process: the concurrent figure IS the single-process one -- nothing to run
+        return {"value": None, "processes": 1, "threads_per_process": best_th, "cgroup_cpu_quota": quota, "equal_to_single_process": True,
+                "note": f"{avail} CPUs in the affinity mask, cgroup CFS quota {quota}: this container is paid for {eff} CPUs, which hold ONE oracle "
+                        f"process at its best thread count ({best_th}); more processes are only throttled (measured once on this pool: 16 x 16 "
+                        "threads under a 16-CPU quota took 43x longer per step).  The all-cores figure of this container equals the single-process one"}
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{T},{seed},{best_th},{run_s}"]
     env = dict(os.environ, OMP_NUM_THREADS=str(best_th), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     procs = []
@@ -753,7 +759,8 @@ def main():
                 line["machine_probes"] = {"error": str(ex)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cb = cpu_baseline(T, S, 0, a.cpu_budget)
-            allc = (cb.get("all_cores_concurrent") or {}).get("value")
+            acc = cb.get("all_cores_concurrent") or {}
+            allc = cb["value"] if acc.get("equal_to_single_process") else acc.get("value")
             line["speedup_vs_cpu_baseline"] = {
                 "vs_single_process": round(value / max(cb["value"], 1e-9), 1),
                 "vs_all_cores_concurrent": round(value / allc, 1) if allc else None,
