@@ -250,9 +250,11 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
                                            "one ticket per sampling and reads it behind the step's own synchronisation"}
     batch = {"inputs_2d": x2d, "inputs_3d": gt[:x2d.shape[0]], "init_noise": noise, "init_noise_flip": noise}
     tv, res = timed(lambda: evaluate(diff, [batch], scale=1.0, device=dev, verbose=False), n=1)
-    out["evaluate_equiv_frames_per_s"] = {"value": round(Bl * T / tv, 1), "unit": "frames/s", "windows_per_s": round(Bl / tv, 3),
+    To = gt.shape[1]                               # target frames per window: T, or 1 for a seq2frame model
+    out["evaluate_equiv_frames_per_s"] = {"value": round(Bl * To / tv, 1), "unit": "frames/s", "windows_per_s": round(Bl / tv, 3),
                                           "mpjpe_mm_vs_synthetic_gt": round(res["mpjpe_mm"], 3),
-                                          "note": "evaluate(): 2 DDIM samplings per window (normal + flipped 2D) + merge + MPJPE (RUN:575-621)"}
+                                          "note": "evaluate(): 2 DDIM samplings per window (normal + flipped 2D) + merge + MPJPE (RUN:575-621; "
+                                                  "a seq2frame model -- the 3DHP runner's form -- predicts ONE frame per window)"}
     if a.precision != "fp32":
         net.precision = "fp32"
         e32 = diff._engine(dev)
@@ -503,6 +505,7 @@ def main():
     tickets = []                                  # one F16X3 range-guard ticket per sampling: posted behind it, READ after the
                                                   # step's own synchronisation (the read-back of the MPJPE sums) -- never a wait of its own
     guard_on = a.precision == "f16x3"
+    seen_flags = [0]                              # OR of the flags read so far
 
     def step(record=False):
         pred = eng.ddim_sample(x2d, noise)
@@ -516,6 +519,8 @@ def main():
             e1.record()                           # (the current stream waits for the collective before anything behind it)
             ag_events.append((e0, e1))
         res = tta_mpjpe(pred, None, gt, None, 1.0, [], [])          # (reads the two sums back: the step's synchronisation)
+        while tickets:                            # ... behind which this sampling's snapshot has run: its flags are there, no wait
+            seen_flags[0] |= eng.take_range(tickets.pop(), block=True) or 0
         if not first_done:
             first_done.append(time.time())
         return res
@@ -530,7 +535,7 @@ def main():
         eng.set_graph_mode(True)
     for _ in range(a.warmup):
         step()
-    tickets.clear()
+    seen_flags[0] = 0                             # (the timed samplings' flags only)
     # ---- timed region: the engine as a user gets it -- per-kernel event timing OFF
     fence()
     t0 = time.perf_counter()
@@ -545,9 +550,7 @@ def main():
     except Exception:
         t_created = _T_IMPORT
     startup_s = (first_done[0] - t_created) if first_done else None
-    range_flags = 0
-    for tk in tickets:                            # the timed samplings' range flags (every snapshot has long run: no wait)
-        range_flags |= eng.take_range(tk, block=True) or 0
+    range_flags = seen_flags[0]                   # the timed samplings' range flags (read inside step(), behind each step's own sync)
     rank_stats = None
     if use_dist:
         cdev = dev if backend == "nccl" else "cpu"
@@ -734,7 +737,7 @@ def main():
                             "one_process_per_gpu": not bool(os.environ.get("D3D_BENCH_ONE_DEVICE")),
                             "collectives": ["barrier", "all_gather_into_tensor", "all_reduce(MAX)"]}
     extras = None
-    if world == 1 and not a.no_extras and not a.seq2frame:
+    if world == 1 and not a.no_extras:
         extras = companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl)
     if rank == 0:
         if extras:

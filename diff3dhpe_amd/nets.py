@@ -70,8 +70,9 @@ class _MixSTEDenoiser(nn.Module):
     range_check = os.environ.get("D3D_CHECK_RANGE", "1").strip().lower() not in ("0", "false", "no", "off")
     # One process per GPU is the supported multi-GPU form (torchrun; parallel.py).  nn.DataParallel over SEVERAL devices in one
     # process (RUN:216-218 with --gpu_id 0,1,...) would need one engine per device driven from DataParallel's worker threads:
-    # that path has never run on hardware, so it fails loudly instead of being trusted.  Flip this to try it anyway.
-    allow_multi_device = False
+    # that path has never run on hardware, so it fails loudly instead of being trusted.  Flip this (or export D3D_ALLOW_MULTI_DEVICE=1
+    # for the unchanged runner with --gpu_id 0,1,...) to try it anyway.
+    allow_multi_device = os.environ.get("D3D_ALLOW_MULTI_DEVICE", "0").strip().lower() in ("1", "true", "yes", "on")
 
     def __init__(self, num_frame=9, num_joints=17, in_chans=2, embed_dim=32, depth=4, num_heads=8, mlp_ratio=2.,
                  qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None,
@@ -155,7 +156,8 @@ class _MixSTEDenoiser(nn.Module):
                     f"this model already runs on cuda:{next(iter(self._engines))} and is now asked to run on cuda:{idx}: diff3dhpe_amd "
                     "supports ONE device per process (launch one process per GPU: `python bench.py --gpus N`, torchrun --nproc-per-node "
                     "N, or pass one id to --gpu_id); nn.DataParallel over several devices in one process is untested -- set "
-                    "allow_multi_device = True on the model class to try it (moving the whole module with .to() is fine)")
+                    "allow_multi_device = True on the model class (or D3D_ALLOW_MULTI_DEVICE=1) to try it (moving the whole module "
+                    "with .to() is fine)")
         engines, sigs = (self._engines_fb, self._engine_sig_fb) if fallback else (self._engines, self._engine_sig)
         want = "fp32" if fallback else self._primary_precision()
         eng = engines.get(idx)
