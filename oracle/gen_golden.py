@@ -634,10 +634,65 @@ def gen_round5():
     save("evaluate_3dhp_s2f", **ev)
 
 
+def gen_round5b():
+    """The reference's OWN 3DHP command lines (Experiments.sh:15-17: ...S2S... model, out_all=True, stride = frames = 27, no time
+    embedding) through the data flow of the 3DHP runner's evaluate() (run_..._3dhp.py:510-533) on the synthetic 3DHP-shaped set: seq2seq
+    windows with the last one shifted, the overlap mask ANDed with the frames' `valid` flags -- per-batch MPJPE and frame counts."""
+    import tempfile
+    from types import SimpleNamespace
+    from common.mpiinf3dhp_dataset import MPIINF3DHPDataset
+    from data.load_noisy_data import load_Dataset_3dhp
+    from diff3dhpe_amd.synth import write_synth_3dhp
+    with tempfile.TemporaryDirectory() as root:
+        write_synth_3dhp(root, seed=0)
+        T, S = 27, 3
+        opt = SimpleNamespace(dataset="3dhp", keypoints="gt", subjects_train="S1,S2", subjects_test="TS1,TS5,TS3", actions="*", downsample=1,
+                              subset=1, stride=T, test_time_augmentation=True, number_of_frames=T, out_all=True, batch_size=4,
+                              data_augmentation=False)
+        ds = MPIINF3DHPDataset(opt, root_path=root)
+        cfg = cfg_full(T, with_time_emb=False)
+        net, diff, sd = build_ref(cfg, 12, sampling=S)
+        jl, jr = ds.joints_left, ds.joints_right
+        tabs = orc.diffusion_tables("cosine", 1000)
+        out = {}
+        for seq in ("TS1", "TS5", "TS3"):
+            refq = load_Dataset_3dhp(opt, ds._test, pos_3d_min=ds._pos_3d_min, pos_3d_max=ds._pos_3d_max, split="test", seq_filter=seq)
+            loader = torch.utils.data.DataLoader(refq, batch_size=2, shuffle=False, num_workers=0, drop_last=False)
+            errs, cnts = [], []
+            for bi, (_, inputs_3d, inputs_3d_norm, inputs_2d, inputs_2d_flip, target_mask, *_rest) in enumerate(loader):
+                B = inputs_2d.shape[0]
+                noise = torch.from_numpy(hash_uniform(f"eval3dhp_s2s/{seq}/noise/{bi}", B * T * 17 * 3, 5).astype(np.float32).reshape(B, T, 17, 3)) * 1.7
+                noise_f = torch.from_numpy(hash_uniform(f"eval3dhp_s2s/{seq}/noise_flip/{bi}", B * T * 17 * 3, 5).astype(np.float32).reshape(B, T, 17, 3)) * 1.7
+                tmask = target_mask.view(-1)
+                n3f = inputs_3d_norm.clone()
+                n3f[:, :, :, 0] *= -1
+                n3f[:, :, jl + jr] = n3f[:, :, jr + jl]
+                with torch.no_grad():
+                    with inject_noise(noise):
+                        _, pred = diff(clean_3d_pose=inputs_3d_norm, noisy_2d_pose=inputs_2d)
+                    with inject_noise(noise_f):
+                        _, pred_f = diff(clean_3d_pose=n3f, noisy_2d_pose=inputs_2d_flip)
+                pred_f[:, :, :, 0] *= -1
+                pred_f[:, :, jl + jr] = pred_f[:, :, jr + jl]
+                p = refq.reverse_norm_3d_pose((pred + pred_f) / 2.0)
+                p = p.view(-1, 17, 3)[tmask == True, :, :].unsqueeze(1)  # noqa: E712
+                g = inputs_3d.view(-1, 17, 3)[tmask == True, :, :].unsqueeze(1)  # noqa: E712
+                e = ref_mpjpe(p, g)
+                oe, on = orc.evaluate_batch(sd, tabs, inputs_2d, inputs_2d_flip, inputs_3d, target_mask, noise, noise_f, scale=float(refq.scale),
+                                            depth=8, sampling_timesteps=S, joints_left=jl, joints_right=jr)
+                assert on == g.shape[0]
+                check(f"3dhp s2s evaluate {seq} batch {bi} mpjpe (mm)", oe, e, 2e-3)
+                errs.append(float(e)); cnts.append(int(g.shape[0]))
+            out[f"{seq}/mpjpe_per_batch"] = np.asarray(errs, np.float64)
+            out[f"{seq}/frames_per_batch"] = np.asarray(cnts, np.int32)
+            print(f"  3dhp s2s evaluate() {seq}: {len(errs)} batches, {sum(cnts)} valid frames, MPJPE {np.dot(errs, cnts) / sum(cnts):.4f} mm")
+        save("evaluate_3dhp_s2s", seed=np.int32(12), S=np.int32(S), batch_size=np.int32(2), scale=np.float32(refq.scale), **out)
+
+
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
-    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5,
+    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5, "round5b": gen_round5b,
 }
 
 if __name__ == "__main__":

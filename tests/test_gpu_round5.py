@@ -438,3 +438,41 @@ def test_head_kernel_recompute_fence(prec):
     X = torch.randn(77, 512, device="cuda")
     a = eng.head(X)
     assert torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_evaluate_seq2seq_3dhp_the_references_own_command_lines(prec):
+    """Experiments.sh:15-17 as written: the ...S2S... model WITHOUT time embedding on MPI-INF-3DHP, out_all=True (27-frame windows, the last
+    one shifted, its overlap mask ANDed with the frames' `valid` flags), the 3DHP runner's evaluate() call shape -- per test sequence
+    (run_evaluation(): seq_filter), both routes (DataLoader batches of the host adaptor; evaluate_sequence on the device), against the
+    per-batch MPJPE the REFERENCE produced on the synthetic 3DHP-shaped set (evaluate_3dhp_s2s.npz)."""
+    from conftest import gold
+    from diff3dhpe_amd.data import EvalData3DHP
+    from diff3dhpe_amd.evaluate import evaluate_sequence
+    from diff3dhpe_amd.synth import synth_mocap_3dhp, hash_uniform
+    g = gold("evaluate_3dhp_s2s")
+    T, S, bs = 27, int(g["S"]), int(g["batch_size"])
+    cfg = cfg_full(T, with_time_emb=False)
+    _, net, diff = _model(cfg, int(g["seed"]), lambda sd: None, precision=prec, sampling=S)
+    test, train = synth_mocap_3dhp(0)
+    ed = EvalData3DHP(test, ["TS1", "TS5", "TS3"], T, out_all=True, train_data=train)
+    kw = dict(scale=ed.scale, joints_left=ed.joints_left, joints_right=ed.joints_right, output_loss=True, unit_scale=1.0)
+    for seq in ("TS1", "TS5", "TS3"):
+        batches, nzs, nzfs = [], [], []
+        for bi, b in enumerate(ed.batches(bs, seq_filter=seq)):
+            B = b["inputs_2d"].shape[0]
+            b["init_noise"] = torch.from_numpy(hash_uniform(f"eval3dhp_s2s/{seq}/noise/{bi}", B * T * 17 * 3, 5).astype(np.float32).reshape(B, T, 17, 3)) * 1.7
+            b["init_noise_flip"] = torch.from_numpy(hash_uniform(f"eval3dhp_s2s/{seq}/noise_flip/{bi}", B * T * 17 * 3, 5).astype(np.float32).reshape(B, T, 17, 3)) * 1.7
+            batches.append(b); nzs.append(b["init_noise"]); nzfs.append(b["init_noise_flip"])
+        ref_e, ref_n = g[f"{seq}/mpjpe_per_batch"], g[f"{seq}/frames_per_batch"]
+        for bi, b in enumerate(batches):
+            r = evaluate(diff, [b], verbose=False, **kw)
+            assert r["frames"] == int(ref_n[bi]) and abs(r["mpjpe_mm"] - float(ref_e[bi])) <= GATE * ed.scale, (seq, bi, r, ref_e[bi])
+        whole = evaluate(diff, batches, verbose=False, **kw)
+        ref = float(np.dot(ref_e, ref_n) / ref_n.sum())
+        assert whole["frames"] == int(ref_n.sum()) and abs(whole["mpjpe_mm"] - ref) <= GATE * ed.scale
+        _, p2, p3, valid = ed.sequence(seq)
+        dev_route = evaluate_sequence(diff, torch.from_numpy(p2), torch.from_numpy(p3), num_frames=T, batch_size=bs, init_noise=torch.cat(nzs).cuda(),
+                                      init_noise_flip=torch.cat(nzfs).cuda(), valid=torch.from_numpy(valid), **kw)
+        assert dev_route["frames"] == whole["frames"] and dev_route["mpjpe_mm"] == whole["mpjpe_mm"]
+        print(f"3DHP seq2seq evaluate() {seq} [{prec}]: MPJPE {whole['mpjpe_mm']:.4f} mm (reference {ref:.4f}), {whole['frames']} valid frames")
