@@ -150,6 +150,9 @@ hipError_t launch_linear_bf16(const void* A, const void* W, const float* bias, c
 bool bf16_rows_ok(int N, int K);
 hipError_t launch_linear_bf16_rows(const void* A, const void* W, const float* bias, float* X, void* Hb, int M, int N, int K,
                                    const X3PostNorm& pn, hipStream_t s);
+// kernels_gemm_bf16q.hip: the plain bf16 GEMMs (qkv, fc1) on the hand-specialised two-phase k-loop; bit-identical to launch_linear_bf16's forms
+bool gemm_bf16q_ok(int N, int K);
+hipError_t launch_gemm_bf16q(const void* A, const void* W, const float* bias, void* Cb, int M, int N, int K, int epi, int qcols, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* x, float* y, size_t n, hipStream_t s);
 hipError_t launch_scale_cols(float* x, size_t rows, int cols, int ncols_scaled, float f, hipStream_t s);   // op hooks only

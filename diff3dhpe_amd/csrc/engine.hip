@@ -86,6 +86,9 @@ struct d3d_engine {
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
+  // "bf16_gemm_kernel": BF16 mode, qkv and fc1 on their own kernel (kernels_gemm_bf16q.hip: the hand-specialised k-loop) from two rounds of
+  // 256 x 256 tiles on; bit-identical to the token GEMM's forms
+  bool opt_bf16_gemm_kernel = true;
   // "head_inject" (tests only): the head kernel perturbs the FIRST of its two evaluations of row 0's dot products, so that its
   // run-time fence -- compare, third evaluation, D3D_RANGE_RECOMPUTE -- can be seen working (kernels_elem.hip k_head)
   int opt_head_inject = 0;
@@ -529,6 +532,8 @@ int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   auto linear = [&](const uint16_t* A, const uint16_t* W, const float* bias, const float* R, float* C, uint16_t* Cb, int N, int K, int epi,
                     int qcols, int sub) -> hipError_t {
     Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)N * K, 2.0 * ((double)M * K + (double)N * K) + (double)M * N * (R ? 8.0 : 2.0), s, sub);
+    if (e->opt_bf16_gemm_kernel && !R && Cb && gemm_bf16q_ok(N, K) && (long long)((M + 255) / 256) * (N / 256) >= 2LL * device_cu_count())
+      return launch_gemm_bf16q(A, W, bias, Cb, M, N, K, epi, qcols, s);
     return launch_linear_bf16(A, W, bias, R, C, Cb, M, N, K, epi, qcols, s);
   };
   auto lnorm = [&](LnArgs a) -> hipError_t {
@@ -1317,6 +1322,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   else if (k == "fc1_kernel") e->opt_fc1_kernel = value != 0;
   else if (k == "proj_kernel") e->opt_proj_kernel = value != 0;
   else if (k == "head_inject") e->opt_head_inject = value != 0;
+  else if (k == "bf16_gemm_kernel") e->opt_bf16_gemm_kernel = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");
     e->opt_streams = (int)value;

@@ -7,6 +7,18 @@
 // in the shadow of the SIMD partner's MFMAs.
 #pragma once
 
+// QF_MMA(ACC, BH, BL, AH, AL) (optional): the products of one (m-tile, n-tile) pair for one staged 128-byte line of each operand row.
+// Default: F16X3 -- the line holds the 32 hi and the 32 lo halves of a 32-deep k-tile: a_lo b_hi + a_hi b_lo + a_hi b_hi, smallest terms
+// first.  kernels_gemm_bf16q.hip defines the bf16 form (the line holds 64 bf16 k values: one MFMA per 16-byte fragment pair).
+#ifndef QF_MMA
+#define QF_MMA(ACC, BH, BL, AH, AL)                                                                                      \
+  do {                                                                                                                   \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(BH, AL, ACC, 0, 0, 0);                                                  \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(BL, AH, ACC, 0, 0, 0);                                                  \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(BH, AH, ACC, 0, 0, 0);                                                  \
+  } while (0)
+#endif
+
     // one phase (kernels_gemm_x3p.hip D3D_PHASE, WPF form): H = 0: m-tiles 0-3 of k-tile KT, issues A(KT+1) (and all of W(1), ahead of
     // A(1), in a tile's first phase); H = 1: m-tiles 4-7, issues W(KT+2); the W fragments of KT+1 replace those of KT behind the
     // last group's MFMA triples (W_AHEAD), the odd phase's first A pair is requested by the last group of the even phase
@@ -63,9 +75,7 @@
         }                                                                                                                \
         const bool w_ahead_ = (H) == 1 && g == G1 - 1 && (W_AHEAD);                                                      \
         _Pragma("unroll") for (int j = 0; j < QF_NJ; ++j) {                                                              \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                      \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                      \
+          QF_MMA(acc[g][j], bh[j], bl[j], ah[g & 1], al[g & 1]);                                                         \
           if (w_ahead_) {                                                                                                \
             const unsigned char* sbn = lds + (((KT) + 1) & 1) * QF_STAGE;                                                \
             bh[j] = *reinterpret_cast<const h8*>(sbn + boff + j * 2048);                                                 \

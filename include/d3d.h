@@ -145,6 +145,8 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *                     with the token GEMM's own epilogue function, from two rounds of 256 x 256 tiles on -- / as a form of the token GEMM.
  *                     Bit-identical.
  *   "proj_kernel"     1 (default) / 0: the same for proj (192 x 256 tiles; rows behind the last whole tile through the token GEMM).
+ *   "bf16_gemm_kernel" 1 (default) / 0: BF16 mode, qkv and fc1 on their own kernel (the hand-specialised two-phase k-loop with one bf16
+ *                     MFMA per fragment pair, from two rounds of 256 x 256 tiles on) / as forms of the token GEMM.  Bit-identical.
  *   "head_inject"     0 (default) / 1, tests only: the head kernel perturbs the first of its two evaluations of row 0 -- the fence must
  *                     repair the row (result unchanged) and raise D3D_RANGE_RECOMPUTE
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and

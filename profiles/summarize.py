@@ -60,6 +60,9 @@ def short(name: str) -> str:
         return "k_fc1_x3<256x256 persistent, EPI_GELU, pair-out, LN-folded> (fc1)"
     if "k_proj_x3" in name:
         return "k_proj_x3<192x256 persistent, EPI_RESIDUAL, pair-out, plane residual + row stats> (proj)"
+    if "k_gemm_bf16q" in name:      # template argument = EPI: 0 none (qkv), 1 GELU (fc1)
+        gelu = "k_gemm_bf16q<1>" in name or "k_gemm_bf16qILi1E" in name
+        return "k_gemm_bf16q<256x256 persistent, {}, bf16-out, bf16 operands> ({})".format("EPI_GELU" if gelu else "EPI_NONE", "fc1" if gelu else "qkv")
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("d3d::", "").strip()
     _FX = {"0": "", "1": ", LN-folded", "2": ", plane residual", "6": ", plane residual + row stats",
@@ -178,7 +181,7 @@ def traffic(pmc_json, traffic_json, T, B, prec):
         if "k_qkv_sattn" in n or "k_qkv_tattn" in n:
             return False
         return "k_attn_spatial" in n or "k_attn_temporal_x3p<1," in n or "k_attn_temporal_x3<1," in n or "(spatial blocks)" in n
-    cls = {"linear": lambda n: "k_linear" in n or "k_fc1_x3" in n or "k_proj_x3" in n, "layernorm": lambda n: "k_layernorm" in n, "qkv_sattn": lambda n: "k_qkv_sattn" in n, "qkv_tattn": lambda n: "k_qkv_tattn" in n,
+    cls = {"linear": lambda n: "k_linear" in n or "k_fc1_x3" in n or "k_proj_x3" in n or "k_gemm_bf16q" in n, "layernorm": lambda n: "k_layernorm" in n, "qkv_sattn": lambda n: "k_qkv_sattn" in n, "qkv_tattn": lambda n: "k_qkv_tattn" in n,
            "attn_spatial": is_spatial, "attn_temporal": lambda n: ("k_attn_temporal" in n or "k_attn_bf16" in n) and not is_spatial(n)}
     tj = json.load(open(traffic_json)) if os.path.exists(traffic_json) else {}
     for c, pat in cls.items():

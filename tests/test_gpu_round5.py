@@ -476,3 +476,27 @@ def test_evaluate_seq2seq_3dhp_the_references_own_command_lines(prec):
                                       init_noise_flip=torch.cat(nzfs).cuda(), valid=torch.from_numpy(valid), **kw)
         assert dev_route["frames"] == whole["frames"] and dev_route["mpjpe_mm"] == whole["mpjpe_mm"]
         print(f"3DHP seq2seq evaluate() {seq} [{prec}]: MPJPE {whole['mpjpe_mm']:.4f} mm (reference {ref:.4f}), {whole['frames']} valid frames")
+
+
+# ------------------------------------------------------------------------------------------------ bf16 operand mode (second-class)
+@pytest.mark.parametrize("T,B", [(81, 25), (27, 80)])
+def test_bf16_gemm_kernel_is_bit_identical_to_the_token_gemm_forms(T, B):
+    """BF16 mode: qkv and fc1 on their own kernel (kernels_gemm_bf16q.hip: the hand-specialised two-phase k-loop of the fused F16X3 kernels
+    with one bf16 MFMA per fragment pair) against the token GEMM's bf16 forms -- per element the same MFMAs in the same order and the same
+    epilogue function, so a whole forward is bit-identical; M = B T 17 is not a multiple of 256 (the ragged last M-tile goes through the
+    checked epilogue) and the workspace is filled with NaN first (operand pad rows are staged, never stored)."""
+    cfg = type(cfg_full(T))(num_frame=T, embed_dim=512, depth=2)
+    _, net, diff = _model(cfg, 21, lambda sd: None, precision="bf16", sampling=2)
+    eng = diff._engine(_dev())
+    inp = inputs(B, T, 77)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    assert (B * T * 17) % 256 != 0
+    outs = []
+    for on in (1, 0, 1):
+        eng.set_option("bf16_gemm_kernel", on)
+        eng._ws = None
+        eng._workspace(B).view(torch.float32).fill_(float("nan"))
+        outs.append(eng.ddim_sample(x2d, nz).clone())
+    eng.set_option("bf16_gemm_kernel", 1)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -22,6 +22,8 @@ KERNELS = {
     "void d3d::(anonymous namespace)::k_linear_x3q_persist<8, 1, 8, 2, 2, 10>(_Float16 const*, _Float16 const*)": "fc2 + post-norm",
     "void d3d::(anonymous namespace)::k_linear_x3q_persist<8, 2, 4, 0, 1, 1>(_Float16 const*, _Float16 const*)": "(qkv)",
     "void d3d::k_head<2>(d3d::HeadArgs)": "k_head<2>",
+    "void d3d::(anonymous namespace)::k_gemm_bf16q<0>(d3d::(anonymous namespace)::BqArgs)": "(qkv)",
+    "void d3d::(anonymous namespace)::k_gemm_bf16q<1>(d3d::(anonymous namespace)::BqArgs)": "(fc1)",
 }
 
 
@@ -31,5 +33,5 @@ def test_every_product_kernel_gets_a_name_and_a_price():
         name = summ.short(raw)
         assert name.strip() and part in name, (raw, name)
     src = open(os.path.join(ROOT, "profiles", "roofline_table.py")).read()
-    for key in ("k_qkv_sattn", "k_qkv_tattn", "k_fc1_x3", "k_proj_x3", "k_linear", "k_head", "k_embed"):
+    for key in ("k_qkv_sattn", "k_qkv_tattn", "k_fc1_x3", "k_proj_x3", "k_gemm_bf16q", "k_linear", "k_head", "k_embed"):
         assert key in src
