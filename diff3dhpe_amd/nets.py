@@ -193,6 +193,8 @@ class _MixSTEDenoiser(nn.Module):
             flags &= ~_lib.RANGE_RECOMPUTE
             if not flags:
                 return False
+        if flags & _lib.RANGE_INDEX:            # not a precision matter either: no engine computes a row whose timestep is outside the tables
+            raise IndexError(f"{what}: " + Engine.describe_range_flags(_lib.RANGE_INDEX) + " (the row's output is NaN; DIFF:21-24)")
         self._guard["flagged"] += 1
         msg = Engine.describe_range_flags(flags)
         if self.precision != "auto":
