@@ -126,7 +126,9 @@ class _MixSTEDenoiser(nn.Module):
         return {name: self._tensor(name) for name, _, _, _ in denoiser_param_spec(self.cfg)}
 
     def _param_signature(self):
-        return tuple((t.data_ptr(), t._version) for t in self._named_tensors().values())
+        # (over self.parameters(): 0.3 ms for the 240 tensors -- the attribute walk of _named_tensors() is 1.4 ms, per call, and shows in
+        # the latency of small batches; a DataParallel replica has no Parameters and is never asked: it carries the source's _src_sig)
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _replicate_for_data_parallel(self):
         # nn.DataParallel re-broadcasts the parameters on every call (RUN:217); remember the source tensors' identity

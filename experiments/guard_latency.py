@@ -20,6 +20,9 @@ net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 0)
 diff = d3d.GaussianDiffusion(model=net, timesteps=1000, sampling_timesteps=S, loss_type="l2", clip_denoised=True, beta_schedule="cosine",
                              ddim_sampling_eta=0.0, clipLoss=True).eval().to(dev)
 eng = diff._engine(dev)
+if os.environ.get("STREAMS"):
+    eng.set_option("streams", int(os.environ["STREAMS"]))
+    print("streams", os.environ["STREAMS"])
 for B in [int(a) for a in sys.argv[1:]] or [1, 4, 16, 64]:
     inp = synth_inputs_rows(0, B, T, seed=42)
     x2d, nz = torch.from_numpy(inp["x2d"]).to(dev), torch.from_numpy(inp["noise"]).to(dev)
