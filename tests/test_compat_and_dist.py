@@ -150,3 +150,24 @@ def test_bench_self_launch_ends_its_ranks_when_the_launcher_is_terminated():
     assert p.returncode not in (0, None) and "ending the rank processes" in err
     gone, alive = psutil.wait_procs(kids, timeout=5)
     assert not alive
+
+
+def test_bench_host_side_helpers():
+    """bench.py pieces that run without a GPU: the per-row synthetic batch (any shard of it holds the same rows), the cgroup-aware CPU
+    count, and the concurrent CPU-baseline leg (oracle workers as fresh processes; one process when the CPU quota holds only one)."""
+    import importlib.util
+    import numpy as np
+    from diff3dhpe_amd.synth import synth_inputs_rows
+    a = synth_inputs_rows(0, 7, 9)
+    b = synth_inputs_rows(3, 5, 9)
+    assert a["x2d"].shape == (7, 9, 17, 2) and all(np.array_equal(a[k][3:5], b[k]) for k in a)
+    assert synth_inputs_rows(4, 4, 9)["noise"].shape == (0, 9, 17, 3)
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    aff, quota = bench.usable_cpus()
+    assert aff >= 1 and (quota is None or quota > 0)
+    one = bench.cpu_baseline_concurrent(9, 3, 0, 4, 64, 0.1, quota=4.0)          # a 4-CPU quota holds ONE 4-thread process: nothing is started
+    assert one["equal_to_single_process"] and one["processes"] == 1 and one["value"] is None
+    two = bench.cpu_baseline_concurrent(9, 3, 0, 1, 2, 0.1, run_s=0.5, quota=None)   # two 1-thread oracle workers, T = 9
+    assert two.get("processes") == 2 and two["value"] and two["steps_finished"] >= 2, two
