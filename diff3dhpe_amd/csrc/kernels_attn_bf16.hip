@@ -64,6 +64,16 @@ void k_attn_bf16(const __bf16* __restrict__ qkv, __bf16* __restrict__ out, int T
   const int r = lane & 31, h = lane >> 5;
   const size_t tok0 = (size_t)b * T * J + j;                       // token(t) = tok0 + t * J
 
+  // the first pass's query fragments are requested together with the K / V rows, in front of the staging barrier (round 5: behind it
+  // their latency was exposed once per unit -- these kernels are latency-bound: 3 TB/s of 8 with the matrix pipe 9 % busy)
+  // (QT = 1 forms only: the two-pass forms sit at the register limit)
+  bf8 qf0[4];
+  if constexpr (QT == 1) {
+    const int tq0 = 32 * wave + r;
+    const size_t o = (tok0 + (size_t)(tq0 < T ? tq0 : 0) * J) * D3 + hd * BDH + 8 * h;   // rows >= T reuse row 0: never stored
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf0[ks] = *reinterpret_cast<const bf8*>(qkv + o + 16 * ks);
+  }
   {  // ---- stage K and V rows of the unit (pad rows zero); all global loads are issued before the LDS writes
     constexpr int NIT = 4 * QT;                                    // TP * 8 chunk slots / (64 * NW threads)
     uint4 kk[NIT], vv[NIT];
@@ -109,7 +119,10 @@ void k_attn_bf16(const __bf16* __restrict__ qkv, __bf16* __restrict__ out, int T
   const int tq = 32 * (wave + pass * NW) + r;
   if (32 * (wave + pass * NW) >= T) break;                        // (wave-uniform)
   bf8 qf[4];
-  {
+  if (QT == 1) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qf0[ks];
+  } else {
     const size_t o = (tok0 + (size_t)(tq < T ? tq : 0) * J) * D3 + hd * BDH + 8 * h;   // rows >= T reuse row 0: never stored
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8*>(qkv + o + 16 * ks);
