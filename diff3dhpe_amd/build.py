@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libd3d_hip.so")
-SOURCES = ["engine.hip", "kernels_gemm.hip", "kernels_gemm_f16x3.hip", "kernels_gemm_x3p.hip", "kernels_elem.hip", "kernels_attn.hip", "kernels_attn_x3.hip", "kernels_attn_bf16.hip", "kernels_qkv_sattn.hip", "kernels_qkv_tattn.hip", "kernels_fc1_x3.hip", "kernels_proj_x3.hip", "kernels_gemm_bf16q.hip", "probes.hip"]
+SOURCES = ["engine.hip", "kernels_gemm.hip", "kernels_gemm_f16x3.hip", "kernels_gemm_x3p.hip", "kernels_elem.hip", "kernels_attn.hip", "kernels_attn_x3.hip", "kernels_attn_bf16.hip", "kernels_qkv_sattn.hip", "kernels_qkv_tattn.hip", "kernels_fc1_x3.hip", "kernels_proj_x3.hip", "kernels_fc2_ring.hip", "kernels_gemm_bf16q.hip", "probes.hip"]
 HEADERS = ["d3d_kernels.h", "gemm_x3p_prelude.h", "gemm_x3p_epilogue.h", "x3q_epilogue_acc.h", "qkv_fused_kloop.h", os.path.join("..", "..", "include", "d3d.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -176,6 +176,15 @@ hipError_t launch_qkv_sattn(const void* Apair, const void* Wpair_headmajor, cons
 bool proj_x3_ok(int N, int K);
 hipError_t launch_proj_x3(const void* Apair, const void* Wpair, const float* bias, void* Xpair, float* st_out, int w_exp, int M, int N, int K,
                           hipStream_t s);
+// kernels_fc2_ring.hip: fc2 + post-norm (launch_linear_x3p's X3Fold Rp + pn form, outsplit 2 / 0) on a k-loop without workgroup barriers
+// (wave-private W slots, A through a four-slot ring with per-slot arrival counters in LDS), 128 x 512 whole-row tiles, the ragged last
+// tile included; bit-identical to that form.  delay: waves 4-7 start each tile that many x 64 cycles late (default 24).
+bool fc2_ring_ok(int N, int K);
+void set_fc2_ring_delay(int d);
+void set_fc2_ring_dbg(int d);
+void set_fc2_ring_diag(unsigned long long* dev_buf);   // nullable; 8 u64 per workgroup
+hipError_t launch_fc2_ring(const void* Apair, const void* Wpair, const float* bias, float* C, void* Ch, int M, int N, int K, int outsplit,
+                           const X3Fold* fold, int w_exp, hipStream_t s);
 bool fc1_x3_ok(int N, int K);
 hipError_t launch_fc1_x3(const void* Apair, const void* Wpair, const float* bias_f, const float* csum, const float* st_in, int st_np,
                          float eps, int w_exp, void* out_pair, int M, int N, int K, hipStream_t s);

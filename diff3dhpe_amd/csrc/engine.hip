@@ -21,7 +21,7 @@ namespace {
 
 thread_local std::string g_err;
 // process-wide diagnostic switches (d3d_engine_set_option with a NULL engine): in-kernel stamp reports of the op hooks
-std::atomic<int> g_opt_gemm_diag{0}, g_opt_attn_diag{0};
+std::atomic<int> g_opt_gemm_diag{0}, g_opt_attn_diag{0}, g_opt_fc2_ring_op{0};
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -83,6 +83,8 @@ struct d3d_engine {
   bool opt_fc1_kernel = true;
   // "proj_kernel": the same for proj (kernels_proj_x3.hip: whole 192-row tiles; the rows behind the last whole tile stay with the template)
   bool opt_proj_kernel = true;
+  // "fc2_ring" (off: measured 2.5 % behind the template form, NOTES round 6): fc2 + post-norm on the barrier-free k-loop (kernels_fc2_ring.hip)
+  bool opt_fc2_ring = false;
   // "streams" = 2 (default): d3d_ddim_sample runs two half-batches concurrently, the second on side_stream (forked / joined by
   // events); 1: the whole batch on the caller's stream
   int opt_streams = 2;
@@ -473,13 +475,20 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
       f.pn.g = pn_g; f.pn.b = pn_b; f.pn.eps = 1e-6f; f.pn.pos_div = 1; f.pn.pos_mod = 1; f.pn.rows_per_batch = T * J;
       if (k == 0) { f.pn.pos = e->tpos; f.pn.pos_div = J; f.pn.pos_mod = T; }
       if (!last && tvec) { f.pn.tvec = tvec + (size_t)(k + 1) * D; f.pn.tvec_stride = tvec_stride; }
+      // (on the ring kernel where the template would take its persistent walk: the same tiles and values)
+      const bool fc2_ring = e->opt_fc2_ring && fc2_ring_ok(D, e->Dm) && (M + 127) / 128 >= 2 * 256;
+      auto fc2 = [&](float* C, uint16_t* Ch, int outsplit) -> hipError_t {
+        if (!fc2_ring) return gemm(HIDx, bw.fc2_x3, bw.fc2_e, bw.fc2b, C, Ch, nullptr, outsplit, D, e->Dm, EPI_RESIDUAL, 0, f);
+        Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)D * e->Dm, 4.0 * ((double)M * e->Dm + (double)D * e->Dm + 2.0 * M * D), s, D3D_KC_LINEAR_FC2);
+        return launch_fc2_ring(HIDx, bw.fc2_x3, bw.fc2b, C, Ch, M, D, e->Dm, outsplit, &f, bw.fc2_e, s);
+      };
       if (!last) {
         f.st_out = w.ST1;
-        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2_e, bw.fc2b, nullptr, XP, nullptr, 2, D, e->Dm, EPI_RESIDUAL, 0, f));
+        HIP_TRY(fc2(nullptr, XP, 2));
         np1 = np2;
         TRACE(k, 6, 1, w.ST1, (size_t)M * 8 * np2);
       } else {
-        HIP_TRY(gemm(HIDx, bw.fc2_x3, bw.fc2_e, bw.fc2b, w.X, nullptr, nullptr, 0, D, e->Dm, EPI_RESIDUAL, 0, f));
+        HIP_TRY(fc2(w.X, nullptr, 0));
       }
       TRACE(k, 6, 0, w.X, MDb);
       continue;
@@ -1314,6 +1323,10 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   if (k == "attn_diag") { g_opt_attn_diag = value != 0; return D3D_OK; }
   if (k == "qs_diag") { set_qkv_sattn_diag(value != 0); return D3D_OK; }
   if (k == "qt_diag") { set_qkv_tattn_diag(value != 0); return D3D_OK; }
+  if (k == "fc2_ring_delay") { set_fc2_ring_delay((int)value); return D3D_OK; }   // the ring kernel's start delay of waves 4-7 (x 64 cycles)
+  if (k == "fc2_ring_dbg") { set_fc2_ring_dbg((int)value); return D3D_OK; }
+  if (k == "fc2_ring_diag") { set_fc2_ring_diag(reinterpret_cast<unsigned long long*>((uintptr_t)value)); return D3D_OK; }   // 8 u64 per workgroup
+  if (k == "fc2_ring_op") { g_opt_fc2_ring_op = value != 0; return D3D_OK; }       // d3d_op_linear_postnorm through the ring kernel
   if (!e) return fail(D3D_EINVAL, "null engine");
   if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;
@@ -1321,6 +1334,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   else if (k == "fused_temporal") e->opt_fused_temporal = value != 0;
   else if (k == "fc1_kernel") e->opt_fc1_kernel = value != 0;
   else if (k == "proj_kernel") e->opt_proj_kernel = value != 0;
+  else if (k == "fc2_ring") e->opt_fc2_ring = value != 0;
   else if (k == "head_inject") e->opt_head_inject = value != 0;
   else if (k == "bf16_gemm_kernel") e->opt_bf16_gemm_kernel = value != 0;
   else if (k == "streams") {
@@ -1808,7 +1822,9 @@ int d3d_op_linear_postnorm(const float* A, const float* W, const float* bias, co
   f.pn.pos = pos; f.pn.pos_div = pos ? pos_div : 1; f.pn.pos_mod = pos ? pos_mod : 1;
   f.pn.tvec = tvec; f.pn.tvec_stride = tvec_stride; f.pn.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
   f.st_out = part;
+  const bool ring = g_opt_fc2_ring_op && fc2_ring_ok(N, K);
   auto once = [&]() -> hipError_t {
+    if (ring) return launch_fc2_ring(ap.dev, wp.dev, bias, stats ? nullptr : Y, stats ? yp.dev : nullptr, M, N, K, stats ? 2 : 0, &f, wp.wexp, s);
     if (stats) return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, nullptr, yp.dev, nullptr, M, N, K, EPI_RESIDUAL, 2, 0, 0, s, &f, wp.wexp);
     return launch_linear_x3p(ap.dev, wp.dev, bias, nullptr, Y, nullptr, nullptr, M, N, K, EPI_RESIDUAL, 0, 0, 0, s, &f, wp.wexp);
   };

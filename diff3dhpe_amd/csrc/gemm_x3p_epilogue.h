@@ -352,10 +352,14 @@ __device__ __forceinline__ void x3q_epilogue8(f32x4 (&acc)[TM][4], float* patch,
 // vacate; row statistics go through xch ([BM][WN] float2 of LDS beside the patches: one (sum, M2) partial per wave);
 // sweep 2 normalises and stores planes + the (sum, sum of squares) partials of y for the next folded GEMM
 // (OUTSPLIT 2) or fp32 rows (OUTSPLIT 0, last block).
-template <int TM, int WN, int OUTSPLIT, bool CHECK>
+// RING (kernels_fc2_ring.hip): the patches are the calling wave's OWN operand slot and the k-loop has no workgroup barrier, so (i) there
+// is no entry barrier, (ii) the barrier between the sweeps waits for LDS operations only (the caller keeps staging DMA in flight across
+// it), (iii) `hook` runs between sweep 1 and that barrier -- the patches are dead from there on (the caller re-fills its slot).
+struct X3NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int TM, int WN, int OUTSPLIT, bool CHECK, bool RING = false, class Hook = X3NoHook>
 __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patch, float* xch, const float* __restrict__ bias,
                                                 float* Ct, _Float16* Cht, const _Float16* Rpt, const X3Tail& fx, int mt0, int nt0,
-                                                int wn, int lane, int M, int N, int gl, int gh) {
+                                                int wn, int lane, int M, int N, int gl, int gh, Hook hook = Hook()) {
   static_assert(WN == 8, "row partials are read back as four float4");
   const float P_OUT_SCALE = fx.out_scale;
   const int m16 = lane & 15, q4 = lane >> 4;          // write side: accumulator layout
@@ -387,7 +391,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < PF; ++i) load_res(i);
-  __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
+  if constexpr (!RING) __syncthreads();   // every wave is done with the operand stages: reuse LDS for the transpose patches
   f2 vv[TM][2][4];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -440,7 +444,13 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
   if (tv_uniform) load8(fx.pn.tvec + n, tv);
   const int npart = N >> 6;
   float amax = 0.0f;   // range guard
-  __syncthreads();
+  if constexpr (RING) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's patch reads and exchange writes are done
+    hook();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else {
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i < gl || i >= gh) continue;
