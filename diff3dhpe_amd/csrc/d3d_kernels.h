@@ -257,7 +257,8 @@ struct HeadArgs {
   float alpha, alpha_next, somac, eta;
   float* traj_rev; float* traj_x0; int traj_rev_stride, traj_x0_stride, traj_idx;   // nullable
   unsigned* range;       // filled in by launch_head: the launching engine's guard word (RANGE_BIT_RECOMPUTE)
-  int inject;            // tests only ("head_inject" option): perturb the first evaluation of row 0
+  int fence;             // "head_fence" option: every row's dot products evaluated twice and compared (RANGE_BIT_RECOMPUTE)
+  int inject;            // tests only ("head_inject" option; implies the fence): perturb the first evaluation of row 0
 };
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 

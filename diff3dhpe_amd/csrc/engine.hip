@@ -94,6 +94,9 @@ struct d3d_engine {
   // "head_inject" (tests only): the head kernel perturbs the FIRST of its two evaluations of row 0's dot products, so that its
   // run-time fence -- compare, third evaluation, D3D_RANGE_RECOMPUTE -- can be seen working (kernels_elem.hip k_head)
   int opt_head_inject = 0;
+  // "head_fence": that fence on (round 5's default).  Off since round 6: the deviation it guarded against is identified (a packed fp32
+  // form beside another wave's MFMAs) and its absence from every kernel is a build-time test
+  int opt_head_fence = 0;
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int device = -1;                // ordinal of the device the weights were committed on
@@ -715,7 +718,7 @@ int head_rows(const d3d_engine* e, int B) { return e->cfg.seq2frame ? B * e->J :
 // fills X / rows for the head (runs the seq2frame frame reduce first when needed)
 int prep_head(d3d_engine* e, HeadArgs& h, int B, const Workspace& w, hipStream_t s) {
   h.g = e->hd_g; h.b = e->hd_b; h.eps = 1e-5f; h.Wh = e->hd_w; h.bh = e->hd_bias; h.D = e->D;
-  h.inject = e->opt_head_inject;
+  h.inject = e->opt_head_inject; h.fence = e->opt_head_fence;
   h.rows = head_rows(e, B);
   if (e->cfg.seq2frame) {
     Prof p(e, D3D_KC_OTHER, 2.0 * B * e->T * e->J * e->D, 4.0 * B * e->T * e->J * e->D, s);
@@ -1336,6 +1339,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   else if (k == "proj_kernel") e->opt_proj_kernel = value != 0;
   else if (k == "fc2_ring") e->opt_fc2_ring = value != 0;
   else if (k == "head_inject") e->opt_head_inject = value != 0;
+  else if (k == "head_fence") e->opt_head_fence = value != 0;
   else if (k == "bf16_gemm_kernel") e->opt_bf16_gemm_kernel = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");

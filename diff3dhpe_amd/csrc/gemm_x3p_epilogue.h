@@ -421,7 +421,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
       // pairwise update formula -- as accurate as a two-pass variance, with one exchange)
       const f2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
       const float sm = row8_sum(s2.x + s2.y);
-      const f2 lm = splat2(sm * (1.0f / 64.0f));
+      const f2 lm = splat2_rt(sm * (1.0f / 64.0f));
       f2 d[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = v[e] - lm;
@@ -466,7 +466,7 @@ __device__ __forceinline__ void x3q_epilogue_pn(f32x4 (&acc)[TM][4], float* patc
                   e6 = p3.x * (1.0f / 64.0f) - mean, e7 = p3.z * (1.0f / 64.0f) - mean;
       const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
                        64.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
-      const f2 rstd = splat2(1.0f / sqrtf(m2 * invn + fx.pn.eps)), mean2 = splat2(mean);
+      const f2 rstd = splat2_rt(1.0f / sqrtf(m2 * invn + fx.pn.eps)), mean2 = splat2_rt(mean);
       f2 (&v)[4] = vv[i][p];
       if (CHECK && m >= M) continue;
 #pragma unroll
@@ -548,7 +548,7 @@ __device__ __forceinline__ void x3q_epilogue_rows_bf16(f32x4 (&acc)[TM][4], floa
   auto partial = [&](const f2 (&v)[4], float* dst, int r) {   // this wave's 64 columns of row r: (sum, M2 about their own mean)
     const f2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
     const float sm = row8_sum(s2.x + s2.y);
-    const f2 lm = splat2(sm * (1.0f / 64.0f));
+    const f2 lm = splat2_rt(sm * (1.0f / 64.0f));
     f2 d[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = v[e] - lm;
@@ -565,8 +565,8 @@ __device__ __forceinline__ void x3q_epilogue_rows_bf16(f32x4 (&acc)[TM][4], floa
                 e6 = p3.x * (1.0f / 64.0f) - mean, e7 = p3.z * (1.0f / 64.0f) - mean;
     const float m2 = (((p0.y + p0.w) + (p1.y + p1.w)) + ((p2.y + p2.w) + (p3.y + p3.w))) +
                      64.0f * (((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3)) + ((e4 * e4 + e5 * e5) + (e6 * e6 + e7 * e7)));
-    mean2 = splat2(mean);
-    rstd2 = splat2(1.0f / sqrtf(m2 * invn + eps));
+    mean2 = splat2_rt(mean);
+    rstd2 = splat2_rt(1.0f / sqrtf(m2 * invn + eps));
   };
 #pragma unroll
   for (int i = 0; i < TM; ++i) {

@@ -457,7 +457,7 @@ hipError_t launch_frame_reduce(const float* X, const float* w, const float* bias
 // wrong words; this whole-line form deviated as well) -- what decides it is the instruction stream of the 3-row dot product
 // below.  Whole-line ownership is kept as a performance rule: no two workgroups store into the same 128-byte line.
 constexpr int HEAD_ROWS = 32;
-template <int NV>
+template <int NV, bool FENCE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
   static_assert(HEAD_ROWS % WAVES_PER_BLOCK == 0 && (HEAD_ROWS * 3 * 4) % 128 == 0, "whole lines per workgroup");
   __shared__ float so[HEAD_ROWS * 3];
@@ -476,14 +476,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
       v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
     }
     ln_row<NV>(v, D, lane, a.g, a.b, a.eps);
-    // The three dot products of the row, as a function of the weight pointer so that they can be evaluated TWICE from independently
-    // loaded fragments (below).  One weight fragment loaded and consumed at a time, and the three sums kept out of packed (v_pk_*)
-    // register pairs by an opaque barrier after every update.  This is the instruction stream that never deviated on a GPU shared
-    // with a second process (0 of ~900 traced samplings); the compiler's free schedule -- three loads in flight behind counted waits,
-    // o[0] / o[1] in v_pk_fma_f32 pairs -- returned ONE wrong o[0] in about 1 launch of 60 there.  The mechanism below the
-    // instruction stream is not identified (experiments/NOTES.md); tests/test_abi_host.py checks the built kernel's ISA for these
-    // two properties in EVERY evaluation (the one-fragment-at-a-time waits at every width, the unpacked sums at the production
-    // width), and the default GPU suite repeats a two-process sampling (tests/test_gpu_round4.py) as the run-time cross-check.
+    // The three dot products of the row, as a function of the weight pointer so that they can be evaluated more than once (FENCE below).
+    // One weight fragment loaded and consumed at a time, and the three sums kept out of packed (v_pk_*) register pairs by an opaque
+    // barrier after every update.  This is the instruction stream that never deviated on a GPU shared with a second process (0 of ~900
+    // traced samplings); the compiler's free schedule -- three loads in flight behind counted waits, o[0] / o[1] in v_pk_fma_f32 pairs
+    // with op_sel -- returned ONE wrong o[0] in about 1 launch of 60 there.  Round 6 identified the mechanism (experiments/NOTES.md
+    // section 000, experiments/probes/pk_beside_mfma*.hip): a packed fp32 instruction whose SRC1 low half selects the high dword of its
+    // register pair now and then reads 0 for that half in lanes 48-63 while the SIMD's other wave -- here: a wave of the other
+    // process's GEMM -- issues MFMAs.  tests/test_abi_host.py checks the built kernel's ISA for the two properties above and, since
+    // round 6, EVERY kernel of the library for the absence of that instruction form.
     typedef const float __attribute__((address_space(1))) * gfp;   // (a laundered pointer stays a GLOBAL pointer: global_load, not flat_load)
     auto dot3 = [&](gfp Wh, float (&o)[3], float poke) {
       o[0] = poke; o[1] = 0.f; o[2] = 0.f;
@@ -510,29 +511,32 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_head(HeadArgs a) {
       o[2] = wave_sum(o[2]);
       asm volatile("" : "+v"(o[2]));
     };
-    // RUN-TIME FENCE (round 5): the sums are formed twice -- the second time from fragments loaded again through a pointer the
-    // compiler cannot see through -- and compared bit for bit.  They have to agree: same instruction stream, same inputs.  If they
-    // do not (the signature of the two-process deviation, whatever its cause), a third evaluation decides by majority and the
-    // engine's D3D_RANGE_RECOMPUTE bit is raised, so that a toolchain or driver change that brings the deviation back is REPORTED
-    // by the default guard read instead of silently moving a pose.  Cost: the weight fragments come from L1 / L2 (6 KB), the row is
-    // already in registers -- measured +0.03 ms per launch of 0.21.  a.inject (tests only) perturbs the
-    // first evaluation of row 0.
-    float o[3], o2[3];
-    dot3((gfp)a.Wh, o, (a.inject && row == 0 && lane == 0) ? 1.0f : 0.0f);
-    gfp Wh2 = (gfp)a.Wh;
-    asm volatile("" : "+s"(Wh2));
-    dot3(Wh2, o2, 0.0f);
-    const bool same = ((__float_as_uint(o[0]) ^ __float_as_uint(o2[0])) | (__float_as_uint(o[1]) ^ __float_as_uint(o2[1])) |
-                       (__float_as_uint(o[2]) ^ __float_as_uint(o2[2]))) == 0u;
-    if (!same) {                                      // wave-uniform: wave_sum hands every lane the same value
-      float o3[3];
-      gfp Wh3 = (gfp)a.Wh;
-      asm volatile("" : "+s"(Wh3));
-      dot3(Wh3, o3, 0.0f);
+    // RUN-TIME FENCE ("head_fence" option; round 5's default, since round 6 off: the deviation it guarded against is identified and
+    // pinned out of every kernel at build time): the sums are formed twice -- the second time from fragments loaded again through a
+    // pointer the compiler cannot see through -- and compared bit for bit.  They have to agree: same instruction stream, same inputs.
+    // If they do not, a third evaluation decides by majority and the engine's D3D_RANGE_RECOMPUTE bit is raised.  Cost: +0.08 ms per
+    // launch of 0.21.  a.inject (tests only) perturbs the first evaluation of row 0.
+    float o[3];
+    if constexpr (!FENCE) {
+      dot3((gfp)a.Wh, o, 0.0f);
+    } else {
+      float o2[3];
+      dot3((gfp)a.Wh, o, (a.inject && row == 0 && lane == 0) ? 1.0f : 0.0f);
+      gfp Wh2 = (gfp)a.Wh;
+      asm volatile("" : "+s"(Wh2));
+      dot3(Wh2, o2, 0.0f);
+      const bool same = ((__float_as_uint(o[0]) ^ __float_as_uint(o2[0])) | (__float_as_uint(o[1]) ^ __float_as_uint(o2[1])) |
+                         (__float_as_uint(o[2]) ^ __float_as_uint(o2[2]))) == 0u;
+      if (!same) {                                      // wave-uniform: wave_sum hands every lane the same value
+        float o3[3];
+        gfp Wh3 = (gfp)a.Wh;
+        asm volatile("" : "+s"(Wh3));
+        dot3(Wh3, o3, 0.0f);
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        o[k] = (__float_as_uint(o3[k]) == __float_as_uint(o2[k])) ? o2[k] : ((__float_as_uint(o3[k]) == __float_as_uint(o[k])) ? o[k] : o3[k]);
-      if (lane == 0) range_raise(a.range, RANGE_BIT_RECOMPUTE);
+        for (int k = 0; k < 3; ++k)
+          o[k] = (__float_as_uint(o3[k]) == __float_as_uint(o2[k])) ? o2[k] : ((__float_as_uint(o3[k]) == __float_as_uint(o[k])) ? o[k] : o3[k]);
+        if (lane == 0) range_raise(a.range, RANGE_BIT_RECOMPUTE);
+      }
     }
     if (lane < 3) so[lr * 3 + lane] = (lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]));
   }
@@ -573,12 +577,15 @@ hipError_t launch_head(const HeadArgs& a_in, hipStream_t s) {
   a.range = launch_range_word();
   if (a.rows <= 0 || (a.D & 3) || a.D > 256 * LN_MAXV) return hipErrorInvalidValue;
   const int grid = (a.rows + HEAD_ROWS - 1) / HEAD_ROWS;
-  if (a.D <= 256)
-    hipLaunchKernelGGL((k_head<1>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
-  else if (a.D <= 512)
-    hipLaunchKernelGGL((k_head<2>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_head<4>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+#define D3D_HEAD_LAUNCH(NV)                                                                                              \
+  do {                                                                                                                   \
+    if (a.fence || a.inject) hipLaunchKernelGGL((k_head<NV, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);    \
+    else hipLaunchKernelGGL((k_head<NV, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, s, a);                       \
+  } while (0)
+  if (a.D <= 256) D3D_HEAD_LAUNCH(1);
+  else if (a.D <= 512) D3D_HEAD_LAUNCH(2);
+  else D3D_HEAD_LAUNCH(4);
+#undef D3D_HEAD_LAUNCH
   return hipGetLastError();
 }
 

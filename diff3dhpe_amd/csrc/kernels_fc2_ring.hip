@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
     const char* const ubA = reinterpret_cast<const char*>(a.Ap) + (size_t)(m0 + wave * 8) * rowb;
     const char* const ubAn = reinterpret_cast<const char*>(a.Ap) + (size_t)(mtn * R2_BM + wave * 8) * rowb;
     const char* const ubW = reinterpret_cast<const char*>(a.Wp) + (size_t)(wave * 64) * rowb;
-    const int dstA = R2_A + wave * 1024 + lane * 16, dstW = wave * R2_WSLOT + lane * 16;
+    const int dstA = R2_A + wave * 1024, dstW = wave * R2_WSLOT;   // wave-uniform: M0 holds the wave's base, the hardware adds lane * 16
     const size_t a_it = (size_t)64 * rowb, w_it = (size_t)8 * rowb;
 
     f32x4 acc[R2_TM][R2_NJ];
@@ -185,15 +185,13 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
 #define R2_WPIECE(KTT, P)                                                                                               \
     R2_GLDS(sgpr_ptr(ubW + ((size_t)(KTT) * 128 + (P) * w_it)) + (lofs_e ^ (((P) & 1) ? 64u : 0u)), dstW + (P) * 1024)
 
-    // One k-tile.  SRCA: wave-uniform source of this wave's first A piece of ring k-tile T + 2; DO_A / DO_W: whether those / the next
-    // k-tile's W pieces exist (literal true in the steady state: no branch inside the MFMA stream).
-    // Groups: g0 2 A pieces, g1 .. g4 2 W pieces each (behind the W fragment reads of g0), g5 .. g7 none.
-#define R2_KTILE(KT, SRCA, DO_A, DO_W, STEADY)                                                                                  \
+    // The opening of a tile's first k-tile: the wave's own pieces landed, its W(T) fragments, the A slot complete, the first A pair.
+    // Every later k-tile finds all of that done by the last group of its predecessor (PREF below).
+#define R2_OPEN()                                                                                                       \
     do {                                                                                                                \
       R2_STAMP(5);                                                                                                      \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* my W(T) has landed (and everything older) */               \
       R2_STAMP(0);                                                                                                      \
-      if (a.dbg & 1) __syncthreads();                                                                                   \
       _Pragma("unroll") for (int j = 0; j < R2_NJ; ++j) {   /* W: this wave's own slot */                               \
         bh[j] = *reinterpret_cast<const h8*>(lds + boff + j * 2048);                                                    \
         bl[j] = *reinterpret_cast<const h8*>(lds + ((boff + j * 2048) ^ 64));                                           \
@@ -202,42 +200,78 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
         const unsigned n_ = (unsigned)__builtin_amdgcn_readfirstlane(                                                  \
             (int)lds_poll_ge(cnt + 4u * (T & 3u), 8u * ((T >> 2) + 1u), R2_POLL_LIMIT));                                \
         tmo |= n_ >= R2_POLL_LIMIT ? 1u : 0u;                                                                           \
-        if (a.dbg & 256) {   /* the wave that did not have to wait is the one behind: it gets the matrix pipe first */  \
-          if (n_ <= 1u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);                               \
-        }                                                                                                               \
         if (a.diag) dg_s += n_;                                                                                         \
       }                                                                                                                 \
       R2_STAMP(1);                                                                                                      \
       asm volatile("" : "+v"(lofs_e) : : "memory");                                                                     \
+      const unsigned char* const sa0 = lds + R2_A + (int)(T & 3u) * R2_ASLOT;                                           \
+      ah[0] = *reinterpret_cast<const h8*>(sa0 + aoff);                                                                 \
+      al[0] = *reinterpret_cast<const h8*>(sa0 + (aoff ^ 64));                                                          \
+    } while (0)
+
+    // One k-tile; on entry W(T)'s fragments and the first A pair are in registers and the A slot is known complete.
+    // SRCA: wave-uniform source of this wave's first A piece of ring k-tile T + 2; DO_A / DO_W: whether those / the next k-tile's W pieces
+    // exist (literal true in the steady state: no branch inside the MFMA stream); STEADY: the signal's wait is counted.
+    // Groups: g0 .. g3 2 W pieces each, g4 2 A pieces, g3 the signal, g6 requests the next slot's counter, g7 (PREF) opens the NEXT
+    // k-tile: own pieces landed (vmcnt 0), the next A slot complete, its first A pair requested, W(T+1)'s fragments behind the last triples.
+#define R2_KTILE(KT, SRCA, DO_A, DO_W, STEADY, PREF)                                                                    \
+    do {                                                                                                                \
       const unsigned char* const sa = lds + R2_A + (int)(T & 3u) * R2_ASLOT;                                            \
-      ah[0] = *reinterpret_cast<const h8*>(sa + aoff);                                                                  \
-      al[0] = *reinterpret_cast<const h8*>(sa + (aoff ^ 64));                                                           \
+      unsigned cv_ = 0;                                                                                                 \
       _Pragma("unroll") for (int g = 0; g < R2_TM; ++g) {                                                               \
+        if ((PREF) && g == R2_TM - 2 && !(a.dbg & 64))   /* the next slot's counter, read a group ahead of its use */    \
+          asm volatile("ds_read_b32 %0, %1" : "=v"(cv_) : "v"(cnt + 4u * ((T + 1u) & 3u)) : "memory");                  \
+        if ((PREF) && g == R2_TM - 1) {                                                                                 \
+          R2_STAMP(4);                                                                                                  \
+          if (STEADY) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   /* my W(T+1) (the two A pieces behind it stay in flight); the counter word; this group's A pair */ \
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+          R2_STAMP(0);                                                                                                  \
+          if (!(a.dbg & 64)) {                                                                                          \
+            const unsigned tgt_ = 8u * (((T + 1u) >> 2) + 1u);                                                          \
+            unsigned n_ = 0;                                                                                            \
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)cv_) < tgt_) {                                            \
+              n_ = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_poll_ge(cnt + 4u * ((T + 1u) & 3u), tgt_, R2_POLL_LIMIT)); \
+              tmo |= n_ >= R2_POLL_LIMIT ? 1u : 0u;                                                                     \
+            }                                                                                                           \
+            if (a.dbg & 256) {   /* the wave that did not have to wait is the one behind: it gets the matrix pipe first */ \
+              if (n_ == 0u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);                           \
+            }                                                                                                           \
+            if (a.diag) dg_s += n_;                                                                                     \
+          }                                                                                                             \
+          R2_STAMP(1);                                                                                                  \
+          asm volatile("" : "+v"(lofs_e) : : "memory");                                                                 \
+          const unsigned char* const san = lds + R2_A + (int)((T + 1u) & 3u) * R2_ASLOT;                                \
+          ah[0] = *reinterpret_cast<const h8*>(san + aoff);                                                             \
+          al[0] = *reinterpret_cast<const h8*>(san + (aoff ^ 64));                                                      \
+        }                                                                                                               \
         if (g + 1 < R2_TM) {                                                                                            \
           ah[(g + 1) & 1] = *reinterpret_cast<const h8*>(sa + aoff + (g + 1) * 2048);                                   \
           al[(g + 1) & 1] = *reinterpret_cast<const h8*>(sa + ((aoff + (g + 1) * 2048) ^ 64));                          \
         }                                                                                                               \
-        if (g == 0) {                                                                                                   \
+        if (g < 4) {                                                                                                    \
+          if (DO_W) { R2_WPIECE((KT) + 1, 2 * g); R2_WPIECE((KT) + 1, 2 * g + 1); }                                     \
+        } else if (g == 4) {                                                                                            \
           if (DO_A) { R2_APIECE(SRCA, 0); R2_APIECE(SRCA, 1); }                                                         \
-        } else if (g <= 4) {                                                                                            \
-          if (DO_W) { R2_WPIECE((KT) + 1, 2 * (g - 1)); R2_WPIECE((KT) + 1, 2 * (g - 1) + 1); }                         \
         }                                                                                                               \
         _Pragma("unroll") for (int j = 0; j < R2_NJ; ++j) {                                                             \
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[g & 1], acc[g][j], 0, 0, 0);                     \
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[g & 1], acc[g][j], 0, 0, 0);                     \
+          if ((PREF) && g == R2_TM - 1) {   /* W(T+1)'s fragments replace W(T)'s behind their last use */                \
+            bh[j] = *reinterpret_cast<const h8*>(lds + boff + j * 2048);                                                \
+            bl[j] = *reinterpret_cast<const h8*>(lds + ((boff + j * 2048) ^ 64));                                       \
+          }                                                                                                             \
         }                                                                                                               \
-        if (g == 0) {   /* the opening: this group's A pair, 2 MFMAs, then as below */                                   \
+        if ((PREF) && g == R2_TM - 1) {   /* the next A pair, then MFMA triple, its W pair's successor, ... */           \
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                            \
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                            \
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                            \
         } else {        /* 2 MFMAs, a read, 2 MFMAs, a read, 2 MFMAs, a piece, 2 MFMAs, the other piece, 4 MFMAs */     \
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
         }                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         if (g == 0) R2_STAMP(2);                                                                                        \
-        if (g == R2_SIG) {   /* "my pieces of A(T+1) have landed": everything older than this k-tile's 2 A + 6 W pieces */ \
+        if (g == R2_SIG) {   /* "my pieces of A(T+1) have landed": everything older than this k-tile's 8 W pieces */          \
           if (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
           if (!(a.dbg & 64)) lds_signal(cnt + 4u * ((T + 1u) & 3u), lane);                                              \
@@ -259,19 +293,20 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
           R2_STAMP(3);                                                                                                  \
         }                                                                                                               \
       }                                                                                                                 \
-      R2_STAMP(4);                                                                                                      \
       ++T;                                                                                                              \
     } while (0)
 
     int kt = 0;
+    R2_OPEN();
     if (a.dbg & 48) {   // timing probes (wrong results): 16 no W pieces, 32 no A pieces in the steady state
       const bool pa = !(a.dbg & 32), pw = !(a.dbg & 16);
-      for (; kt + 2 < nk; ++kt) R2_KTILE(kt, ubA + (size_t)(kt + 2) * 128, pa, pw, false);
+      for (; kt + 2 < nk; ++kt) R2_KTILE(kt, ubA + (size_t)(kt + 2) * 128, pa, pw, false, true);
     }
-    for (; kt + 2 < nk; ++kt) R2_KTILE(kt, ubA + (size_t)(kt + 2) * 128, true, true, true);
-    R2_KTILE(kt, ubAn, has_next, true, false);            // k-tile nk - 2: A(0) of the next tile
+    for (; kt + 2 < nk; ++kt) R2_KTILE(kt, ubA + (size_t)(kt + 2) * 128, true, true, true, true);
+    R2_KTILE(kt, ubAn, has_next, true, false, true);      // k-tile nk - 2: A(0) of the next tile
     ++kt;
-    R2_KTILE(kt, ubAn + 128, has_next, false, false);     // k-tile nk - 1: A(1) of the next tile; its W(0) waits for the patches
+    R2_KTILE(kt, ubAn + 128, has_next, false, false, false);   // k-tile nk - 1: A(1) of the next tile; its W(0) waits for the patches
+#undef R2_OPEN
 #undef R2_KTILE
 #undef R2_APIECE
 
@@ -324,7 +359,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
 
 bool fc2_ring_ok(int N, int K) { return N == 512 && K % 128 == 0 && K >= 256; }
 
-static std::atomic<int> g_r2_delay{24}, g_r2_dbg{2};
+static std::atomic<int> g_r2_delay{24}, g_r2_dbg{256};
 void set_fc2_ring_dbg(int d) { g_r2_dbg = d; }
 static std::atomic<unsigned long long*> g_r2_diag{nullptr};
 void set_fc2_ring_delay(int d) { g_r2_delay = d < 0 ? 0 : (d > 4096 ? 4096 : d); }

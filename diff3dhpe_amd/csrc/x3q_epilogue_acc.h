@@ -8,6 +8,18 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat2(float a) { return (f2)(a); }
+// (a, a) as a register pair the compiler cannot see through -- for every RUN-TIME scalar that meets packed arithmetic.  Reason: a gfx950
+// deviation found in round 6 (experiments/probes/pk_beside_mfma*.hip, experiments/NOTES.md section 000): v_pk_{add,mul,fma}_f32 whose
+// SRC1 low half selects the HIGH dword of its register pair (op_sel:[.,1,..] -- what the compiler emits when it folds a broadcast of a
+// value that sits in an odd register) now and then computes the low result of lanes 48-63 with src1 = 0 while the SIMD's other wave
+// issues MFMAs next to LDS-DMA.  With the pair opaque there is nothing to fold; tests/test_abi_host.py pins the absence of that form
+// in every kernel of the library.
+__device__ __forceinline__ f2 splat2_rt(float a) {
+  f2 r;
+  r.x = a; r.y = a;
+  asm volatile("" : "+v"(r));
+  return r;
+}
 // GELU(x) = 0.5 x + |x| (0.5 - q),  q = 0.5 erfc(|x| / sqrt 2) = t (a1 + t (a2 + ... a5 t)) exp(-x^2 / 2) / 2,  t = 1 / (1 + p |x| / sqrt 2)
 // (Abramowitz-Stegun 7.1.26, coefficients halved).  Per pair of values: 2 + 2 scalar instructions that take |x| as a source
 // modifier, 9 packed ones, v_rcp and v_exp twice -- four issue slots fewer than the form max(x, 0) - (|x| / 2) (p t) e, which

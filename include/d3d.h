@@ -147,8 +147,15 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *   "proj_kernel"     1 (default) / 0: the same for proj (192 x 256 tiles; rows behind the last whole tile through the token GEMM).
  *   "bf16_gemm_kernel" 1 (default) / 0: BF16 mode, qkv and fc1 on their own kernel (the hand-specialised two-phase k-loop with one bf16
  *                     MFMA per fragment pair, from two rounds of 256 x 256 tiles on) / as forms of the token GEMM.  Bit-identical.
- *   "head_inject"     0 (default) / 1, tests only: the head kernel perturbs the first of its two evaluations of row 0 -- the fence must
- *                     repair the row (result unchanged) and raise D3D_RANGE_RECOMPUTE
+ *   "head_fence"      0 (default) / 1: the head kernel evaluates every row's three dot products twice from independently loaded weight
+ *                     fragments, compares them bit for bit, repairs a disagreement by a third evaluation and raises D3D_RANGE_RECOMPUTE
+ *                     (round 5's default against a deviation seen on a GPU shared by two processes; since round 6 that deviation is
+ *                     identified -- one packed fp32 instruction form beside another wave's MFMAs -- and pinned out of every kernel at
+ *                     build time, so the second evaluation is optional: +0.08 ms per launch of 0.21)
+ *   "head_inject"     0 (default) / 1, tests only (implies "head_fence"): the head kernel perturbs the first of its two evaluations of
+ *                     row 0 -- the fence must repair the row (result unchanged) and raise D3D_RANGE_RECOMPUTE
+ *   "fc2_ring"        0 (default) / 1: fc2 + post-norm on the k-loop without workgroup barriers (kernels_fc2_ring.hip: wave-private W
+ *                     slots, A through a ring with arrival counters in LDS); bit-identical; measured level with the token GEMM's form
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured

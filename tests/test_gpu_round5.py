@@ -417,6 +417,9 @@ def test_head_kernel_recompute_fence(prec):
         _, clean = diff(clean_3d_pose=z, noisy_2d_pose=x2d, output_loss=False, init_noise=nz)
         assert eng.take_range(eng.post_range()) == 0
         raw = eng.ddim_sample(x2d, nz)
+    eng.set_option("head_fence", 1)
+    assert torch.equal(eng.ddim_sample(x2d, nz), raw)                             # the fence by itself changes nothing
+    assert eng.take_range(eng.post_range()) == 0
     eng.set_option("head_inject", 1)
     try:
         poked = eng.ddim_sample(x2d, nz)
@@ -433,6 +436,7 @@ def test_head_kernel_recompute_fence(prec):
         assert g.get("recomputes") == 2
     finally:
         eng.set_option("head_inject", 0)
+        eng.set_option("head_fence", 0)
     assert eng.take_range(eng.post_range()) == 0
     # the single-op hook runs the same kernel (rows that are not a multiple of the 32-row workgroup included)
     X = torch.randn(77, 512, device="cuda")
