@@ -1014,6 +1014,11 @@ static bool x3q_big(int M, int N) {
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   return N % 256 == 0 && tiles >= 4 * 256;
 }
+static bool x3q_small(int M, int N) {   // every 128 x 128 tile gets a CU of its own
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const int n_cu = device_cu_count();
+  return N % 128 == 0 && n_cu > 0 && tiles <= (long long)n_cu;
+}
 int x3q_ntiles(int M, int N) { (void)M; return (N + 63) / 64; }   // statistics partials per row: one per 64 columns
 
 static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const float* bias, const float* R, float* C,
@@ -1027,6 +1032,11 @@ static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const 
   if (x3q_big(M, N) && (K / PBK) % 2 == 0)
     return launch_x3q_persist(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, fold, w_exp);
   if (x3q_big(M, N)) return launch_x3q<8, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
+  // Smallest launches (a batch of one sequence: the visualisation scripts, the ragged last batch of evaluate()): where 128 x 128 tiles
+  // (<2,4,2>: eight waves of 32 x 64) still find a CU each, the launch is as long as ONE tile takes and that tile is shorter -- proj at
+  // B = 1, T = 243: 26 -> 20.7 us per launch.  Beyond that (two such workgroups sharing a CU) the shape loses: fc1 at B = 1 28.7 -> 38.2 us
+  // (NOTES round 6).  Values do not depend on the tile shape.
+  if (x3q_small(M, N)) return launch_x3q<2, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
   return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
 }
 
