@@ -221,7 +221,7 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
         return (time.perf_counter() - t0) / n, r
 
     modes, ref, same = {}, None, True
-    for name, st, gr in (("eager_1stream", 1, False), ("eager_2stream", 2, False), ("graph_1stream", 1, True), ("graph_2stream", 2, True)):
+    for name, st, gr in (("eager_1stream", 1, False), ("eager_2stream", 2, False), ("graph_2stream", 2, True)):
         eng.set_option("streams", st)
         eng.set_graph_mode(gr)
         t, y = timed(lambda: eng.ddim_sample(x2d, noise))
@@ -233,8 +233,33 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
     out["launch_modes"] = {"ms_per_sampling": modes, "bit_identical_across_modes": same,
                            "note": "the same sampling (profiling off) as eager launches / as ONE hipGraph replay of the whole S-step loop "
                                    "(d3d_engine_set_graph_mode), on one stream / as two half-batches on two streams (\"streams\" option)"}
-    out["graph_vs_eager"] = {"eager_ms": modes["eager_1stream"], "graph_ms": modes["graph_1stream"],
-                             "graph_over_eager": round(modes["graph_1stream"] / modes["eager_1stream"], 4), "bit_identical": same}
+    out["graph_vs_eager"] = {"eager_ms": modes["eager_2stream"], "graph_ms": modes["graph_2stream"],
+                             "graph_over_eager": round(modes["graph_2stream"] / modes["eager_2stream"], 4), "bit_identical": same,
+                             "under": "two streams (the default)"}
+    # serving latency of small batches (visualisation scripts: B = 1; the ragged last batch of evaluate()): ms per S-step sampling
+    small = {}
+    for b in (1, 4):
+        if b < x2d.shape[0]:
+            xs, ns = x2d[:b].contiguous(), noise[:b].contiguous()
+            t, _ = timed(lambda: eng.ddim_sample(xs, ns), n=3)
+            small[str(b)] = round(t * 1e3, 3)
+    if small:
+        out["small_batch_latency_ms"] = dict(small, note="ms per sampling at B = 1 / B = 4 on this engine (eager launches, default streams)")
+    if (T, S, Bl) == (243, 9, 64) and a.precision == "f16x3" and not a.seq2frame and a.scaling == "weak":
+        # BASELINE configs[2] EXACTLY (B = 512) on this one GPU, so that a driver-timed figure exists for the configuration as written;
+        # the headline stays the B = 64 per-GPU shard (comparable with rounds 1-5)
+        try:
+            from diff3dhpe_amd.synth import synth_inputs_rows
+            big = synth_inputs_rows(0, 512, T, seed=42)
+            xb, nb = torch.from_numpy(big["x2d"]).to(dev), torch.from_numpy(big["noise"]).to(dev)
+            tb512, yb512 = timed(lambda: eng.ddim_sample(xb, nb), n=2)
+            out["strong_B512_N1"] = {"value": round(512 / tb512, 3), "unit": "pose-seq/s", "ms_per_step": round(tb512 * 1e3, 2),
+                                     "finite": bool(torch.isfinite(yb512).all()),
+                                     "first_64_rows_equal_the_headline_batch": bool(torch.equal(yb512[:x2d.shape[0]], eng.ddim_sample(x2d, noise))),
+                                     "note": "BASELINE configs[2] as written (global batch 512) on ONE GPU: 2 timed samplings after 1 warm one"}
+            del xb, nb, yb512
+        except Exception as ex:          # (e.g. a smaller-memory device) never fails the run
+            out["strong_B512_N1"] = {"error": str(ex)[:200]}
     if a.precision == "f16x3":
         # cost of reading the range guard the way the Python layer does by default: one one-lane snapshot kernel behind the call + a
         # wait on ITS event (never the device) -- timed back to back on an idle stream, i.e. with nothing to hide behind
@@ -298,6 +323,16 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
     return out
 
 
+def _mark_ready():
+    """Tell the self-launcher's watchdog that this rank's first sampling is done (a file in D3D_BENCH_READY_DIR; no-op elsewhere)."""
+    d = os.environ.get("D3D_BENCH_READY_DIR")
+    if d:
+        try:
+            open(os.path.join(d, "rank_" + os.environ.get("RANK", "0")), "w").close()
+        except OSError:
+            pass
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's JSON line.
 
@@ -315,6 +350,12 @@ def self_launch(n: int) -> int:
     import signal
     import tempfile
     procs = []
+    # Watchdog: every rank touches <ready_dir>/rank_<r> when its first sampling (and reduction) is done; a rank that
+    # has not done so `startup_timeout_s` after its start (D3D_BENCH_STARTUP_TIMEOUT_S, default 120: imports + weight commit + rendezvous +
+    # code-object loads take 5 ... 20 s) is named, every rank is ended and the launcher exits non-zero -- a hung rendezvous does not
+    # sit until the harness's own limit
+    startup_timeout_s = float(os.environ.get("D3D_BENCH_STARTUP_TIMEOUT_S", "120"))
+    ready_dir = tempfile.mkdtemp(prefix="d3d_bench_ready_")
 
     def end_children(grace=5.0):
         """terminate() every live child (its whole session: start_new_session below), wait briefly, then kill()."""
@@ -343,15 +384,28 @@ def self_launch(n: int) -> int:
         try:
             for r in range(n):
                 env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                           MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, D3D_BENCH_LAUNCHER="self")
+                           MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, D3D_BENCH_LAUNCHER="self",
+                           D3D_BENCH_READY_DIR=ready_dir)
                 env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
                 procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                               stdout=out0 if r == 0 else sys.stderr, start_new_session=True))
+            t_start = time.time()
+            watchdog_done = startup_timeout_s <= 0
             while any([p.poll() is None for p in procs]):     # (a list: every child is polled each round)
                 for r, p in enumerate(procs):
                     if first_bad is None and p.returncode not in (None, 0):
                         first_bad = (r, p.returncode)
                         end_children()         # a dead rank leaves the others waiting in a collective: end exactly our children
+                if not watchdog_done and first_bad is None:
+                    ready = [os.path.exists(os.path.join(ready_dir, f"rank_{r}")) for r in range(n)]
+                    if all(ready):
+                        watchdog_done = True
+                    elif time.time() - t_start > startup_timeout_s:
+                        slow = [r for r in range(n) if not ready[r]]
+                        print(f"bench.py self-launch: rank(s) {slow} had not finished a first sampling {startup_timeout_s:.0f} s after the "
+                              f"start (D3D_BENCH_STARTUP_TIMEOUT_S); ending all ranks", file=sys.stderr)
+                        first_bad = (slow[0], 124)
+                        end_children()
                 time.sleep(0.05)
         except KeyboardInterrupt as ex:
             print(f"bench.py self-launch: interrupted ({ex or 'SIGINT'}); ending the rank processes", file=sys.stderr)
@@ -360,6 +414,8 @@ def self_launch(n: int) -> int:
             end_children()                     # whatever ends the launcher -- Ctrl-C, SIGTERM, an exception -- no rank outlives it
             for sg, h in old_handlers.items():
                 signal.signal(sg, h)
+            import shutil
+            shutil.rmtree(ready_dir, ignore_errors=True)
         out0.seek(0)
         sys.stdout.write(out0.read().decode(errors="replace"))
         sys.stdout.flush()
@@ -428,6 +484,13 @@ def main():
         # launcher self-test (tests/test_compat_and_dist.py, no GPU): report the rank environment and leave; the rank named by
         # D3D_BENCH_LAUNCH_CHECK_FAIL exits non-zero instead (the launcher must propagate it and end the other ranks)
         r = int(os.environ.get("RANK", "0"))
+        if os.environ.get("D3D_BENCH_LAUNCH_CHECK_HANG") == str(r):
+            time.sleep(60)                     # (a rank stuck before its first sampling: the launcher's watchdog has to end it)
+            return
+        _mark_ready()
+        if os.environ.get("D3D_BENCH_LAUNCH_CHECK_HANG"):
+            time.sleep(60)                     # (the others would sit in a collective waiting for it)
+            return
         if os.environ.get("D3D_BENCH_LAUNCH_CHECK_FAIL") == str(r):
             sys.exit(7)
         if os.environ.get("D3D_BENCH_LAUNCH_CHECK_FAIL"):
@@ -494,6 +557,21 @@ def main():
     if a.seq2frame:   # one target frame per window (DIFF-S2F): noise / ground truth of the centre frame
         noise, gt_local = noise[:, :1].contiguous(), gt_local[:, T // 2:T // 2 + 1].contiguous()
     gt = parallel.all_gather_pred(gt_local, Bg) if world > 1 else gt_local
+    census = None
+    if use_dist:
+        # what the communicator itself saw: its rank count and the number of DISTINCT devices behind those ranks,
+        # from the devices' UUIDs gathered over it -- "RCCL saw N ranks on N devices" is then in the line, not an assumption
+        try:
+            uu = str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")) or f"cuda:{local}@{os.uname().nodename}"
+            mine = torch.zeros(64, dtype=torch.uint8)
+            raw = uu.encode()[:64]
+            mine[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+            mine = mine.to(dev if backend == "nccl" else "cpu")
+            allu = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allu, mine)
+            census = {"world": dist.get_world_size(), "distinct_devices": len({bytes(u.cpu().tolist()) for u in allu})}
+        except Exception as ex:
+            census = {"world": dist.get_world_size(), "distinct_devices": None, "error": str(ex)[:120]}
     eng = diff._engine(dev)
     eng.set_option("streams", a.streams)
     for kv in a.option:
@@ -523,6 +601,7 @@ def main():
             seen_flags[0] |= eng.take_range(tickets.pop(), block=True) or 0
         if not first_done:
             first_done.append(time.time())
+            _mark_ready()
         return res
 
     def fence():
@@ -566,7 +645,11 @@ def main():
                       "ms_per_step_max_over_ranks": round(float(tmax[0]) / a.steps * 1e3, 3),
                       "this_rank_ms_per_step": round(rank_ms, 3),
                       "allgather_ms_per_step_max_over_ranks": round(float(agt[0]), 4),
+                      "allgather_frac_of_step": round(float(agt[0]) / max(float(tmax[0]) / a.steps * 1e3, 1e-9), 5),
                       "allgather_bytes_per_rank": int(noise.numel() * 4),
+                      "rccl_world": (census or {}).get("world") if backend == "nccl" else None,
+                      "comm_world": (census or {}).get("world"),
+                      "distinct_devices": (census or {}).get("distinct_devices"),
                       "startup_s_max_over_ranks": round(float(agt[1]), 2),
                       "startup_note": "process creation -> this rank's first sampling + reduction done (imports, weight commit, rendezvous, "
                                       "first-launch code-object loads); max over ranks",
@@ -679,6 +762,12 @@ def main():
                     per = [(tj.get(f"{k}:T{T}:B{Bl}:{a.precision}"), prof[k]["launches"]) for k in fam]
                     roof["traffic"] = (round(sum(b * n for b, n in per) / sum(n for _, n in per)) if all(b is not None for b, _ in per) else None)
                 if roof["traffic"] is not None:
+                    # the file carries the hash of the library it was collected with (profiles/collect.sh): a kernel change since then
+                    # makes the figure stale -- said here instead of silently kept
+                    import hashlib
+                    from diff3dhpe_amd import _lib as _l
+                    sha = hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()
+                    roof["traffic_stale"] = ((tj.get("_lib_sha256") or {}).get(f"T{T}:B{Bl}:{a.precision}") != sha)
                     roof["traffic_source"] = ("profiles/hbm_traffic.json: mean bytes per launch of this kernel class from the "
                                               f"rocprofv3 --pmc passes of profiles/collect.sh ({tj.get('_collected', 'date not recorded')}), "
                                               "NOT measured in this run")

@@ -94,6 +94,9 @@ struct d3d_engine {
   // "head_inject" (tests only): the head kernel perturbs the FIRST of its two evaluations of row 0's dot products, so that its
   // run-time fence -- compare, third evaluation, D3D_RANGE_RECOMPUTE -- can be seen working (kernels_elem.hip k_head)
   int opt_head_inject = 0;
+  // "norm_eps_bits": eps of the constructor's norm_layer -- norm1 / norm2 of every block and the two post-norms (S2S:184: LayerNorm
+  // eps = 1e-6 unless the caller passes another norm_layer); the head's own LayerNorm keeps its 1e-5 (S2S:218)
+  float ln_eps = 1e-6f;
   // "head_fence": that fence on (round 5's default).  Off since round 6: the deviation it guarded against is identified (a packed fp32
   // form beside another wave's MFMAs) and its absence from every kernel is a build-time test
   int opt_head_fence = 0;
@@ -417,17 +420,17 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     if (temporal && fused_tp && bw.qkv_f3h) {
       // temporal block: q, k, v of one (batch, joint) group stay in LDS and feed the T-key attention in the same kernel (kernels_qkv_tattn.hip)
       Prof p(e, D3D_KC_QKV_TATTN, 2.0 * M * 3.0 * D * D + 4.0 * M * (double)T * D, 2.0 * MD4 + 4.0 * 3.0 * D * D, s);
-      HIP_TRY(launch_qkv_tattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, 1e-6f, bw.qkv_fe, AOx, B, T, J, D, D, e->H, s));
+      HIP_TRY(launch_qkv_tattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, e->ln_eps, bw.qkv_fe, AOx, B, T, J, D, D, e->H, s));
       TRACE(k, 3, 0, AOx, MDb);
     } else if (!temporal && fused_sp) {
       // spatial block: q, k, v of a frame group stay in LDS and feed the 17-key attention in the same kernel (kernels_qkv_sattn.hip)
       Prof p(e, D3D_KC_QKV_SATTN, 2.0 * M * 3.0 * D * D + 4.0 * M * (double)J * D, 2.0 * MD4 + 4.0 * 3.0 * D * D, s);
-      HIP_TRY(launch_qkv_sattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, 1e-6f, bw.qkv_fe, AOx, M, D, J, D, e->H, s));
+      HIP_TRY(launch_qkv_sattn(XP, bw.qkv_f3h, bw.qkv_fbh, bw.qkv_csh, w.ST1, np1, e->ln_eps, bw.qkv_fe, AOx, M, D, J, D, e->H, s));
       TRACE(k, 3, 0, AOx, MDb);
     } else {
     {  // q, k, v planes = norm1(x) Wqkv^T + b   (LayerNorm folded; q third pre-scaled by dh^-0.5)
       X3Fold f{};
-      f.st_in = w.ST1; f.st_np = np1; f.csum = bw.qkv_cs; f.eps = 1e-6f;
+      f.st_in = w.ST1; f.st_np = np1; f.csum = bw.qkv_cs; f.eps = e->ln_eps;
       HIP_TRY(gemm(XP, bw.qkv_f3, bw.qkv_fe, bw.qkv_fb, nullptr, QKVh, QKVl, 1, 3 * D, D, EPI_NONE, D, f));
     }
     TRACE(k, 2, 0, QKVh, 3 * MDb);
@@ -460,10 +463,10 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     TRACE(k, 4, 1, w.ST2, (size_t)M * 8 * np2);
     {  // hidden = gelu(norm2(x) W1^T + b1), LayerNorm folded
       X3Fold f{};
-      f.st_in = w.ST2; f.st_np = np2; f.csum = bw.fc1_cs; f.eps = 1e-6f;
+      f.st_in = w.ST2; f.st_np = np2; f.csum = bw.fc1_cs; f.eps = e->ln_eps;
       if (fc1_own) {
         Prof p(e, D3D_KC_LINEAR, 2.0 * M * (double)e->Dm * D, 4.0 * ((double)M * D + (double)e->Dm * D + (double)M * e->Dm), s, D3D_KC_LINEAR_FC1);
-        HIP_TRY(launch_fc1_x3(XP, bw.fc1_f3, bw.fc1_fb, bw.fc1_cs, w.ST2, np2, 1e-6f, bw.fc1_fe, HIDx, M, e->Dm, D, s));
+        HIP_TRY(launch_fc1_x3(XP, bw.fc1_f3, bw.fc1_fb, bw.fc1_cs, w.ST2, np2, e->ln_eps, bw.fc1_fe, HIDx, M, e->Dm, D, s));
       } else {
         HIP_TRY(gemm(XP, bw.fc1_f3, bw.fc1_fe, bw.fc1_fb, nullptr, HIDx, nullptr, 2, e->Dm, D, EPI_GELU, 0, f));
       }
@@ -475,7 +478,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     if (pn) {  // x = post_norm(x + hidden W2^T + b2) [+ Temporal_pos_embed] [+ next block's time vector], all in the fc2 epilogue
       X3Fold f{};
       f.Rp = XP;
-      f.pn.g = pn_g; f.pn.b = pn_b; f.pn.eps = 1e-6f; f.pn.pos_div = 1; f.pn.pos_mod = 1; f.pn.rows_per_batch = T * J;
+      f.pn.g = pn_g; f.pn.b = pn_b; f.pn.eps = e->ln_eps; f.pn.pos_div = 1; f.pn.pos_mod = 1; f.pn.rows_per_batch = T * J;
       if (k == 0) { f.pn.pos = e->tpos; f.pn.pos_div = J; f.pn.pos_mod = T; }
       if (!last && tvec) { f.pn.tvec = tvec + (size_t)(k + 1) * D; f.pn.tvec_stride = tvec_stride; }
       // (on the ring kernel where the template would take its persistent walk: the same tiles and values)
@@ -505,7 +508,7 @@ int run_blocks_fold(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector] -> planes + statistics (or fp32 at the end)
       LnArgs a{};
       a.x = w.HN;
-      a.g1 = pn_g; a.b1 = pn_b; a.eps1 = 1e-6f;
+      a.g1 = pn_g; a.b1 = pn_b; a.eps1 = e->ln_eps;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       if (k == 0) { a.pos = e->tpos; a.pos_div = J; a.pos_mod = T; }
       if (!last) {
@@ -554,7 +557,7 @@ int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast
   };
   {  // h = bf16(norm1_0(x))
     LnArgs a{};
-    a.x = w.X; a.h_bf16 = HNb; a.g1 = e->blk[0].n1g; a.b1 = e->blk[0].n1b; a.eps1 = 1e-6f;
+    a.x = w.X; a.h_bf16 = HNb; a.g1 = e->blk[0].n1g; a.b1 = e->blk[0].n1b; a.eps1 = e->ln_eps;
     a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
     HIP_TRY(lnorm(a));
   }
@@ -579,19 +582,19 @@ int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     if (rows) {
       {  // x += attn Wproj^T + b (fp32 stream in place); h = bf16(norm2(x)) over the attention output's rows (same tile rows: in place)
         X3PostNorm pn{};
-        pn.g2 = bw.n2g; pn.b2 = bw.n2b; pn.eps2 = 1e-6f; pn.pos_div = 1; pn.pos_mod = 1; pn.rows_per_batch = T * J;
+        pn.g2 = bw.n2g; pn.b2 = bw.n2b; pn.eps2 = e->ln_eps; pn.pos_div = 1; pn.pos_mod = 1; pn.rows_per_batch = T * J;
         HIP_TRY(linear_rows(HNb, bw.proj_x3, bw.projb, HNb, D, pn, D3D_KC_LINEAR_PROJ));
       }
       HIP_TRY(linear(HNb, bw.fc1_x3, bw.fc1b, nullptr, nullptr, HIDb, e->Dm, D, EPI_GELU, 0, D3D_KC_LINEAR_FC1));
       {  // x = post_norm(x + hidden W2^T + b2) [+ Temporal_pos_embed] [+ next block's time vector]; h = bf16(next.norm1(x))
         X3PostNorm pn{};
-        pn.g = temporal ? e->tn_g : e->sn_g; pn.b = temporal ? e->tn_b : e->sn_b; pn.eps = 1e-6f;
+        pn.g = temporal ? e->tn_g : e->sn_g; pn.b = temporal ? e->tn_b : e->sn_b; pn.eps = e->ln_eps;
         pn.pos_div = 1; pn.pos_mod = 1; pn.rows_per_batch = T * J;
         if (k == 0) { pn.pos = e->tpos; pn.pos_div = J; pn.pos_mod = T; }
         const bool last = k + 1 == e->nblk;
         if (!last) {
           if (tvec) { pn.tvec = tvec + (size_t)(k + 1) * D; pn.tvec_stride = tvec_stride; }
-          pn.g2 = e->blk[k + 1].n1g; pn.b2 = e->blk[k + 1].n1b; pn.eps2 = 1e-6f;
+          pn.g2 = e->blk[k + 1].n1g; pn.b2 = e->blk[k + 1].n1b; pn.eps2 = e->ln_eps;
         }
         HIP_TRY(linear_rows(HIDb, bw.fc2_x3, bw.fc2b, last ? nullptr : HNb, e->Dm, pn, D3D_KC_LINEAR_FC2));
       }
@@ -600,7 +603,7 @@ int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     HIP_TRY(linear(HNb, bw.proj_x3, bw.projb, w.X, w.X, nullptr, D, D, EPI_RESIDUAL, 0, D3D_KC_LINEAR_PROJ));
     {  // h = bf16(norm2(x))
       LnArgs a{};
-      a.x = w.X; a.h_bf16 = HNb; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
+      a.x = w.X; a.h_bf16 = HNb; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = e->ln_eps;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       HIP_TRY(lnorm(a));
     }
@@ -609,12 +612,12 @@ int run_blocks_bf16(d3d_engine* e, const float* x2d, const float* y, int y_bcast
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = bf16(next.norm1(x))
       LnArgs a{};
       a.x = w.X; a.y = w.X;
-      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = 1e-6f;
+      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = e->ln_eps;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       if (k == 0) { a.pos = e->tpos; a.pos_div = J; a.pos_mod = T; }
       if (k + 1 < e->nblk) {
         if (tvec) { a.tvec = tvec + (size_t)(k + 1) * D; a.tvec_stride = tvec_stride; }
-        a.h_bf16 = HNb; a.g2 = e->blk[k + 1].n1g; a.b2 = e->blk[k + 1].n1b; a.eps2 = 1e-6f;
+        a.h_bf16 = HNb; a.g2 = e->blk[k + 1].n1g; a.b2 = e->blk[k + 1].n1b; a.eps2 = e->ln_eps;
       }
       HIP_TRY(lnorm(a));
     }
@@ -660,7 +663,7 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
   };
   {  // h = norm1_0(x)
     LnArgs a{};
-    a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = e->blk[0].n1g; a.b1 = e->blk[0].n1b; a.eps1 = 1e-6f;
+    a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = e->blk[0].n1g; a.b1 = e->blk[0].n1b; a.eps1 = e->ln_eps;
     a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
     HIP_TRY(lnorm(a));
   }
@@ -690,7 +693,7 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
     HIP_TRY(linear(w.HN, HNx, bw.projw, bw.proj_x3, bw.proj_e, bw.projb, w.X, w.X, nullptr, nullptr, 0, D, D, EPI_RESIDUAL));
     {  // h = norm2(x)
       LnArgs a{};
-      a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = 1e-6f;
+      a.x = w.X; a.y = nullptr; a.h = w.HN; a.g1 = bw.n2g; a.b1 = bw.n2b; a.eps1 = e->ln_eps;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       HIP_TRY(lnorm(a));
     }
@@ -700,12 +703,12 @@ int run_blocks(d3d_engine* e, const float* x2d, const float* y, int y_bcast, con
     {  // x = post_norm(x) [+ Temporal_pos_embed before TTE0] [+ next block's time vector]; h = next.norm1(x)
       LnArgs a{};
       a.x = w.X; a.y = w.X;
-      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = 1e-6f;
+      a.g1 = temporal ? e->tn_g : e->sn_g; a.b1 = temporal ? e->tn_b : e->sn_b; a.eps1 = e->ln_eps;
       a.rows = M; a.D = D; a.rows_per_batch = T * J; a.pos_div = 1; a.pos_mod = 1;
       if (k == 0) { a.pos = e->tpos; a.pos_div = J; a.pos_mod = T; }
       if (k + 1 < e->nblk) {
         if (tvec) { a.tvec = tvec + (size_t)(k + 1) * D; a.tvec_stride = tvec_stride; }
-        a.h = w.HN; a.g2 = e->blk[k + 1].n1g; a.b2 = e->blk[k + 1].n1b; a.eps2 = 1e-6f;
+        a.h = w.HN; a.g2 = e->blk[k + 1].n1g; a.b2 = e->blk[k + 1].n1b; a.eps2 = e->ln_eps;
       }
       HIP_TRY(lnorm(a));
     }
@@ -1340,6 +1343,13 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   else if (k == "fc2_ring") e->opt_fc2_ring = value != 0;
   else if (k == "head_inject") e->opt_head_inject = value != 0;
   else if (k == "head_fence") e->opt_head_fence = value != 0;
+  else if (k == "norm_eps_bits") {
+    const uint32_t b = (uint32_t)value;
+    float v;
+    memcpy(&v, &b, 4);
+    if (!(v > 0.f) || !(v < 1.f)) return fail(D3D_EINVAL, "norm_eps_bits: the bit pattern of an eps in (0, 1)");
+    e->ln_eps = v;
+  }
   else if (k == "bf16_gemm_kernel") e->opt_bf16_gemm_kernel = value != 0;
   else if (k == "streams") {
     if (value != 1 && value != 2) return fail(D3D_EINVAL, "streams must be 1 or 2");

@@ -263,13 +263,16 @@ class Engine:
 
     def _timesteps(self, t: torch.Tensor, B: int, check: bool = True) -> torch.Tensor:
         """(B,) integer timesteps for the table gathers of q_sample / the p_losses tail, checked like the reference's `table[t]`
-        (extract, DIFF:21-24: IndexError outside the table; a short t cannot be broadcast).  Cold path: one tiny reduction."""
+        (extract, DIFF:21-24: IndexError outside the table; a ONE-entry t broadcasts over the batch as there, any other short t is refused).
+        Cold path: one tiny reduction."""
         t = t.detach().reshape(-1)
+        if t.numel() == 1 and B > 1:            # extract() reshapes to (t.shape[0], 1, 1, 1): a one-entry t broadcasts over the batch there
+            t = t.expand(B)
         if t.numel() != B:
             raise IndexError(f"timestep tensor has {t.numel()} entries for a batch of {B}")
         n = self.num_timesteps
         if B and n is not None and check:       # (check=False: t was drawn by p_losses itself -- in range by construction; the kernels
-            lo, hi = int(t.min()), int(t.max())
+            lo, hi = (int(v) for v in torch.aminmax(t))      # (ONE reduction, one read-back)
             if lo < 0 or hi >= n:
                 raise IndexError(f"timestep index out of range: [{lo}, {hi}] outside [0, {n})")   # still bound-check every gather)
         return t.to(device=self.device, dtype=torch.int32).contiguous()

@@ -29,9 +29,9 @@ class _Holder(nn.Module):
 
 
 class _AttnParams(_Holder):
-    def __init__(self, dim: int):
+    def __init__(self, dim: int, qkv_bias: bool = True):
         super().__init__()
-        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)     # S2S:67
         self.proj = nn.Linear(dim, dim)
 
 
@@ -45,11 +45,11 @@ class _MlpParams(_Holder):
 class _BlockParams(_Holder):
     """Keys: norm1, attn.{qkv,proj}, norm2, time_mlp.1, mlp.{fc1,fc2} (reference Block, S2S:90-109)."""
 
-    def __init__(self, dim: int, hidden: int, time_dim: Optional[int]):
+    def __init__(self, dim: int, hidden: int, time_dim: Optional[int], qkv_bias: bool = True, norm_eps: float = 1e-6):
         super().__init__()
-        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
-        self.attn = _AttnParams(dim)
-        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.norm1 = nn.LayerNorm(dim, eps=norm_eps)
+        self.attn = _AttnParams(dim, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=norm_eps)
         self.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_dim, dim)) if time_dim else None
         self.mlp = _MlpParams(dim, hidden)
 
@@ -78,12 +78,24 @@ class _MixSTEDenoiser(nn.Module):
                  qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None,
                  with_time_emb=True, **kwargs):
         super().__init__()
-        if not qkv_bias:
-            raise NotImplementedError("qkv_bias=False is not supported by the HIP engine (the reference runner always passes True, RUN:179)")
-        if qk_scale is not None:
-            raise NotImplementedError("qk_scale override is not supported (reference runner passes None, RUN:179)")
+        # The three arguments the runner never changes (RUN:179) but the reference accepts (S2S:140-142, 184):
+        #   qkv_bias=False   no ".attn.qkv.bias" parameters (S2S:67); the engine is handed zero vectors
+        #   qk_scale         overrides head_dim ** -0.5 (S2S:65); the engine's attention scale is fixed (it is folded into the q planes as
+        #                    a power of two), so the q rows of every qkv weight / bias are handed over multiplied by qk_scale / head_dim ** -0.5
+        #   norm_layer       a LayerNorm factory, e.g. partial(nn.LayerNorm, eps=...): its eps goes to norm1 / norm2 of every block and to
+        #                    the two post-norms (S2S:95, 101, 202, 214); anything that is not an affine nn.LayerNorm is refused
+        self._qkv_bias = bool(qkv_bias)
+        self._q_rescale = 1.0 if qk_scale is None or not qk_scale else float(qk_scale) / float((embed_dim // num_heads) ** -0.5)
+        norm_eps = 1e-6
         if norm_layer is not None:
-            raise NotImplementedError("custom norm_layer is not supported (reference default LayerNorm eps=1e-6, S2S:183)")
+            probe = norm_layer(embed_dim)
+            if not isinstance(probe, nn.LayerNorm) or not probe.elementwise_affine or tuple(probe.normalized_shape) != (embed_dim,):
+                raise NotImplementedError("norm_layer must build an affine nn.LayerNorm over the embedding (e.g. partial(nn.LayerNorm, eps=1e-5)); "
+                                          f"got {type(probe).__name__}")
+            norm_eps = float(probe.eps)
+            if not 0.0 < norm_eps < 1.0:
+                raise ValueError(f"norm_layer eps must lie in (0, 1), got {norm_eps}")
+        self._norm_eps = norm_eps
         # drop_rate / attn_drop_rate / drop_path_rate only act in training mode (S2S:123-128), which is out of scope.
         self.cfg = DenoiserConfig(num_frame=num_frame, num_joints=num_joints, in_chans=in_chans, embed_dim=embed_dim,
                                   depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio, with_time_emb=bool(with_time_emb),
@@ -96,11 +108,11 @@ class _MixSTEDenoiser(nn.Module):
         self.fusion_layer = nn.Linear(3 + in_chans, D)
         self.block_depth = depth
         self.Spatial_pos_embed = nn.Parameter(torch.zeros(1, num_joints, D))
-        self.STEblocks = nn.ModuleList([_BlockParams(D, Dm, time_dim) for _ in range(depth)])
-        self.Spatial_norm = nn.LayerNorm(D, eps=1e-6)
+        self.STEblocks = nn.ModuleList([_BlockParams(D, Dm, time_dim, qkv_bias, norm_eps) for _ in range(depth)])
+        self.Spatial_norm = nn.LayerNorm(D, eps=norm_eps)
         self.Temporal_pos_embed = nn.Parameter(torch.zeros(1, num_frame, D))
-        self.TTEblocks = nn.ModuleList([_BlockParams(D, Dm, time_dim) for _ in range(depth)])
-        self.Temporal_norm = nn.LayerNorm(D, eps=1e-6)
+        self.TTEblocks = nn.ModuleList([_BlockParams(D, Dm, time_dim, qkv_bias, norm_eps) for _ in range(depth)])
+        self.Temporal_norm = nn.LayerNorm(D, eps=norm_eps)
         if self._seq2frame:
             self.weighted_mean = nn.Conv1d(in_channels=num_frame, out_channels=1, kernel_size=1)
         self.head = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, 3))
@@ -123,7 +135,20 @@ class _MixSTEDenoiser(nn.Module):
         return obj
 
     def _named_tensors(self):
-        return {name: self._tensor(name) for name, _, _, _ in denoiser_param_spec(self.cfg)}
+        """The tensors the engine expects, by reference state-dict name: the parameters themselves, except what the constructor arguments
+        qkv_bias=False / qk_scale turn into derived tensors (zero bias vectors; q rows multiplied by qk_scale / head_dim ** -0.5)."""
+        D = self.cfg.embed_dim
+        out = {}
+        for name, _, _, _ in denoiser_param_spec(self.cfg):
+            if name.endswith(".attn.qkv.bias") and not self._qkv_bias:
+                t = torch.zeros(3 * D, dtype=torch.float32)
+            else:
+                t = self._tensor(name)
+            if self._q_rescale != 1.0 and (name.endswith(".attn.qkv.weight") or name.endswith(".attn.qkv.bias")):
+                t = t.detach().to(torch.float32).clone()
+                t[:D] *= self._q_rescale
+            out[name] = t
+        return out
 
     def _param_signature(self):
         # (over self.parameters(): 0.3 ms for the 240 tensors -- the attribute walk of _named_tensors() is 1.4 ms, per call, and shows in
@@ -165,6 +190,9 @@ class _MixSTEDenoiser(nn.Module):
         eng = engines.get(idx)
         if eng is None or eng.precision != want:
             eng = Engine(self.cfg, precision=want, device=torch.device("cuda", idx))
+            if self._norm_eps != 1e-6:
+                import struct
+                eng.set_option("norm_eps_bits", struct.unpack("<I", struct.pack("<f", self._norm_eps))[0])
             engines[idx] = eng
             sigs[idx] = None
         sig = self._src_sig if self._src_sig is not None else self._param_signature()
@@ -210,21 +238,75 @@ class _MixSTEDenoiser(nn.Module):
                           RuntimeWarning, stacklevel=4)
         return True
 
+    # tickets of one engine that a deferred block may leave open: the engine keeps 256 slots (d3d_engine_range_post recycles the oldest)
+    _MAX_OPEN_TICKETS = 192
+
+    def _lazy_read(self, eng, what: str) -> None:
+        """Guard read for an engine on which no precision flag can rise (fp32, bf16, the "auto" fallback): only the fault indicators
+        travel in its word -- the head fence's D3D_RANGE_RECOMPUTE and the bound check of the timestep gathers, D3D_RANGE_INDEX.  The
+        ticket is posted and the OPEN ones are polled without waiting, so the host does not synchronise with every call; a
+        raised bit is therefore reported at the next guarded call at the latest (the public q_sample / p_losses entry points check
+        their timesteps on the host beforehand: engine.py _timesteps)."""
+        lazy = self._guard.setdefault("lazy", [])
+        lazy.append((eng, eng.post_range(), what))
+        self._guard["posted"] += 1
+        flags, first = 0, None
+        keep = []
+        for i, (e, t, w) in enumerate(lazy):
+            # earlier calls' tickets: their work is behind this call's on the stream and long done -- waiting on them is free and makes
+            # "at the next guarded call at the latest" true; this call's own ticket is only polled
+            f = e.take_range(t, block=i + 1 < len(lazy))
+            if f is None:
+                keep.append((e, t, w))
+            elif f:
+                flags |= f
+                first = first or w
+        self._guard["lazy"] = keep
+        if flags & (_lib.RANGE_RECOMPUTE | _lib.RANGE_INDEX):
+            self._flagged(flags & (_lib.RANGE_RECOMPUTE | _lib.RANGE_INDEX), first)      # warns once / raises IndexError
+
+    def flush_range_checks(self) -> None:
+        """Read (waiting on each one's own event) every guard ticket still open from calls on an engine that is read without waiting
+        (fp32, bf16, the "auto" fallback): a fault bit raised by an earlier call is reported now instead of at the next call."""
+        lazy, self._guard["lazy"] = self._guard.get("lazy", []), []
+        flags, first = 0, None
+        for e, t, w in lazy:
+            f = e.take_range(t, block=True)
+            if f:
+                flags |= f
+                first = first or w
+        if flags & (_lib.RANGE_RECOMPUTE | _lib.RANGE_INDEX):
+            self._flagged(flags & (_lib.RANGE_RECOMPUTE | _lib.RANGE_INDEX), first)
+
     def _guarded(self, get_engine, fn, what: str):
         """Run fn(engine) on the model's engine and READ the F16X3 range guard for it (no device-wide synchronisation: one one-lane
         kernel behind the call, one wait on ITS event).  get_engine(fallback) -> a ready engine.  With an open deferred list
-        (deferred_range_checks(): evaluate() resolves it at its own per-batch synchronisation) the read is postponed."""
+        (deferred_range_checks(): evaluate() resolves it at its own per-batch synchronisation) the read is postponed.  Engines on which
+        no precision flag can rise (fp32, bf16, the fallback) are read without waiting (_lazy_read)."""
+        fb_sig = self._guard["fallback"]
+        if fb_sig is not None and fb_sig != self._weights_sig():      # new weights: back to the F16X3 engine, and a new fallback warns again
+            self._guard["fallback"] = None
+            self._guard["warned"] = False
         if self._on_fallback():
-            return fn(get_engine(True))
+            eng = get_engine(True)
+            res = fn(eng)
+            if self.range_check:
+                self._lazy_read(eng, what)
+            return res
         eng = get_engine(False)
         res = fn(eng)
         if not self.range_check:
+            return res
+        if eng.precision != "f16x3":
+            self._lazy_read(eng, what)
             return res
         ticket = eng.post_range()
         self._guard["posted"] += 1
         pend = self._guard["deferred"]
         if pend is not None:
             pend.append((eng, ticket, what))
+            if len(pend) >= self._MAX_OPEN_TICKETS:      # the engine's ticket ring is finite: fold the oldest half into the box now
+                self._guard["deferred_box"].fold(len(pend) // 2)
             return res
         flags = eng.take_range(ticket, block=True)
         if not flags:
@@ -232,6 +314,10 @@ class _MixSTEDenoiser(nn.Module):
         if not self._flagged(flags, what):      # raises unless "auto"
             return res
         self._guard["reruns"] += 1
+        if self._guard["fallback"] is not None:
+            # the F16X3 engine's workspace (34 GB at B = 512, T = 243) is dead weight while the model runs on the fp32 engine: release it so
+            # that the repeat -- which allocates the fp32 engine's own -- does not double the peak; it comes back lazily
+            eng._ws, eng._ws_B = None, 0
         return fn(get_engine(True))
 
     @contextmanager
@@ -239,13 +325,13 @@ class _MixSTEDenoiser(nn.Module):
         """Inside: guarded calls only POST their range tickets.  The yielded object's resolve() -- call it behind a synchronisation
         the caller makes anyway -- reads them all: False = every call was in range; True = precision="auto" has moved the model to
         its fp32 engine and the caller must repeat the work of the block; other precisions raise D3DError."""
-        outer = self._guard["deferred"]
+        outer, outer_box = self._guard["deferred"], self._guard.get("deferred_box")
         box = _Deferred(self)
-        self._guard["deferred"] = box.items
+        self._guard["deferred"], self._guard["deferred_box"] = box.items, box
         try:
             yield box
         finally:
-            self._guard["deferred"] = outer
+            self._guard["deferred"], self._guard["deferred_box"] = outer, outer_box
 
     def _compute_device(self, *tensors) -> torch.device:
         for t in tensors:
@@ -278,9 +364,21 @@ class _Deferred:
     def __init__(self, net: _MixSTEDenoiser):
         self.net = net
         self.items = []
+        self._flags, self._what = 0, None      # what fold() has already read
+
+    def fold(self, n: int) -> None:
+        """Read the n oldest tickets now (blocking on each one's own event) and remember their flags: an engine keeps a finite ring of
+        ticket slots, a block with more guarded calls than that must not let the oldest expire."""
+        for eng, ticket, w in self.items[:n]:
+            f = eng.take_range(ticket, block=True)
+            if f:
+                self._flags |= f
+                self._what = self._what or w
+        del self.items[:n]
 
     def resolve(self) -> bool:
-        flags, what = 0, None
+        flags, what = self._flags, self._what
+        self._flags, self._what = 0, None
         for eng, ticket, w in self.items:
             f = eng.take_range(ticket, block=True)
             if f:

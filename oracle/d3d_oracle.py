@@ -160,21 +160,23 @@ def time_trunk(sd: Dict[str, Tensor], time: Tensor, D: int) -> Tensor:
     return F.linear(h, sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
 
 
-def grand_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int) -> Tensor:
-    """S2S:73-86. x: (G, N, C). (softmax(q k^T * scale) - I) v, then proj. Identity is materialised as in the reference."""
+def grand_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int, qk_scale: Optional[float] = None) -> Tensor:
+    """S2S:73-86. x: (G, N, C). (softmax(q k^T * scale) - I) v, then proj. Identity is materialised as in the reference.
+    scale = qk_scale or head_dim ** -0.5 (S2S:65); a layer built with qkv_bias=False has no ".qkv.bias" entry (S2S:67)."""
     G, N, C = x.shape
     dh = C // heads
     qkv = _block_linear(x, sd[p + ".qkv.weight"], sd.get(p + ".qkv.bias")).reshape(G, N, 3, heads, dh).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    a = (_rnd(q) @ _rnd(k).transpose(-2, -1)) * (dh ** -0.5)
+    a = (_rnd(q) @ _rnd(k).transpose(-2, -1)) * (qk_scale or dh ** -0.5)
     a = a.softmax(dim=-1)
     eye = torch.eye(N, dtype=a.dtype).view(1, 1, N, N).repeat(G, heads, 1, 1)
     o = (_rnd(a - eye) @ _rnd(v)).transpose(1, 2).reshape(G, N, C)
     return _block_linear(o, sd[p + ".proj.weight"], sd[p + ".proj.bias"])
 
 
-def mixste_block(sd: Dict[str, Tensor], p: str, x: Tensor, spatial: bool, temb: Optional[Tensor], heads: int) -> Tensor:
-    """S2S:111-135 (eval branch). x: (b, f, j, c)."""
+def mixste_block(sd: Dict[str, Tensor], p: str, x: Tensor, spatial: bool, temb: Optional[Tensor], heads: int,
+                 qk_scale: Optional[float] = None, norm_eps: float = 1e-6) -> Tensor:
+    """S2S:111-135 (eval branch). x: (b, f, j, c).  norm_eps: the eps of the constructor's norm_layer (S2S:184: 1e-6 by default)."""
     b, f, j, c = x.shape
     if temb is not None and (p + ".time_mlp.1.weight") in sd:
         te = F.linear(F.silu(temb), sd[p + ".time_mlp.1.weight"], sd[p + ".time_mlp.1.bias"])
@@ -183,9 +185,9 @@ def mixste_block(sd: Dict[str, Tensor], p: str, x: Tensor, spatial: bool, temb: 
         x = x.reshape(b * f, j, c)
     else:
         x = x.permute(0, 2, 1, 3).reshape(b * j, f, c)  # real transpose copy, as einops does
-    h = F.layer_norm(x, (c,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6)
-    x = x + grand_attention(sd, p + ".attn", h, heads)
-    h = F.layer_norm(x, (c,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-6)
+    h = F.layer_norm(x, (c,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], norm_eps)
+    x = x + grand_attention(sd, p + ".attn", h, heads, qk_scale)
+    h = F.layer_norm(x, (c,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], norm_eps)
     h = _block_linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])
     h = F.gelu(h)
     h = _block_linear(h, sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
@@ -196,7 +198,7 @@ def mixste_block(sd: Dict[str, Tensor], p: str, x: Tensor, spatial: bool, temb: 
 
 
 def forward_denoise(sd: Dict[str, Tensor], x_cat: Tensor, time: Tensor, *, depth: int, heads: int = 8,
-                    seq2frame: bool = False) -> Tensor:
+                    seq2frame: bool = False, qk_scale: Optional[float] = None, norm_eps: float = 1e-6) -> Tensor:
     """S2S:249-257 / S2F:253-266. x_cat (B,T,J,in+3), time (B,) -> (B,T,J,3) [(B,1,J,3) for seq2frame].
 
     ``sd`` holds the denoiser tensors without the 'model.' prefix.
@@ -208,13 +210,13 @@ def forward_denoise(sd: Dict[str, Tensor], x_cat: Tensor, time: Tensor, *, depth
     for i in range(depth):
         if i == 0:
             x = (x.reshape(b * f, j, D) + sd["Spatial_pos_embed"]).reshape(b, f, j, D)
-        x = mixste_block(sd, f"STEblocks.{i}", x, True, temb, heads)
-        x = F.layer_norm(x, (D,), sd["Spatial_norm.weight"], sd["Spatial_norm.bias"], 1e-6)
+        x = mixste_block(sd, f"STEblocks.{i}", x, True, temb, heads, qk_scale, norm_eps)
+        x = F.layer_norm(x, (D,), sd["Spatial_norm.weight"], sd["Spatial_norm.bias"], norm_eps)
         if i == 0:
             xt = x.permute(0, 2, 1, 3).reshape(b * j, f, D) + sd["Temporal_pos_embed"]
             x = xt.reshape(b, j, f, D).permute(0, 2, 1, 3).contiguous()
-        x = mixste_block(sd, f"TTEblocks.{i}", x, False, temb, heads)
-        x = F.layer_norm(x, (D,), sd["Temporal_norm.weight"], sd["Temporal_norm.bias"], 1e-6)
+        x = mixste_block(sd, f"TTEblocks.{i}", x, False, temb, heads, qk_scale, norm_eps)
+        x = F.layer_norm(x, (D,), sd["Temporal_norm.weight"], sd["Temporal_norm.bias"], norm_eps)
     if seq2frame:
         # S2F:261-263: Conv1d(T->1, k=1) over view(b, f, J*D)
         x = F.conv1d(x.reshape(b, f, j * D), sd["weighted_mean.weight"], sd["weighted_mean.bias"]).reshape(b, 1, j, D)

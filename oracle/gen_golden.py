@@ -519,6 +519,34 @@ def gen_round4():
     save("ddim_s2f_notemb_T27_S7", seed=np.int32(6), input_seed=np.int32(700), B=np.int32(3), S=np.int32(7), y0=y0.numpy())
 
 
+def gen_round6():
+    """The three constructor arguments the engine used to refuse (S2S:140-142, 184): qkv_bias=False, a qk_scale
+    override, and a norm_layer with another eps -- raw denoiser outputs of the imported reference at T = 27, full width, depth 2."""
+    from functools import partial
+    cfg = DenoiserConfig(num_frame=27, embed_dim=512, depth=2)
+    inp = synth_inputs(2, 27, seed=900)
+    xcat = torch.cat([torch.from_numpy(inp["x2d"]), torch.from_numpy(inp["noise"]) * 0.7], dim=-1)
+    out = {}
+    for tag, kw, okw in (("nobias", dict(qkv_bias=False), {}), ("qkscale", dict(qk_scale=0.2), dict(qk_scale=0.2)),
+                         ("eps", dict(norm_layer=partial(nn.LayerNorm, eps=1e-3)), dict(norm_eps=1e-3))):
+        args = dict(num_frame=27, num_joints=17, in_chans=2, embed_dim=512, depth=2, num_heads=8, mlp_ratio=2., qkv_bias=True, qk_scale=None,
+                    drop_path_rate=0.1, with_time_emb=True)
+        args.update(kw)
+        net = HPE_model(S2S_NAME)(**args).eval()
+        sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 13, family="trainedlike" if tag == "eps" else "uniform").items()}
+        if tag == "nobias":
+            sd = {k: v for k, v in sd.items() if not k.endswith("attn.qkv.bias")}
+        net.load_state_dict(sd, strict=True)
+        for t in (999, 17):
+            tv = torch.full((2,), t, dtype=torch.long)
+            with torch.no_grad():
+                r = net.forward_denoise(xcat, tv)
+            check(f"ctor {tag} t={t}", orc.forward_denoise(sd, xcat, tv, depth=2, **okw), r)
+            out[f"{tag}_t{t}"] = r.numpy()
+    save("denoise_ctor_args_T27", seed=np.int32(13), input_seed=np.int32(900), B=np.int32(2), y_scale=np.float32(0.7), qk_scale=np.float32(0.2),
+         norm_eps=np.float32(1e-3), **out)
+
+
 def gen_round5():
     """BASELINE configs[4] (MPI-INF-3DHP, T=27, seq2frame) end to end, from the reference itself:
       chunks_s2f        window tables of ChunkedGenerator_3dhp (out_all False, stride 1; out_all True with `valid` flags)
@@ -692,7 +720,7 @@ def gen_round5b():
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
-    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5, "round5b": gen_round5b,
+    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5, "round5b": gen_round5b, "round6": gen_round6,
 }
 
 if __name__ == "__main__":

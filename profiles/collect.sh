@@ -36,7 +36,11 @@ done
 python3 profiles/summarize.py traffic profiles/${tag}_pmc.json profiles/hbm_traffic.json $T $B $prec > /dev/null || true
 python3 - <<PY
 import json, time
-p = "profiles/hbm_traffic.json"; d = json.load(open(p)); d["_collected"] = "${tag}, " + time.strftime("%Y-%m-%d"); json.dump(d, open(p, "w"), indent=1)
+import hashlib
+p = "profiles/hbm_traffic.json"; d = json.load(open(p)); d["_collected"] = "${tag}, " + time.strftime("%Y-%m-%d")
+# the library these bytes were counted with, per workload: bench.py prints roofline.traffic_stale when the running library differs
+d.setdefault("_lib_sha256", {})["T${T}:B${B}:${prec}"] = hashlib.sha256(open("diff3dhpe_amd/libd3d_hip.so", "rb").read()).hexdigest()
+json.dump(d, open(p, "w"), indent=1)
 PY
 # one reviewable table per tag: launch time x algorithmic work x counters (add the sustained MFMA rate of bench.py's machine_probes by hand:
 #   python3 profiles/roofline_table.py $tag $T $B $prec <TFLOP/s>)

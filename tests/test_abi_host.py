@@ -146,6 +146,34 @@ def test_registry_and_ctor_surface():
         d3d.GaussianDiffusion(model=torch.nn.Linear(2, 2))
 
 
+def test_ctor_accepts_the_arguments_the_reference_accepts():
+    """S2S:140-142, 184: qkv_bias=False (no qkv bias parameters: S2S:67), a qk_scale override (S2S:65) and a LayerNorm factory with
+    another eps are constructor arguments of the reference; the module mirrors their effect on the parameter set and hands the engine
+    derived tensors (zero bias vectors, rescaled q rows).  Anything that is not an affine LayerNorm over the embedding is refused."""
+    from functools import partial
+    kw = dict(num_frame=9, embed_dim=64, depth=1, num_heads=8)
+    plain = d3d.HPE_model(d3d.S2S_NAME)(**kw)
+    nb = d3d.HPE_model(d3d.S2S_NAME)(qkv_bias=False, **kw)
+    assert {k for k in plain.state_dict()} - {k for k in nb.state_dict()} == {"STEblocks.0.attn.qkv.bias", "TTEblocks.0.attn.qkv.bias"}
+    t = nb._named_tensors()
+    assert t["STEblocks.0.attn.qkv.bias"].shape == (192,) and not t["STEblocks.0.attn.qkv.bias"].any()
+    qs = d3d.HPE_model(d3d.S2S_NAME)(qk_scale=0.25, **kw)                 # head_dim 8: default scale 8 ** -0.5
+    qs.load_state_dict(plain.state_dict())
+    r = 0.25 / 8 ** -0.5
+    a, b = qs._named_tensors(), plain._named_tensors()
+    assert torch.equal(a["TTEblocks.0.attn.qkv.weight"][:64], b["TTEblocks.0.attn.qkv.weight"][:64] * r)
+    assert torch.equal(a["TTEblocks.0.attn.qkv.weight"][64:], b["TTEblocks.0.attn.qkv.weight"][64:])
+    assert torch.equal(a["TTEblocks.0.attn.qkv.bias"][:64], b["TTEblocks.0.attn.qkv.bias"][:64] * r)
+    assert torch.equal(qs.STEblocks[0].attn.qkv.weight, plain.STEblocks[0].attn.qkv.weight)        # the parameters themselves are untouched
+    ne = d3d.HPE_model(d3d.S2S_NAME)(norm_layer=partial(torch.nn.LayerNorm, eps=1e-3), **kw)
+    assert ne.Spatial_norm.eps == ne.Temporal_norm.eps == ne.STEblocks[0].norm1.eps == ne.TTEblocks[0].norm2.eps == 1e-3
+    assert ne.head[0].eps == 1e-5 and plain.Spatial_norm.eps == 1e-6                              # the head's LayerNorm is not norm_layer (S2S:218)
+    with pytest.raises(NotImplementedError):
+        d3d.HPE_model(d3d.S2S_NAME)(norm_layer=torch.nn.BatchNorm1d, **kw)
+    with pytest.raises(NotImplementedError):
+        d3d.HPE_model(d3d.S2S_NAME)(norm_layer=partial(torch.nn.LayerNorm, elementwise_affine=False), **kw)
+
+
 def test_state_dict_layout_and_checkpoint_loading():
     cfg = DenoiserConfig(num_frame=27, embed_dim=32, depth=2)
     net = d3d.HPE_model(d3d.S2S_NAME)(num_frame=27, embed_dim=32, depth=2)

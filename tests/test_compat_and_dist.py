@@ -171,3 +171,21 @@ def test_bench_host_side_helpers():
     assert one["equal_to_single_process"] and one["processes"] == 1 and one["value"] is None
     two = bench.cpu_baseline_concurrent(9, 3, 0, 1, 2, 0.1, run_s=0.5, quota=None)   # two 1-thread oracle workers, T = 9
     assert two.get("processes") == 2 and two["value"] and two["steps_finished"] >= 2, two
+
+
+def test_bench_self_launch_watchdog_names_a_rank_that_never_finishes_its_first_sampling():
+    """a rank that has not finished a first sampling `D3D_BENCH_STARTUP_TIMEOUT_S` after the start (a hung
+    rendezvous, a device that does not come up) is NAMED, every rank is ended and the launcher exits non-zero -- it does not sit until the
+    harness's own limit.  Launch-check mode: rank 1 sleeps before it reports ready, the others report and then wait."""
+    import time
+    t0 = time.time()
+    run = _bench(["--gpus", "3"], {"D3D_BENCH_LAUNCH_CHECK": "1", "D3D_BENCH_LAUNCH_CHECK_HANG": "1", "D3D_BENCH_STARTUP_TIMEOUT_S": "3"})
+    assert run.returncode == 124, (run.returncode, run.stderr)
+    assert "rank(s) [1] had not finished a first sampling" in run.stderr and "ending all ranks" in run.stderr
+    assert time.time() - t0 < 25
+
+
+def test_bench_self_launch_watchdog_is_quiet_when_every_rank_reports():
+    """All ranks report their first sampling: the watchdog never fires even with a tiny limit once they have all reported."""
+    run = _bench(["--gpus", "2"], {"D3D_BENCH_LAUNCH_CHECK": "1", "D3D_BENCH_STARTUP_TIMEOUT_S": "30"})
+    assert run.returncode == 0 and "had not finished" not in run.stderr, run.stderr
