@@ -15,6 +15,9 @@ __device__ __forceinline__ f2 splat2(float a) { return (f2)(a); }
 // issues MFMAs next to LDS-DMA.  With the pair opaque there is nothing to fold; tests/test_abi_host.py pins the absence of that form
 // in every kernel of the library.
 __device__ __forceinline__ f2 splat2_rt(float a) {
+#ifdef D3D_EXP_PLAIN_SPLAT   // (A/B of what the opaque pair costs: experiments/build_variant.sh plain "-DD3D_EXP_PLAIN_SPLAT")
+  return (f2)(a);
+#endif
   f2 r;
   r.x = a; r.y = a;
   asm volatile("" : "+v"(r));
