@@ -87,10 +87,21 @@ struct R2Args {
   unsigned long long* diag;   // nullable: per workgroup {k-loop cycles, epilogue cycles, tiles, poll spins} of wave 0 / wave 4
 };
 
-// -DR2_STAMPS builds (experiments/build_variant.sh): shader-clock stamps inside every k-tile of waves 0 and 4 -- cycles from the k-tile's
+// The product build carries no debugging path: -DR2_DEBUG builds (experiments/build_variant.sh ringdbg "-DR2_DEBUG" kernels_fc2_ring)
+// enable the "fc2_ring_dbg" bits (1 workgroup barrier at every k-tile top, 2 at every tile end, 4 in the epilogue hook, 8 W(0) of the next
+// tile issued behind the epilogue, 16 / 32 no W / A pieces, 64 no counters: timing probes with wrong results, 512 static priority for waves
+// 4-7) and the "fc2_ring_diag" stamps (experiments/fc2_ring_op.py).
+#ifdef R2_DEBUG
+#define R2_DBG(BIT) ((a.dbg & (BIT)) != 0)
+#define R2_DIAG (a.diag != nullptr)
+#else
+#define R2_DBG(BIT) false
+#define R2_DIAG false
+#endif
+// -DR2_STAMPS builds (with -DR2_DEBUG): shader-clock stamps inside every k-tile of waves 0 and 4 -- cycles from the k-tile's
 // top to: the own pieces landed (vmcnt), the A slot complete (poll), the first MFMA group done, the signal, the end.
 #ifdef R2_STAMPS
-#define R2_STAMP(I) do { if (a.diag) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[I] += t_ - tprev; tprev = t_; } } while (0)
+#define R2_STAMP(I) do { if (R2_DIAG) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[I] += t_ - tprev; tprev = t_; } } while (0)
 #else
 #define R2_STAMP(I) do { } while (0)
 #endif
@@ -150,13 +161,13 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
     const int mt = b + item * G, mtn = mt + G;
     const int m0 = mt * R2_BM;
     unsigned long long st0 = 0;
-    if (a.diag) st0 = __builtin_amdgcn_s_memtime();
+    if (R2_DIAG) st0 = __builtin_amdgcn_s_memtime();
 #ifdef R2_STAMPS
     tprev = st0;
 #endif
 
     if (wave >= 4) for (int i = 0; i < a.delay; ++i) __builtin_amdgcn_s_sleep(1);
-    if ((a.dbg & 512) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (R2_DBG(512) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     const int lr = lane >> 3, c8 = lane & 7;
     unsigned lofs_e = (unsigned)(lr * (int)rowb + ((c8 ^ (lr >> 1)) << 4));
@@ -196,11 +207,11 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
         bh[j] = *reinterpret_cast<const h8*>(lds + boff + j * 2048);                                                    \
         bl[j] = *reinterpret_cast<const h8*>(lds + ((boff + j * 2048) ^ 64));                                           \
       }                                                                                                                 \
-      if (!(a.dbg & 64)) {                                                                                              \
+      if (!R2_DBG(64)) {                                                                                              \
         const unsigned n_ = (unsigned)__builtin_amdgcn_readfirstlane(                                                  \
             (int)lds_poll_ge(cnt + 4u * (T & 3u), 8u * ((T >> 2) + 1u), R2_POLL_LIMIT));                                \
         tmo |= n_ >= R2_POLL_LIMIT ? 1u : 0u;                                                                           \
-        if (a.diag) dg_s += n_;                                                                                         \
+        if (R2_DIAG) dg_s += n_;                                                                                         \
       }                                                                                                                 \
       R2_STAMP(1);                                                                                                      \
       asm volatile("" : "+v"(lofs_e) : : "memory");                                                                     \
@@ -219,24 +230,23 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
       const unsigned char* const sa = lds + R2_A + (int)(T & 3u) * R2_ASLOT;                                            \
       unsigned cv_ = 0;                                                                                                 \
       _Pragma("unroll") for (int g = 0; g < R2_TM; ++g) {                                                               \
-        if ((PREF) && g == R2_TM - 2 && !(a.dbg & 64))   /* the next slot's counter, read a group ahead of its use */    \
+        if ((PREF) && g == R2_TM - 2 && !R2_DBG(64))   /* the next slot's counter, read a group ahead of its use */    \
           asm volatile("ds_read_b32 %0, %1" : "=v"(cv_) : "v"(cnt + 4u * ((T + 1u) & 3u)) : "memory");                  \
         if ((PREF) && g == R2_TM - 1) {                                                                                 \
           R2_STAMP(4);                                                                                                  \
           if (STEADY) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   /* my W(T+1) (the two A pieces behind it stay in flight); the counter word; this group's A pair */ \
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
           R2_STAMP(0);                                                                                                  \
-          if (!(a.dbg & 64)) {                                                                                          \
+          if (!R2_DBG(64)) {                                                                                          \
             const unsigned tgt_ = 8u * (((T + 1u) >> 2) + 1u);                                                          \
             unsigned n_ = 0;                                                                                            \
             if ((unsigned)__builtin_amdgcn_readfirstlane((int)cv_) < tgt_) {                                            \
               n_ = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_poll_ge(cnt + 4u * ((T + 1u) & 3u), tgt_, R2_POLL_LIMIT)); \
               tmo |= n_ >= R2_POLL_LIMIT ? 1u : 0u;                                                                     \
             }                                                                                                           \
-            if (a.dbg & 256) {   /* the wave that did not have to wait is the one behind: it gets the matrix pipe first */ \
-              if (n_ == 0u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);                           \
-            }                                                                                                           \
-            if (a.diag) dg_s += n_;                                                                                     \
+            /* the wave that did not have to wait is the one behind: it gets the matrix pipe first */                    \
+            if (n_ == 0u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);                             \
+            if (R2_DIAG) dg_s += n_;                                                                                     \
           }                                                                                                             \
           R2_STAMP(1);                                                                                                  \
           asm volatile("" : "+v"(lofs_e) : : "memory");                                                                 \
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
         if (g == R2_SIG) {   /* "my pieces of A(T+1) have landed": everything older than this k-tile's 8 W pieces */          \
           if (STEADY) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
-          if (!(a.dbg & 64)) lds_signal(cnt + 4u * ((T + 1u) & 3u), lane);                                              \
+          if (!R2_DBG(64)) lds_signal(cnt + 4u * ((T + 1u) & 3u), lane);                                              \
           __builtin_amdgcn_sched_barrier(0);                                                                            \
           R2_STAMP(3);                                                                                                  \
         }                                                                                                               \
@@ -298,8 +308,8 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
 
     int kt = 0;
     R2_OPEN();
-    if (a.dbg & 48) {   // timing probes (wrong results): 16 no W pieces, 32 no A pieces in the steady state
-      const bool pa = !(a.dbg & 32), pw = !(a.dbg & 16);
+    if (R2_DBG(48)) {   // timing probes (wrong results): 16 no W pieces, 32 no A pieces in the steady state
+      const bool pa = !R2_DBG(32), pw = !R2_DBG(16);
       for (; kt + 2 < nk; ++kt) R2_KTILE(kt, ubA + (size_t)(kt + 2) * 128, pa, pw, false, true);
     }
     for (; kt + 2 < nk; ++kt) R2_KTILE(kt, ubA + (size_t)(kt + 2) * 128, true, true, true, true);
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
 #undef R2_APIECE
 
     unsigned long long st1 = 0;
-    if (a.diag) { st1 = __builtin_amdgcn_s_memtime(); dg_k += st1 - st0; }
+    if (R2_DIAG) { st1 = __builtin_amdgcn_s_memtime(); dg_k += st1 - st0; }
     {
       const int nt0 = wave * 64;
       const size_t tbase = (size_t)m0 * a.N + nt0;
@@ -321,8 +331,8 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
       _Float16* const Cht = a.Ch ? a.Ch + 2 * tbase : nullptr;
       const _Float16* const Rpt = a.tail.Rp + 2 * tbase;
       auto refill = [&]() {   // W(0) of the next tile (the same rows again), behind the last read of the patches
-        if (a.dbg & 4) __syncthreads();
-        if (has_next && !(a.dbg & 8)) {
+        if (R2_DBG(4)) __syncthreads();
+        if (has_next && !R2_DBG(8)) {
 #pragma unroll
           for (int p = 0; p < 8; ++p) R2_WPIECE(0, p);
         }
@@ -331,9 +341,9 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
                                                       refill);
     }
 #undef R2_WPIECE
-    if (a.diag) dg_e += __builtin_amdgcn_s_memtime() - st1;
-    if (a.dbg & 2) __syncthreads();
-    if ((a.dbg & 8) && has_next) {   // the next tile's W(0) only now
+    if (R2_DIAG) dg_e += __builtin_amdgcn_s_memtime() - st1;
+    if (R2_DBG(2)) __syncthreads();
+    if (R2_DBG(8) && has_next) {   // the next tile's W(0) only now
       const int lane = tid_o & 63;
       const int wave = __builtin_amdgcn_readfirstlane(tid_o >> 6);
       const int lr = lane >> 3, c8 = lane & 7;
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
     }
   }
   if (tmo) range_raise(a.tail.range, RANGE_BIT_RING_TIMEOUT);
-  if (a.diag && (threadIdx.x == 0 || threadIdx.x == 256)) {
+  if (R2_DIAG && (threadIdx.x == 0 || threadIdx.x == 256)) {
     unsigned long long* d = a.diag + 8 * b + (threadIdx.x ? 4 : 0);
     d[0] = dg_k; d[1] = dg_e; d[2] = (unsigned long long)nitems; d[3] = dg_s;
 #ifdef R2_STAMPS
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
 
 bool fc2_ring_ok(int N, int K) { return N == 512 && K % 128 == 0 && K >= 256; }
 
-static std::atomic<int> g_r2_delay{24}, g_r2_dbg{256};
+static std::atomic<int> g_r2_delay{24}, g_r2_dbg{0};
 void set_fc2_ring_dbg(int d) { g_r2_dbg = d; }
 static std::atomic<unsigned long long*> g_r2_diag{nullptr};
 void set_fc2_ring_delay(int d) { g_r2_delay = d < 0 ? 0 : (d > 4096 ? 4096 : d); }
