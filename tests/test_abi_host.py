@@ -268,8 +268,8 @@ def test_no_kernel_uses_the_packed_fp32_form_that_deviates_beside_mfma():
     """gfx950 deviation found in round 6 (experiments/probes/pk_beside_mfma*.hip; experiments/NOTES.md section 000): a
     v_pk_{add,mul,fma}_f32 whose SRC1 low half selects the HIGH dword of its register pair -- `op_sel:[x,1]` / `op_sel:[x,1,y]`, what the
     compiler emits when it folds the broadcast of a value that sits in an odd register -- now and then computes the low result of lanes
-    48-63 with src1 = 0 while the other wave of its SIMD issues MFMAs (2e-8 per wave-instruction in the probe, 1e-5 in a de-phased GEMM
-    epilogue).  It is what made k_head deviate on a GPU shared by two processes (rounds 1-2).  No kernel of the library may contain it:
+    48-63 with src1 = 0 while the other wave of its SIMD STARTS issuing MFMAs after the matrix pipe has been idle (1.5e-5 per
+    wave-instruction beside MFMA bursts in the probe and in a de-phased GEMM epilogue; a continuous MFMA stream only hits at its start).  It is what made k_head deviate on a GPU shared by two processes (rounds 1-2).  No kernel of the library may contain it:
     run-time scalars meet packed arithmetic through splat2_rt (x3q_epilogue_acc.h), the row kernels are built without the SLP
     vectoriser (build.py EXTRA_FLAGS)."""
     import re
