@@ -156,11 +156,16 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *                     row 0 -- the fence must repair the row (result unchanged) and raise D3D_RANGE_RECOMPUTE
  *   "fc2_ring"        0 (default) / 1: fc2 + post-norm on the k-loop without workgroup barriers (kernels_fc2_ring.hip: wave-private W
  *                     slots, A through a ring with arrival counters in LDS); bit-identical; measured level with the token GEMM's form
+ *   "norm_eps_bits"   the bit pattern of the float eps of the constructor's norm_layer (S2S:184; default 1e-6): norm1 / norm2 of every block
+ *                     and the two post-norms; the head's LayerNorm keeps 1e-5 (S2S:218).  The Python classes set it from
+ *                     norm_layer=partial(nn.LayerNorm, eps=...)
  *   "streams"         2 (default) / 1: d3d_ddim_sample runs a batch of B >= 2 as two half-batches on two HIP streams (the caller's and
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
  *                     +2.9 % at T=243 / B=64, neutral at T=81 / T=27).  Per-kernel profiling and the trace force one stream.
- * Process-wide diagnostics (e may be NULL): "gemm_diag", "attn_diag" 0 / 1: the op hooks print in-kernel stamp reports to stderr
+ * Process-wide diagnostics (e may be NULL): "gemm_diag", "attn_diag" 0 / 1: the op hooks print in-kernel stamp reports to stderr;
+ * "fc2_ring_delay" (waves 4-7 of the ring kernel start each tile that many x 64 cycles late; default 24), "fc2_ring_op" 0 / 1
+ * (d3d_op_linear_postnorm through the ring kernel), "fc2_ring_dbg" / "fc2_ring_diag" (builds with -DR2_DEBUG only: experiments/fc2_ring_op.py)
  * (attn_diag needs a -DD3D_ATTN_DIAG_BUILD library); "qs_diag" / "qt_diag" 0 / 1: every 50th launch of the fused spatial / fused temporal kernel
  * runs with per-step stamps and prints their summary to stderr (that launch synchronises its stream; launches inside a hipGraph capture
  * are never stamped).  The diagnostic switches are PROCESS-wide: they act on every engine.  Unknown key: D3D_EINVAL. */

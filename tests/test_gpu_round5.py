@@ -403,9 +403,10 @@ def test_evaluate_sequence_seq2frame_equals_the_batched_route():
 # ------------------------------------------------------------------------------------------------ the head kernel's run-time fence
 @pytest.mark.parametrize("prec", ["f16x3", "fp32", "auto"])
 def test_head_kernel_recompute_fence(prec):
-    """k_head forms every row's three dot products TWICE from independently loaded weight fragments and compares them bit for bit (the
-    one run-to-run deviation this library ever showed -- a wrong o[0] in ~1 launch of 60 beside a second process, with a schedule that is
-    pinned out at build time; mechanism unidentified -- would show exactly there).  "head_inject" perturbs the FIRST evaluation of row 0:
+    """With "head_fence" on (round 5's default; an option since round 6) k_head forms every row's three dot products TWICE from
+    independently loaded weight fragments and compares them bit for bit (the one run-to-run deviation this library ever showed -- a wrong
+    o[0] in ~1 launch of 60 beside a second process -- would show exactly there; round 6 identified it: a packed fp32 instruction form
+    beside another wave's MFMAs, pinned out of every kernel at build time).  "head_inject" perturbs the FIRST evaluation of row 0:
     the kernel must repair the row by its third evaluation (results unchanged, whole sampling), raise D3D_RANGE_RECOMPUTE in EVERY
     precision, and the Python layer must report it once without raising or changing engines."""
     cfg = cfg_full(27)
