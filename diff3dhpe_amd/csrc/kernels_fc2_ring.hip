@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
   unsigned tmo = 0;                                    // a poll gave up: the launch is flagged (its results are wrong)
   unsigned long long dg_k = 0, dg_e = 0;
 #ifdef R2_STAMPS
-  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+  unsigned long long seg[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #endif
   unsigned dg_s = 0;
 
@@ -331,6 +331,9 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
       _Float16* const Cht = a.Ch ? a.Ch + 2 * tbase : nullptr;
       const _Float16* const Rpt = a.tail.Rp + 2 * tbase;
       auto refill = [&]() {   // W(0) of the next tile (the same rows again), behind the last read of the patches
+#ifdef R2_STAMPS
+        if (R2_DIAG) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[6] += t_ - st1; }   // sweep 1 of the epilogue
+#endif
         if (R2_DBG(4)) __syncthreads();
         if (has_next && !R2_DBG(8)) {
 #pragma unroll
@@ -359,8 +362,8 @@ __global__ __launch_bounds__(512) void k_fc2_ring(R2Args a) {
     unsigned long long* d = a.diag + 8 * b + (threadIdx.x ? 4 : 0);
     d[0] = dg_k; d[1] = dg_e; d[2] = (unsigned long long)nitems; d[3] = dg_s;
 #ifdef R2_STAMPS
-    unsigned long long* e = a.diag + 8 * gridDim.x + 12 * b + (threadIdx.x ? 6 : 0);
-    for (int i = 0; i < 6; ++i) e[i] = seg[i];
+    unsigned long long* e = a.diag + 8 * gridDim.x + 14 * b + (threadIdx.x ? 7 : 0);
+    for (int i = 0; i < 7; ++i) e[i] = seg[i];
 #endif
   }
 }

@@ -6,8 +6,8 @@ import torch
 sys.path[:0] = ["."]
 from diff3dhpe_amd import engine as E, _lib
 
-M, delay, dbg, reps = (int(x) for x in (sys.argv[1:5] + ["264384", "24", "0", "20"][len(sys.argv) - 1:]))
-K, N = 1024, 512
+M, delay, dbg, reps, K = (int(x) for x in (sys.argv[1:6] + ["264384", "24", "0", "20", "1024"][len(sys.argv) - 1:]))
+N = 512
 g = torch.Generator().manual_seed(3)
 A = torch.randn(M, K, generator=g).cuda() * 0.5
 W = (torch.rand(N, K, generator=g).cuda() - 0.5) * (2.0 / 32.0)
@@ -25,7 +25,7 @@ for r in range(3):
     tiles = torch.unique(bad.nonzero().flatten() // 128)
     d = (out - ref).abs().max().item()
     info = [(int(t) % 256, int(t) // 256) for t in tiles[:12]]
-    print(f"M {M} delay {delay} dbg {dbg}: template {ms0:.4f} ms, ring {ms1:.4f} ms | bad rows {int(bad.sum())} tiles {tiles.numel()} max diff {d:.3e} (wg, item) {info}")
+    print(f"M {M} K {K} delay {delay} dbg {dbg}: template {ms0:.4f} ms, ring {ms1:.4f} ms | bad rows {int(bad.sum())} tiles {tiles.numel()} max diff {d:.3e} (wg, item) {info}")
     if tiles.numel():
         t = int(tiles[0]); rows = bad[t * 128:(t + 1) * 128].nonzero().flatten().tolist()
         cols = (out[t * 128 + rows[0]] != ref[t * 128 + rows[0]]).nonzero().flatten().tolist()
@@ -39,17 +39,18 @@ for r in range(3):
         print(f"   tile {t}: bad rows in tile {rows[:20]}{'...' if len(rows) > 20 else ''} ({len(rows)}); bad cols of first: {cols[:16]} ({len(cols)})")
 
 # in-kernel stamps (wave 0 and wave 4 of every workgroup): k-loop / epilogue cycles per tile, counter polls per tile
-dg = torch.zeros(256 * 20, dtype=torch.int64, device="cuda")
+dg = torch.zeros(256 * 22, dtype=torch.int64, device="cuda")
 opt("fc2_ring_diag", dg.data_ptr())
 out, _, ms2 = E.op_linear_postnorm(A, W, b, R, ga, be, 1e-6, reps=1)
 opt("fc2_ring_diag", 0)
 d = dg.cpu()[:256 * 8].reshape(256, 2, 4).double()
-sg = dg.cpu()[256 * 8:].reshape(256, 2, 6).double()
+sg = dg.cpu()[256 * 8:].reshape(256, 2, 7).double()
 for h, name in ((0, "wave 0"), (1, "wave 4")):
     tiles = d[:, h, 2]
-    print(f"   {name}: k-loop {float((d[:, h, 0] / tiles).median()):.0f} cycles per tile = {float((d[:, h, 0] / tiles / 32).median()):.0f} per k-tile, "
-          f"epilogue {float((d[:, h, 1] / tiles).median()):.0f}, polls per k-tile {float((d[:, h, 3] / tiles / 32).median()):.2f} (max {float((d[:, h, 3] / tiles / 32).max()):.2f})")
+    print(f"   {name}: k-loop {float((d[:, h, 0] / tiles).median()):.0f} cycles per tile = {float((d[:, h, 0] / tiles / (K // 32)).median()):.0f} per k-tile, "
+          f"epilogue {float((d[:, h, 1] / tiles).median()):.0f}, polls per k-tile {float((d[:, h, 3] / tiles / (K // 32)).median()):.2f} (max {float((d[:, h, 3] / tiles / (K // 32)).max()):.2f})")
     if sg.abs().sum() > 0:   # -DR2_STAMPS library: per k-tile segments
-        kt = tiles * 32
-        names = ["wait own pieces (vmcnt)", "W frags + poll A slot", "A frags + group 0", "groups 1-3 + signal", "groups 4-7", "(tile start / epilogue gap)"]
-        print("      " + "; ".join(f"{n} {float((sg[:, h, i] / kt).median()):.0f}" for i, n in enumerate(names[:5])))
+        kt = tiles * (K // 32)
+        names = ["wait own pieces (vmcnt)", "W frags + poll A slot", "A frags + group 0", "groups 1-3 + signal", "groups 4-7"]
+        print("      " + "; ".join(f"{n} {float((sg[:, h, i] / kt).median()):.0f}" for i, n in enumerate(names[:5])) +
+              f"; epilogue sweep 1 {float((sg[:, h, 6] / tiles).median()):.0f} of {float((d[:, h, 1] / tiles).median()):.0f} cycles per tile")
