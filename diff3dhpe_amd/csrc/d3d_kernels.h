@@ -51,6 +51,9 @@ inline int resident_workgroups_per_cu(const void* fn, int block, size_t dyn_lds)
 // an engine set it around their launches; launches outside an engine (the single-op hooks) write to a per-device sink nobody reads.
 struct LaunchCtx { bool tail_slices = true; unsigned* range_word = nullptr; };
 extern thread_local LaunchCtx tl_launch_ctx;
+// Process-wide switch (engine option "deep_stages", default on): the one-tile-per-workgroup GEMM launches (batches of a few sequences)
+// stage three (256 x 128 tiles) / four (128 x 128) k-tiles deep instead of two (kernels_gemm_x3p.hip, NST).  Values do not depend on it.
+void set_x3q_deep_stages(bool on);
 unsigned* range_sink_word();   // engine.hip: 4 bytes of device memory per device, allocated on first use (nullptr if that failed)
 inline unsigned* launch_range_word() { return tl_launch_ctx.range_word ? tl_launch_ctx.range_word : range_sink_word(); }
 

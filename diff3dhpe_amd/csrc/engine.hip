@@ -1333,6 +1333,7 @@ int d3d_engine_set_option(d3d_engine* e, const char* key, int64_t value) {
   if (k == "fc2_ring_dbg") { set_fc2_ring_dbg((int)value); return D3D_OK; }
   if (k == "fc2_ring_diag") { set_fc2_ring_diag(reinterpret_cast<unsigned long long*>((uintptr_t)value)); return D3D_OK; }   // 8 u64 per workgroup
   if (k == "fc2_ring_op") { g_opt_fc2_ring_op = value != 0; return D3D_OK; }       // d3d_op_linear_postnorm through the ring kernel
+  if (k == "deep_stages") { set_x3q_deep_stages(value != 0); return D3D_OK; }      // 3 / 4 operand stages in the one-tile-per-workgroup GEMM launches
   if (!e) return fail(D3D_EINVAL, "null engine");
   if (k == "fused_postnorm") e->opt_fused_postnorm = value != 0;
   else if (k == "fold_layernorm") e->opt_fold_layernorm = value != 0;

@@ -120,7 +120,10 @@ __device__ __forceinline__ void x3_mma(f32x4& acc, const h8& bh, const h8& bl, c
 // instantiated -- the persistent walk sends ragged tiles through the SUB instantiation, so that its whole-tile path carries ONE
 // branch-free epilogue (the row-statistics form used to run the checked copy -- an exec-mask branch around every residual load
 // and store -- for every tile, because two copies under a run-time branch spilled accumulators).
-template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool PERSIST = false, bool SUB = false, bool FULL = false>
+// NST (one tile per workgroup only): operand stages of the one-barrier loop.  2: k-tile t + 1 is requested while k-tile t is multiplied
+// (a k-tile then lasts at least one DMA round trip -- what bounds the launches whose every tile has a CU of its own: B = 1); 3 / 4:
+// k-tiles t + 1 .. t + NST - 1 are in flight, the wait in front of a k-tile's barrier is a counted vmcnt that leaves the younger ones out.
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, bool PERSIST = false, bool SUB = false, bool FULL = false, int NST = 2>
 __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                          const float* __restrict__ bias, const float* R, float* C, _Float16* Ch, _Float16* Cl,
                                          int M, int N, int K, int m0, int n0, int nt, int ntiles, int qcols,
@@ -137,7 +140,8 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, N_IT = A_IT + B_IT;   // 1-KiB DMA pieces per wave per k-tile
   constexpr int PPG = (N_IT + TM - 1) / TM;                                   // pieces issued per MFMA group
   static_assert(NW % 2 == 0 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must split evenly over the waves");
-  static_assert(2 * STAGE >= NW * 2 * 16 * 64 * 4, "epilogue patches must fit in the operand stages");
+  static_assert(NST * STAGE >= NW * 2 * 16 * 64 * 4, "epilogue patches must fit in the operand stages");
+  static_assert(NST == 2 || (!PERSIST && !SUB && NST >= 2 && NST <= 4), "deeper staging: one tile per workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int bid = blockIdx.x;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   if (diag) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   // beyond the operand stages and the persistent walk's epilogue patches, which start at stage 1 and take 64 KiB (allocated only for
   // the folded forms)
-  constexpr int LDS_X = (PERSIST && STAGE + NW * 2 * 16 * 64 * 4 > 2 * STAGE) ? STAGE + NW * 2 * 16 * 64 * 4 : 2 * STAGE;
+  constexpr int LDS_X = (PERSIST && STAGE + NW * 2 * 16 * 64 * 4 > 2 * STAGE) ? STAGE + NW * 2 * 16 * 64 * 4 : NST * STAGE;
   unsigned char* const lds_x = lds + LDS_X;
   const int tid = tidx;
   const int lane = tid & 63;
@@ -240,7 +244,11 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
   const int nk = K / PBK;
   if (!PERSIST) {
 #pragma unroll
-    for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(0, 0, it);
+    for (int kt0 = 0; kt0 < NST - 1; ++kt0)
+      if (kt0 == 0 || kt0 < nk) {
+#pragma unroll
+        for (int it = 0; it < N_IT; ++it) D3D_QSTAGE_ONE(kt0, kt0, it);
+      }
   }
   // next tile's operand bases (PERSIST): same per-lane offset, other uniform bases
   const char* ubAn = reinterpret_cast<const char*>(Ap) + (size_t)(m0n + wave * 8) * K2_ * 2;
@@ -251,18 +259,39 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     else D3D_GLDS(sgpr_ptr(ubBn + ((IT) - A_IT) * it_stride) + lofs_, dstB + ((IT) - A_IT) * NW * 1024);                 \
   } while (0)
 
+  [[maybe_unused]] auto qk_wait_vm = [](int n) {   // s_waitcnt vmcnt(n), n wave-uniform
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
   // one k-tile = TM groups (one 16-row m-tile each): the A fragments of group g+1 are read, and PPG DMA pieces of the
   // next k-tile are issued, before the 12 MFMAs of group g; the 8 W fragments are read once at the top of the k-tile.
-#define D3D_QKTILE(KT, PREFETCH)                                                                                         \
+#define D3D_QKTILE(KT, PREFETCH, WAITN)                                                                                  \
   do {                                                                                                                   \
     /* this wave's DMA pieces of k-tile KT have landed before it meets the barrier: written out, not left to the fence */\
     /* of __syncthreads() -- in the SUB instantiation (uniform branches around the DMA issues) the compiler emitted no  */\
     /* vmcnt wait in the k-loop at all, and the slices read stale W rows (the last pieces issued)                        */\
-    __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) */                                                                 \
-    __syncthreads();                                                                                                     \
+    if constexpr (NST == 2) {                                                                                            \
+      __builtin_amdgcn_s_waitcnt(0x0F70);   /* vmcnt(0) */                                                               \
+      __syncthreads();                                                                                                   \
+    } else {   /* the pieces of k-tiles KT + 1 .. stay in flight (vmcnt retires in order); LDS reads of k-tile KT - 1 are done */ \
+      qk_wait_vm(WAITN);                                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* (row statistics written to LDS in front of the loop) */    \
+      __builtin_amdgcn_s_barrier();                                                                                      \
+    }                                                                                                                    \
     asm volatile("" : "+v"(lofs_)); /* keeps the lane offset out of the loop's pointer induction (saddr form) */         \
-    const int nst = ((KT) + 1) & 1;                                                                                      \
-    const unsigned char* sb = lds + ((KT) & 1) * STAGE;                                                                  \
+    const int nst = NST == 2 ? (((KT) + 1) & 1) : ((KT) + NST - 1) % NST;                                                \
+    const unsigned char* sb = lds + (NST == 2 ? ((KT) & 1) : (KT) % NST) * STAGE;                                        \
     h8 bh[4], bl[4], ah[2], al[2];                                                                                       \
     ah[0] = *reinterpret_cast<const h8*>(sb + aoff + gl * 2048);                                                         \
     al[0] = *reinterpret_cast<const h8*>(sb + ((aoff + gl * 2048) ^ 64));                                                \
@@ -278,7 +307,7 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
       }                                                                                                                  \
       if (PREFETCH) {                                                                                                    \
         _Pragma("unroll") for (int pp = 0; pp < PPG; ++pp)                                                               \
-          if (g * PPG + pp < N_IT) D3D_QSTAGE_ONE(nst, (KT) + 1, g * PPG + pp);                                          \
+          if (g * PPG + pp < N_IT) D3D_QSTAGE_ONE(nst, (KT) + NST - 1, g * PPG + pp);                                    \
       } else if (PERSIST) {                                                                                              \
         if (has_next) {                                                                                                  \
           _Pragma("unroll") for (int pp = 0; pp < PPG; ++pp)                                                             \
@@ -549,10 +578,15 @@ __device__ __forceinline__ void x3q_tile(const _Float16* __restrict__ Ap, const 
     D3D_PHASE(kt, 1, false, false, false, false);
 #undef D3D_PHASE
 #undef D3D_PIECE
-  } else {
+  } else if constexpr (NST == 2) {
     int kt = 0;
-    for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true);
-    D3D_QKTILE(kt, false);
+    for (; kt + 1 < nk; ++kt) D3D_QKTILE(kt, true, 0);
+    D3D_QKTILE(kt, false, 0);
+  } else {
+    static_assert(N_IT == 2 || N_IT == 3 || N_IT == 4 || N_IT == 6 || N_IT == 8 || N_IT == 9, "counted waits listed above");
+    int kt = 0;
+    for (; kt + NST - 1 < nk; ++kt) D3D_QKTILE(kt, true, (NST - 2) * N_IT);        // k-tiles kt + 1 .. kt + NST - 2 still in flight
+    for (; kt < nk; ++kt) D3D_QKTILE(kt, false, (nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2) * N_IT);
   }
 #undef D3D_QKTILE
 #undef D3D_QSTAGE_ONE
@@ -648,7 +682,7 @@ __device__ __forceinline__ void x3q_tile_sub(const _Float16* __restrict__ Ap, co
 }
 
 // Uniform launch: every workgroup one BM x BN tile; blockIdx -> tile keeps all N-tiles of an M-tile on one XCD.
-template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX>
+template <int TM, int WM, int WN, int EPI, int OUTSPLIT, int FX, int NST = 2>
 __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __restrict__ Ap, const _Float16* __restrict__ Wp,
                                                              const float* __restrict__ bias, const float* R, float* C,
                                                              _Float16* Ch, _Float16* Cl, int M, int N, int K, int mtiles,
@@ -659,7 +693,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_linear_x3q(const _Float16* __r
   const int mt = (slot / ntiles) * 8 + xcd;
   const int nt = slot % ntiles;
   if (mt >= mtiles) return;
-  x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles, qcols, diag, fx);
+  x3q_tile<TM, WM, WN, EPI, OUTSPLIT, FX, false, false, false, NST>(Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mt * BM, nt * BN, nt, ntiles,
+                                                                    qcols, diag, fx);
 }
 
 // Persistent launch (one 8-wave workgroup per CU): the workgroup walks the tiles blockIdx, blockIdx + gridDim, ... of the
@@ -763,6 +798,8 @@ __global__ __launch_bounds__(512) void k_linear_x3q_persist(const _Float16* __re
 static unsigned long long* g_x3_diag = nullptr;
 
 thread_local LaunchCtx tl_launch_ctx;
+static std::atomic<bool> g_x3q_deep{true};
+void set_x3q_deep_stages(bool on) { g_x3q_deep = on; }
 
 // walk of `tiles` tiles over `grid` persistent workgroups
 static X3Walk x3q_walk(int tiles, int grid, bool four_way = true) {
@@ -771,14 +808,14 @@ static X3Walk x3q_walk(int tiles, int grid, bool four_way = true) {
   return w;
 }
 
-template <int TM, int WM, int WN>
+template <int TM, int WM, int WN, int NST = 2>
 static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float* bias, const float* R, float* C, _Float16* Ch,
                              _Float16* Cl, int M, int N, int K, int epi, int outsplit, int qcols, hipStream_t s,
                              unsigned long long* diag = nullptr, const X3Fold* fold = nullptr, int w_exp = 12, bool bf16 = false) {
   constexpr int BM = 16 * TM * WM, BN = 64 * WN;
   const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
   const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-  size_t lds_bytes = 2 * (size_t)((BM + BN) * 128);
+  size_t lds_bytes = NST * (size_t)((BM + BN) * 128);
   X3Tail tail{};
   tail.out_scale = ldexpf(1.0f, -(3 + w_exp));
   tail.range = launch_range_word();
@@ -795,7 +832,7 @@ static hipError_t launch_x3q(const _Float16* Ap, const _Float16* Wp, const float
   }
 #define D3D_X3Q_LAUNCH_FX(EPI_, OS_, FX_)                                                                                 \
   do {                                                                                                                    \
-    auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_, FX_>;                                                                  \
+    auto kfn = k_linear_x3q<TM, WM, WN, EPI_, OS_, FX_, NST>;                                                             \
     static std::atomic<unsigned long long> attr_done{0};   /* one bit per device */                                       \
     if (hipError_t ae = lds_optin(reinterpret_cast<const void*>(kfn), lds_bytes, attr_done)) return ae;                   \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WM * WN), lds_bytes, s, Ap, Wp, bias, R, C, Ch, Cl, M, N, K, mtiles,    \
@@ -1036,8 +1073,12 @@ static hipError_t launch_x3q_auto(const _Float16* ap, const _Float16* wp, const 
   // (<2,4,2>: eight waves of 32 x 64) still find a CU each, the launch is as long as ONE tile takes and that tile is shorter -- proj at
   // B = 1, T = 243: 26 -> 20.7 us per launch.  Beyond that (two such workgroups sharing a CU) the shape loses: fc1 at B = 1 28.7 -> 38.2 us
   // (NOTES round 6).  Values do not depend on the tile shape.
-  if (x3q_small(M, N)) return launch_x3q<2, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
-  return launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
+  const bool deep = g_x3q_deep.load(std::memory_order_relaxed);
+  if (x3q_small(M, N))
+    return deep ? launch_x3q<2, 4, 2, 4>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp)
+                : launch_x3q<2, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
+  return deep ? launch_x3q<4, 4, 2, 3>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp)
+              : launch_x3q<4, 4, 2>(ap, wp, bias, R, C, ch, cl, M, N, K, epi, outsplit, qcols, s, nullptr, fold, w_exp);
 }
 
 // ---- bf16 operand mode (D3D_PREC_BF16) ---------------------------------------------------------------------------------

@@ -163,6 +163,10 @@ int d3d_engine_set_graph_mode(d3d_engine* e, int32_t on);
  *                     one the engine owns, forked and joined by events: the caller sees ONE asynchronous operation on its stream;
  *                     bit-identical to one stream -- every output element is independent of the batch it is computed in; measured
  *                     +2.9 % at T=243 / B=64, neutral at T=81 / T=27).  Per-kernel profiling and the trace force one stream.
+ * Process-wide switch (e may be NULL): "deep_stages" 1 (default) / 0: the one-tile-per-workgroup F16X3 GEMM launches (batches of a few
+ * sequences: proj on 128 x 128 tiles, qkv / proj / fc1 on 256 x 128) keep three / four k-tiles of operands staged instead of two, the wait
+ * in front of a k-tile's barrier a counted vmcnt -- a k-tile no longer lasts a DMA round trip (proj at B = 1, T = 243: 20.8 -> 17.6 us per
+ * launch; a 9-step sampling 18.9 -> 18.3 ms at B = 1, 75.7 -> 72.2 at B = 8).  Bit-identical.
  * Process-wide diagnostics (e may be NULL): "gemm_diag", "attn_diag" 0 / 1: the op hooks print in-kernel stamp reports to stderr;
  * "fc2_ring_delay" (waves 4-7 of the ring kernel start each tile that many x 64 cycles late; default 24), "fc2_ring_op" 0 / 1
  * (d3d_op_linear_postnorm through the ring kernel), "fc2_ring_dbg" / "fc2_ring_diag" (builds with -DR2_DEBUG only: experiments/fc2_ring_op.py)

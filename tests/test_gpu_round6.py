@@ -76,3 +76,55 @@ def test_ctor_arguments_golden(tag, prec):
     assert worst < 1e-4, (tag, prec, worst)
     eng = net.engine_for(torch.device("cuda", torch.cuda.current_device()))
     assert eng.range_flags() == 0
+
+
+@pytest.mark.parametrize("B,T,prec", [(1, 243, "f16x3"), (2, 243, "f16x3"), (5, 243, "f16x3"), (3, 81, "f16x3"), (2, 27, "f16x3"), (3, 243, "bf16")])
+def test_deep_operand_staging_of_the_small_batch_gemms_is_bit_identical(B, T, prec):
+    """One-tile-per-workgroup GEMM launches (batches of a few sequences: proj on 128 x 128 tiles, fc1 / proj / qkv on 256 x 128) stage
+    three / four k-tiles deep ("deep_stages", default on: a k-tile no longer lasts a DMA round trip) -- the same MFMAs in the same order
+    as with two stages: the sampling is bit for bit the two-stage one, one and two streams, NaN-filled workspace (S2S:46-54, 84)."""
+    cfg = cfg_full(T)
+    _, diff = _product(cfg, 5, prec, sampling=2)
+    eng = diff._engine(torch.device("cuda", torch.cuda.current_device()))
+    inp = inputs(B, T, 84)
+    x2d, nz = inp["x2d"].cuda(), inp["noise"].cuda()
+    try:
+        eng.set_option("deep_stages", 0)
+        plain = eng.ddim_sample(x2d, nz).clone()
+        eng.set_option("deep_stages", 1)
+        for streams in (2, 1):
+            eng.set_option("streams", streams)
+            eng._workspace(B).view(torch.float32).fill_(float("nan"))
+            own = eng.ddim_sample(x2d, nz).clone()
+            assert torch.isfinite(own).all()
+            assert torch.equal(own, plain), streams
+    finally:
+        eng.set_option("deep_stages", 1)
+        eng.set_option("streams", 2)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4131, 512, 512, "residual"), (300, 1024, 512, "gelu"), (8262, 1536, 512, "none"), (97, 512, 64, "none"),
+                                       (1000, 512, 32, "residual")])
+def test_deep_operand_staging_op_level(M, N, K, epi):
+    """The same at the op level (d3d_op_linear), incl. K of one and two k-tiles (fewer k-tiles than stages) and ragged M."""
+    from diff3dhpe_amd import _lib as L
+    from diff3dhpe_amd import engine as E
+    from helpers import hashed
+    A = hashed(f"dsA{M}", (M, K), 41, 2.0).cuda()
+    W = hashed(f"dsW{N}{K}", (N, K), 42, 1.0 / K ** 0.5).cuda()
+    b = hashed("dsb", (N,), 43, 0.5).cuda()
+    R = hashed(f"dsR{M}", (M, N), 44, 1.5).cuda() if epi == "residual" else None
+    try:
+        L.check(L.lib().d3d_engine_set_option(None, b"deep_stages", 0))
+        y0 = E.op_linear(A, W, b, R, epi=epi, precision="f16x3")
+        L.check(L.lib().d3d_engine_set_option(None, b"deep_stages", 1))
+        y1 = E.op_linear(A, W, b, R, epi=epi, precision="f16x3")
+    finally:
+        L.check(L.lib().d3d_engine_set_option(None, b"deep_stages", 1))
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if epi == "residual":
+        ref = ref + R.double()
+    assert maxabs(y1, ref.cpu()) < 3e-6 * (K / 32) ** 0.5 + 2e-6
+    assert torch.equal(y0, y1)
