@@ -323,6 +323,74 @@ def companion_legs(a, diff, net, eng, x2d, noise, gt, dev, T, S, Bl):
     return out
 
 
+class PowerSampler:
+    """Socket power / shader clock of THIS rank's card while the timed region runs, read from the amdgpu hwmon files (sysfs; no GPU call, no
+    privilege, ~20 samples a second on a daemon thread): the bench line then says by itself whether the path ran at the board's power cap
+    (DESIGN section 5).  The card is matched by PCI address; every failure mode (no sysfs, no match) gives None, never an error."""
+
+    def __init__(self, pci_bus_id, root="/sys/class/drm"):
+        import glob
+        self.files = None
+        self.rows = []
+        self._stop = None
+        try:
+            want = (pci_bus_id or "").lower()
+            for dev in sorted(glob.glob(os.path.join(root, "card[0-9]*", "device"))):
+                real = os.path.realpath(dev).lower()
+                if not want or not real.endswith(want):
+                    continue
+                hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+                if not hw:
+                    continue
+                pw = next((q for q in (os.path.join(hw[0], "power1_input"), os.path.join(hw[0], "power1_average")) if os.path.exists(q)), None)
+                fq = os.path.join(hw[0], "freq1_input")
+                if pw:
+                    self.files = {"power": pw, "sclk": fq if os.path.exists(fq) else None, "cap": os.path.join(hw[0], "power1_cap"), "card": dev}
+                break
+        except Exception:
+            self.files = None
+
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def start(self):
+        if not self.files:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.rows.append((self._num(self.files["power"]), self._num(self.files["sclk"]) if self.files["sclk"] else None))
+                time.sleep(0.05)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if not self.files or self._stop is None:
+            return None
+        self._stop.set()
+        self._th.join(timeout=1.0)
+
+        def st(xs, scale):
+            xs = sorted(x / scale for x in xs if x is not None)
+            if not xs:
+                return None
+            return {"p50": round(xs[len(xs) // 2], 1), "mean": round(sum(xs) / len(xs), 1), "p95": round(xs[min(len(xs) - 1, int(0.95 * len(xs)))], 1)}
+        cap = self._num(self.files["cap"])
+        pw = st([r[0] for r in self.rows], 1e6)
+        out = {"socket_power_W": pw, "power_cap_W": cap / 1e6 if cap else None, "sclk_MHz": st([r[1] for r in self.rows], 1e6), "samples": len(self.rows),
+               "source": "amdgpu hwmon (power1_input, freq1_input) of this rank's card, ~20 samples/s over the timed region, no GPU call"}
+        if pw and cap:
+            out["frac_of_cap_p50"] = round(pw["p50"] / (cap / 1e6), 4)
+        return out
+
+
 def _mark_ready():
     """Tell the self-launcher's watchdog that this rank's first sampling is done (a file in D3D_BENCH_READY_DIR; no-op elsewhere)."""
     d = os.environ.get("D3D_BENCH_READY_DIR")
@@ -616,12 +684,21 @@ def main():
         step()
     seen_flags[0] = 0                             # (the timed samplings' flags only)
     # ---- timed region: the engine as a user gets it -- per-kernel event timing OFF
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        pci = "%04x:%02x:%02x.0" % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+    except Exception:
+        pci = None
+    power = PowerSampler(pci) if pci else None
     fence()
+    if power:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         err, cnt = step(record=True)
     fence()
     elapsed = time.perf_counter() - t0
+    power_stats = power.stop() if power else None
     rank_ms = elapsed / a.steps * 1e3
     try:                                          # process creation -> first sampling (and its reduction) done on this rank
         import psutil
@@ -797,6 +874,11 @@ def main():
             "headline_under": ("2-stream" if (a.streams == 2 and Bl >= 2) else "eager") + ("+graph" if a.graph else ""),
             "roofline": roof,
         }
+        if power_stats:
+            # rank 0's card over the timed region: at the cap, time is energy (J per pose-sequence = W x s / sequences of THIS rank)
+            power_stats["joules_per_pose_sequence"] = (round(power_stats["socket_power_W"]["mean"] * (elapsed / a.steps) / max(Bl, 1), 2)
+                                                       if power_stats.get("socket_power_W") else None)
+            line["power"] = power_stats
         if rank_stats:
             line["ranks"] = rank_stats
         if a.precision == "f16x3":

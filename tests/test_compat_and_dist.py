@@ -173,6 +173,37 @@ def test_bench_host_side_helpers():
     assert two.get("processes") == 2 and two["value"] and two["steps_finished"] >= 2, two
 
 
+def test_bench_power_sampler_reads_the_card_with_this_pci_address(tmp_path):
+    """bench.py's PowerSampler (the `power` object of the bench line: socket power and shader clock of the rank's card over the timed region,
+    from the amdgpu hwmon files): it picks the card whose sysfs device resolves to the rank's PCI address, reports microwatts / hertz as W /
+    MHz with the cap beside them, and is silent (None) when no card matches or the tree is missing."""
+    import importlib.util
+    import time as _t
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n, addr, pw in ((0, "0000:05:00.0", 240e6), (1, "0000:15:00.0", 1394e6)):
+        real = tmp_path / "pci" / addr
+        hw = real / "hwmon" / f"hwmon{n + 3}"
+        hw.mkdir(parents=True)
+        (hw / "power1_input").write_text(str(int(pw)))
+        (hw / "freq1_input").write_text(str(int(1878e6)))
+        (hw / "power1_cap").write_text(str(int(1400e6)))
+        (tmp_path / "drm" / f"card{n}").mkdir(parents=True)
+        os.symlink(real, tmp_path / "drm" / f"card{n}" / "device")
+    ps = bench.PowerSampler("0000:15:00.0", root=str(tmp_path / "drm"))
+    assert ps.files and ps.files["power"].endswith("hwmon4/power1_input")
+    ps.start()
+    _t.sleep(0.2)
+    out = ps.stop()
+    assert out["socket_power_W"]["p50"] == 1394.0 and out["power_cap_W"] == 1400.0 and out["sclk_MHz"]["p50"] == 1878.0
+    assert out["frac_of_cap_p50"] == round(1394 / 1400, 4) and out["samples"] >= 2
+    none = bench.PowerSampler("0000:99:00.0", root=str(tmp_path / "drm"))
+    none.start()
+    assert none.files is None and none.stop() is None
+    assert bench.PowerSampler("0000:15:00.0", root=str(tmp_path / "nowhere")).stop() is None
+
+
 def test_bench_self_launch_watchdog_names_a_rank_that_never_finishes_its_first_sampling():
     """a rank that has not finished a first sampling `D3D_BENCH_STARTUP_TIMEOUT_S` after the start (a hung
     rendezvous, a device that does not come up) is NAMED, every rank is ended and the launcher exits non-zero -- it does not sit until the
