@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "d3d_engine_profile_read", "d3d_kernel_class_name", "d3d_op_linear_bench", "d3d_op_linear_postnorm", "d3d_engine_set_graph_mode", "d3d_num_windows", "d3d_window_gather",
     "d3d_engine_set_trace", "d3d_engine_trace_read", "d3d_engine_range_flags", "d3d_op_head", "d3d_engine_set_option",
     "d3d_weighted_loss", "d3d_repeat_batch", "d3d_hypothesis_mean", "d3d_engine_get_info", "d3d_probe_machine",
-    "d3d_engine_range_post", "d3d_engine_range_take", "d3d_window_gather_s2f",
+    "d3d_engine_range_post", "d3d_engine_range_take", "d3d_window_gather_s2f", "d3d_pose_metrics",
 ]
 
 
@@ -67,6 +67,7 @@ def _bind(lib: C.CDLL) -> None:
         "d3d_engine_get_info": (C.c_int, [vp, C.c_char_p, C.POINTER(i64)]),
         "d3d_probe_machine": (C.c_int, [i32, f32, C.POINTER(f32), vp]),
         "d3d_tta_mpjpe": (C.c_int, [vp, vp, vp, vp, f32, C.POINTER(i32), C.POINTER(i32), i32, vp, vp, i32, i32, i32, vp]),
+        "d3d_pose_metrics": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "d3d_engine_set_profiling": (C.c_int, [vp, i32]),
         "d3d_engine_set_graph_mode": (C.c_int, [vp, i32]),
         "d3d_engine_set_option": (C.c_int, [vp, C.c_char_p, i64]),

@@ -279,6 +279,8 @@ hipError_t launch_hypothesis_mean(const float* pred, float* out, int B, int64_t 
 struct JointPerm { static constexpr int MAXJ = 64; int32_t p[MAXJ]; };
 hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, const uint8_t* mask, float scale,
                             const JointPerm& perm, float* merged, double* sums, int B, int T, int J, hipStream_t s);
+// evaluate()'s other three protocols on the merged prediction (kernels_elem.hip k_pose_metrics; RUN:602-614, LOSS:43-93, 132-142)
+hipError_t launch_pose_metrics(const float* pred, const float* gt, const uint8_t* mask, double* sums, int N, int J, hipStream_t s);
 
 hipError_t launch_window_gather(const float* seq, float* out, uint8_t* mask, const JointPerm& perm, int n, int T, int J, int C,
                                 int flip, hipStream_t s);

@@ -1463,6 +1463,13 @@ int d3d_tta_mpjpe(const float* pred, const float* pred_flip, const float* gt, co
   return D3D_OK;
 }
 
+int d3d_pose_metrics(const float* pred, const float* gt, const uint8_t* mask, double* sums, int32_t N, int32_t J, void* stream) {
+  if (!pred || !gt || !sums || N <= 0 || J <= 0) return fail(D3D_EINVAL, "bad argument");
+  if (J > JointPerm::MAXJ) return fail(D3D_EUNSUP, "more than 64 joints");
+  HIP_TRY(launch_pose_metrics(pred, gt, mask, sums, N, J, reinterpret_cast<hipStream_t>(stream)));   // asynchronous on `stream`
+  return D3D_OK;
+}
+
 int d3d_num_windows(int32_t n_frames, int32_t T) { return (n_frames < 1 || T < 1) ? 0 : (n_frames + T - 1) / T; }
 
 int d3d_window_gather(const float* seq, int32_t n_frames, int32_t T, int32_t J, int32_t C, int32_t flip, const int32_t* jl,

@@ -726,6 +726,155 @@ hipError_t launch_tta_mpjpe(const float* pred, const float* pred_flip, const flo
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ evaluate()'s other protocols
+// RUN:602-614 on the merged, de-normalised prediction: per KEPT frame (mask != 0) -- one thread each, fp64 inside --
+//   N-MPJPE (LOSS:83-93): s = <g, p> / <p, p> over the frame's joints; sum_j |s p_j - g_j|
+//   P-MPJPE (LOSS:43-81): centred, norm-scaled point sets X0 (target) / Y0 (prediction), H = X0^T Y0 = U S V^T, R = V U^T with the last
+//           singular direction flipped when det < 0, a = tr normX / normY: aligned_j - x_j = normX (tr y0_j R - x0_j).  The SVD of the
+//           3 x 3 H comes from the Jacobi eigen-decomposition of H^T H (V, S^2), u_i = H v_i / s_i for the two largest values, and
+//           R = v1 u1^T + v2 u2^T + (v1 x v2)(u1 x u2)^T -- which IS the reflection-corrected rotation whatever the sign of det H (the
+//           third pair of a proper SVD is +-(v1 x v2), +-(u1 x u2) with the product of the signs = sign det H, and the correction
+//           multiplies that sign away); tr = s1 + s2 + sign(det H) s3.  No division by the smallest singular value: planar poses are fine.
+//   MPJVE  (LOSS:132-142): first difference against the PREVIOUS KEPT frame of the flattened batch (np.diff after the mask), sum_j of
+//           |(p_f - p_q) - (g_f - g_q)|; the first kept frame has no predecessor.
+// sums[0..2] += the three joint-distance sums, sums[3] += kept frames, sums[4] += frames with a predecessor (caller zeroes sums).
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(128) void k_pose_metrics(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                      const uint8_t* __restrict__ mask, double* __restrict__ sums, int N, int J) {
+  const int f = blockIdx.x * 128 + threadIdx.x;
+  double en = 0.0, ep = 0.0, ev = 0.0, kept = 0.0, pairs = 0.0;
+  if (f < N && (!mask || mask[f])) {
+    kept = 1.0;
+    const float* P = pred + (size_t)f * J * 3;
+    const float* G = gt + (size_t)f * J * 3;
+    double mp[3] = {0, 0, 0}, mg[3] = {0, 0, 0}, gp = 0.0, pp = 0.0;
+    for (int j = 0; j < J; ++j)
+      for (int k = 0; k < 3; ++k) {
+        const double a = P[3 * j + k], b = G[3 * j + k];
+        mp[k] += a; mg[k] += b; gp += a * b; pp += a * a;
+      }
+    const double sc = gp / pp;
+    for (int k = 0; k < 3; ++k) { mp[k] /= J; mg[k] /= J; }
+    // centred sets, their norms, H[a][b] = sum_j x0_j[a] y0_j[b]
+    double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, nx = 0.0, ny = 0.0;
+    for (int j = 0; j < J; ++j) {
+      double x[3], y[3], d2 = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        x[k] = (double)G[3 * j + k] - mg[k];
+        y[k] = (double)P[3 * j + k] - mp[k];
+        nx += x[k] * x[k]; ny += y[k] * y[k];
+        const double d = sc * (double)P[3 * j + k] - (double)G[3 * j + k];
+        d2 += d * d;
+      }
+      en += sqrt(d2);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) H[a][b] += x[a] * y[b];
+    }
+    nx = sqrt(nx); ny = sqrt(ny);
+    const double inv = 1.0 / (nx * ny);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) H[a][b] *= inv;
+    const double detH = H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) - H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0]) +
+                        H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0]);
+    // A = H^T H, cyclic Jacobi: A = V diag(lambda) V^T
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) A[a][b] = H[0][a] * H[0][b] + H[1][a] * H[1][b] + H[2][a] * H[2][b];
+    for (int sweep = 0; sweep < 12; ++sweep) {
+      const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+      if (off < 1e-300 || off <= 1e-17 * (fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]))) break;
+      for (int pq = 0; pq < 3; ++pq) {
+        const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+        if (A[p][q] == 0.0) continue;
+        const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; ++k) {      // columns p, q of A, then rows p, q; columns p, q of V
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+    }
+    int i1 = 0, i2 = 1, i3 = 2;            // eigenvalues in descending order
+    if (A[i1][i1] < A[i2][i2]) { const int t_ = i1; i1 = i2; i2 = t_; }
+    if (A[i2][i2] < A[i3][i3]) { const int t_ = i2; i2 = i3; i3 = t_; }
+    if (A[i1][i1] < A[i2][i2]) { const int t_ = i1; i1 = i2; i2 = t_; }
+    const double s1 = sqrt(fmax(A[i1][i1], 0.0)), s2 = sqrt(fmax(A[i2][i2], 0.0)), s3 = sqrt(fmax(A[i3][i3], 0.0));
+    double v1[3] = {V[0][i1], V[1][i1], V[2][i1]}, v2[3] = {V[0][i2], V[1][i2], V[2][i2]}, u1[3], u2[3];
+    for (int a = 0; a < 3; ++a) u1[a] = H[a][0] * v1[0] + H[a][1] * v1[1] + H[a][2] * v1[2];
+    double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    for (int a = 0; a < 3; ++a) u1[a] /= n1;
+    for (int a = 0; a < 3; ++a) u2[a] = H[a][0] * v2[0] + H[a][1] * v2[1] + H[a][2] * v2[2];
+    const double dot = u2[0] * u1[0] + u2[1] * u1[1] + u2[2] * u1[2];
+    for (int a = 0; a < 3; ++a) u2[a] -= dot * u1[a];
+    double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    if (!(n2 > 1e-12 * s1)) {             // rank-one H (collinear points): any unit vector orthogonal to u1 serves (s2 = s3 = 0)
+      const int m = fabs(u1[0]) <= fabs(u1[1]) ? (fabs(u1[0]) <= fabs(u1[2]) ? 0 : 2) : (fabs(u1[1]) <= fabs(u1[2]) ? 1 : 2);
+      double e[3] = {0, 0, 0};
+      e[m] = 1.0;
+      const double d_ = e[0] * u1[0] + e[1] * u1[1] + e[2] * u1[2];
+      for (int a = 0; a < 3; ++a) u2[a] = e[a] - d_ * u1[a];
+      n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    }
+    for (int a = 0; a < 3; ++a) u2[a] /= n2;
+    const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+    double R[3][3];                         // R[b][a]: prediction space -> target space (row vector y R)
+    for (int b = 0; b < 3; ++b)
+      for (int a = 0; a < 3; ++a) R[b][a] = v1[b] * u1[a] + v2[b] * u2[a] + v3[b] * u3[a];
+    const double tr = s1 + s2 + (detH > 0.0 ? s3 : (detH < 0.0 ? -s3 : 0.0));
+    for (int j = 0; j < J; ++j) {
+      double y0[3], d2 = 0.0;
+      for (int k = 0; k < 3; ++k) y0[k] = ((double)P[3 * j + k] - mp[k]) / ny;
+      for (int a = 0; a < 3; ++a) {
+        const double x0 = ((double)G[3 * j + a] - mg[a]) / nx;
+        const double d = tr * (y0[0] * R[0][a] + y0[1] * R[1][a] + y0[2] * R[2][a]) - x0;
+        d2 += d * d;
+      }
+      ep += nx * sqrt(d2);
+    }
+    int q = f - 1;
+    while (q >= 0 && mask && !mask[q]) --q;
+    if (q >= 0) {
+      pairs = 1.0;
+      const float* Pq = pred + (size_t)q * J * 3;
+      const float* Gq = gt + (size_t)q * J * 3;
+      for (int j = 0; j < J; ++j) {
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) {     // np.diff of float32 arrays: the differences are rounded to fp32 there
+          const float dp = P[3 * j + k] - Pq[3 * j + k], dg = G[3 * j + k] - Gq[3 * j + k];
+          const double d = (double)(dp - dg);
+          d2 += d * d;
+        }
+        ev += sqrt(d2);
+      }
+    }
+  }
+  en = wave_sum_d(en); ep = wave_sum_d(ep); ev = wave_sum_d(ev); kept = wave_sum_d(kept); pairs = wave_sum_d(pairs);
+  if ((threadIdx.x & 63) == 0 && kept > 0.0) {
+    atomicAdd(&sums[0], en); atomicAdd(&sums[1], ep); atomicAdd(&sums[2], ev); atomicAdd(&sums[3], kept); atomicAdd(&sums[4], pairs);
+  }
+}
+
+hipError_t launch_pose_metrics(const float* pred, const float* gt, const uint8_t* mask, double* sums, int N, int J, hipStream_t s) {
+  if (N < 1 || J < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_pose_metrics, dim3((N + 127) / 128), dim3(128), 0, s, pred, gt, mask, sums, N, J);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ eval windows
 // ChunkedGenerator(out_all=True, pad=0) for one sequence (GEN:27-48, 247-276): non-overlapping T-frame windows, the last
 // one shifted back to end at the last frame, frames it shares with its predecessor masked out; sequences shorter than T

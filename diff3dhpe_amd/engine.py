@@ -456,6 +456,29 @@ def tta_mpjpe(pred: torch.Tensor, pred_flip: Optional[torch.Tensor], gt: torch.T
     return (float(s[0]), int(s[1]), merged) if want_merged else (float(s[0]), int(s[1]))
 
 
+def pose_metrics(merged: torch.Tensor, gt: torch.Tensor, target_mask: Optional[torch.Tensor] = None):
+    """evaluate()'s other three protocols on the merged, de-normalised prediction (RUN:602-614; LOSS:43-81 P-MPJPE, 83-93 N-MPJPE,
+    132-142 MPJVE) -- d3d_pose_metrics.  merged / gt: (..., J, 3) with the same leading shape, flattened to frames in memory order;
+    target_mask: one flag per frame (None: every frame kept).  Returns (kept_frames, n_mpjpe, p_mpjpe, mpjve) of THIS batch in the data's
+    unit -- mpjve is nan for a batch of one kept frame (numpy's mean of an empty difference in the reference)."""
+    dev = merged.device
+    J = merged.shape[-2]
+    p, g = _f32c(merged, dev), _f32c(gt, dev)
+    assert p.shape == g.shape and p.shape[-1] == 3, (p.shape, g.shape)
+    N = p.numel() // (J * 3)
+    m = target_mask.detach().to(device=dev, dtype=torch.uint8).contiguous() if target_mask is not None else None
+    assert m is None or m.numel() == N, (m.numel(), N)
+    sums = torch.zeros(5, dtype=torch.float64, device=dev)
+    if N > 0:
+        with torch.cuda.device(dev):
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(_lib.lib().d3d_pose_metrics(_ptr(p), _ptr(g), _ptr(m), _ptr(sums), N, J, st))
+    s = sums.cpu().tolist()
+    kept, pairs = int(s[3]), int(s[4])
+    nan = float("nan")
+    return (kept, s[0] / (J * kept) if kept else nan, s[1] / (J * kept) if kept else nan, s[2] / (J * pairs) if pairs else nan)
+
+
 def window_gather(seq: torch.Tensor, T: int, flip: bool = False, joints_left=(), joints_right=(), want_mask: bool = True):
     """(n, J, C) device tensor -> (windows, T, J, C) evaluation windows [+ (windows, T) bool target mask] (GEN:27-48, 247-276)."""
     dev = seq.device

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import parallel
-from .engine import tta_mpjpe, window_gather, window_gather_s2f
+from .engine import pose_metrics, tta_mpjpe, window_gather, window_gather_s2f
 
 H36M_JOINTS_LEFT = [4, 5, 6, 11, 12, 13]     # after remove_joints (reference common/h36m_dataset.py:20-21,288)
 H36M_JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]
@@ -34,18 +34,22 @@ def flip_2d(x2d: torch.Tensor, joints_left: Sequence[int], joints_right: Sequenc
 def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, scale: float = 1.0,
              joints_left: Sequence[int] = H36M_JOINTS_LEFT, joints_right: Sequence[int] = H36M_JOINTS_RIGHT,
              test_time_augmentation: bool = True, device: Optional[torch.device] = None, verbose: bool = True,
-             output_loss: bool = False, unit_scale: float = 1000.0):
+             output_loss: bool = False, unit_scale: float = 1000.0, all_protocols: bool = True):
     """batches yield dicts with inputs_2d (B,T,J,2), inputs_3d (B,T',J,3) [ground truth in the data set's unit; T' = T, or 1 for a
     seq2frame model], optional inputs_2d_flip, target_mask (B,T') bool, init_noise / init_noise_flip (B,T',J,3), inputs_3d_norm.
     output_loss=True is the 3DHP runner's call shape (run_..._3dhp.py:517-520 leaves forward()'s default): every sampling is preceded
     by the forward-only p_losses on the normalised ground truth (its flipped copy for the flipped input, :497-500) -- the value is
     discarded there and here; it matters for the generator draws it consumes.  unit_scale multiplies the reported error (1000: H36M
-    ground truth in metres -> mm; 1: 3DHP ground truth already in mm).  Returns a dict with MPJPE, frames, seconds."""
+    ground truth in metres -> mm; 1: 3DHP ground truth already in mm).  all_protocols (default, as the reference): besides Protocol #1
+    the batch's merged prediction goes through d3d_pose_metrics for P-MPJPE, N-MPJPE and MPJVE, each weighted by the batch's kept frames
+    (RUN:602-614) -- False keeps the MPJPE-only tail (one kernel, no merged tensor).  Returns a dict with the four errors, frames,
+    seconds; as_reference_tuple(result) is evaluate()'s own return value (e1, e2, e3, ev, N, epoch_time)."""
     model_diffusion.eval()
     dev = device or torch.device("cuda", torch.cuda.current_device())
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     tot_err, tot_cnt, secs, frames = 0.0, 0, 0.0, 0
+    tot_p, tot_n, tot_v = 0.0, 0.0, 0.0            # running sums of (kept frames of the batch) x (the batch's protocol value), RUN:603-614
     for batch in batches:
         x2d = batch["inputs_2d"]
         gt = batch["inputs_3d"]
@@ -87,8 +91,12 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
                 else:
                     pred = parallel.all_gather_pred(pred, B)
                 gsl = slice(0, B)
-            return tta_mpjpe(pred, pred_f, gt[gsl].to(dev), None if mask is None else mask[gsl].to(dev), scale,
-                             list(joints_left), list(joints_right))     # (reads the two sums back: the batch's one synchronisation)
+            gtd, md = gt[gsl].to(dev), (None if mask is None else mask[gsl].to(dev))
+            if not all_protocols:
+                return tta_mpjpe(pred, pred_f, gtd, md, scale, list(joints_left), list(joints_right)) + (None,)   # (reads the two sums
+                # back: the batch's one synchronisation)
+            err_, cnt_, merged = tta_mpjpe(pred, pred_f, gtd, md, scale, list(joints_left), list(joints_right), want_merged=True)
+            return err_, cnt_, pose_metrics(merged, gtd, md)
 
         net = getattr(getattr(model_diffusion, "module", model_diffusion), "model", None)
         if world == 1 and hasattr(net, "deferred_range_checks"):
@@ -96,24 +104,40 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
             # own); a flagged batch is repeated on the model's exact-fp32 engine (precision "auto") or raises D3DError ("f16x3")
             rng = torch.cuda.get_rng_state(dev)          # (a repeated batch draws the same noise: the reference's generator sequence)
             with net.deferred_range_checks() as pending:
-                err, cnt = run_batch()
+                err, cnt, extra = run_batch()
             if pending.resolve():
                 torch.cuda.set_rng_state(rng, dev)
-                err, cnt = run_batch()
+                err, cnt, extra = run_batch()
         else:   # several ranks: a rank must know its own flags BEFORE its shard enters the all-gather -- each sampling waits on its ticket
-            err, cnt = run_batch()
+            err, cnt, extra = run_batch()
         torch.cuda.synchronize(dev)
         secs += time.time() - t0
         tot_err += err
         tot_cnt += cnt
         frames += cnt // shape[2]
+        if extra is not None and extra[0] > 0:       # (a batch without a kept frame adds nothing; one kept frame: mpjve nan, as there)
+            kept, en, ep, ev = extra
+            tot_n += kept * en
+            tot_p += kept * ep
+            tot_v += kept * ev
     e1 = tot_err / max(tot_cnt, 1) * unit_scale
+    nfr = max(frames, 1)
+    e2, e3, ev_ = ((tot_p / nfr * unit_scale, tot_n / nfr * unit_scale, tot_v / nfr * unit_scale) if all_protocols else (None, None, None))
     if verbose and rank == 0:
         print('eval_frame:', frames)
         print('inference_time:', secs / 60, 'min')
         print('inference_speed:', frames / max(secs, 1e-9), 'frame/s')
         print('Protocol #1 Error (MPJPE):', e1, 'mm')
-    return {"mpjpe_mm": e1, "frames": frames, "seconds": secs}
+        if all_protocols:
+            print('Protocol #2 Error (P-MPJPE):', e2, 'mm')
+            print('Protocol #3 Error (N-MPJPE):', e3, 'mm')
+            print('Velocity Error (MPJVE):', ev_, 'mm')
+    return {"mpjpe_mm": e1, "p_mpjpe_mm": e2, "n_mpjpe_mm": e3, "mpjve_mm": ev_, "frames": frames, "seconds": secs}
+
+
+def as_reference_tuple(result: Dict[str, float]):
+    """evaluate()'s return value in the reference's own shape (RUN:654): (e1, e2, e3, ev, N, epoch_time)."""
+    return (result["mpjpe_mm"], result["p_mpjpe_mm"], result["n_mpjpe_mm"], result["mpjve_mm"], result["frames"], result["seconds"])
 
 
 @torch.no_grad()
@@ -122,7 +146,7 @@ def evaluate_sequence(model_diffusion, poses_2d: torch.Tensor, poses_3d: torch.T
                       kps_left: Optional[Sequence[int]] = None, kps_right: Optional[Sequence[int]] = None,
                       test_time_augmentation: bool = True, batch_size: int = 512, device: Optional[torch.device] = None,
                       init_noise=None, init_noise_flip=None, valid: Optional[torch.Tensor] = None, seq2frame: Optional[bool] = None,
-                      output_loss: bool = False, unit_scale: float = 1000.0):
+                      output_loss: bool = False, unit_scale: float = 1000.0, all_protocols: bool = True):
     """A whole video 2D-in -> MPJPE-out without host round trips: the window table, edge
     padding, target mask and the flipped 2D copy are built on the device, every window goes through the DDIM loop (twice with TTA),
     and merge + masked MPJPE run in one kernel (RUN:583-606).  Two window tables:
@@ -163,4 +187,4 @@ def evaluate_sequence(model_diffusion, poses_2d: torch.Tensor, poses_3d: torch.T
         batches.append(b)
     return evaluate(model_diffusion, batches, scale=scale, joints_left=joints_left, joints_right=joints_right,
                     test_time_augmentation=test_time_augmentation, device=dev, verbose=False, output_loss=output_loss,
-                    unit_scale=unit_scale)
+                    unit_scale=unit_scale, all_protocols=all_protocols)

@@ -208,6 +208,21 @@ int d3d_tta_mpjpe(const float* pred_dev, const float* pred_flip_dev, const float
                   float scale, const int32_t* joints_left_host, const int32_t* joints_right_host, int32_t n_lr,
                   float* merged_dev, double* sums_dev, int32_t B, int32_t T, int32_t J, void* stream);
 
+/* evaluate()'s other three protocols (RUN:602-614) on the merged, de-normalised prediction d3d_tta_mpjpe wrote (pred_dev, gt_dev:
+ * N frames of J joints x 3 fp32; mask_dev: N bytes, nullable = every frame kept), one thread per kept frame, fp64 inside:
+ *   sums_dev[0] += sum over kept frames and joints of |s p - g|, s = <g, p> / <p, p> per frame          (N-MPJPE, LOSS:83-93)
+ *   sums_dev[1] += the same for the prediction after the best similarity transform onto its target      (P-MPJPE, LOSS:43-81: scale,
+ *                  rotation without reflection, translation; the 3 x 3 SVD by a Jacobi eigen-decomposition)
+ *   sums_dev[2] += sum over kept frames WITH a kept predecessor in the flattened batch, and joints, of
+ *                  |(p_f - p_prev) - (g_f - g_prev)|                                                      (MPJVE, LOSS:132-142: np.diff
+ *                  of the masked batch -- window and sequence boundaries included, as there)
+ *   sums_dev[3] += kept frames, sums_dev[4] += frames with a predecessor (caller zeroes the five doubles).
+ * A batch's protocol value is sums[k] / (J * sums[3]) (k = 0, 1) and sums[2] / (J * sums[4]) -- 0 / 0 = nan for a batch of one kept
+ * frame, as numpy's mean of an empty difference there; evaluate() weights each by the batch's kept frames.  Asynchronous on `stream`.
+ * J <= 64; more: D3D_EUNSUP. */
+int d3d_pose_metrics(const float* pred_dev, const float* gt_dev, const uint8_t* mask_dev, double* sums_dev, int32_t N, int32_t J,
+                     void* stream);
+
 /* The path's one exchange step (RUN:216-218: nn.DataParallel's gather of the replicas' outputs) for hosts that do not go through
  * torch.distributed: all-gather of count_per_rank fp32 values (the rank's predicted sequences) over an RCCL communicator the
  * CALLER owns (nccl_comm: ncclComm_t), asynchronous on `stream`; recv_dev holds world_size * count_per_rank values in rank

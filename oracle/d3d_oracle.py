@@ -316,6 +316,67 @@ def merge_flip_tta(pred: Tensor, pred_flip: Tensor, scale: float, target_mask: T
     return p[target_mask.reshape(-1) == True, :, :].unsqueeze(1)  # noqa: E712
 
 
+# --------------------------------------------------------------------------- evaluate()'s other three protocols (RUN:602-614, LOSS:43-93, 132-142)
+
+def n_mpjpe(pred: Tensor, target: Tensor) -> Tensor:
+    """LOSS:83-93 (Protocol #3): one scale per frame, <target, pred> / <pred, pred> over the frame's joints, then mpjpe.  pred / target:
+    (N, 1, J, 3) as evaluate() passes them (RUN:603)."""
+    assert pred.shape == target.shape and pred.dim() == 4
+    den = torch.mean(torch.sum(pred ** 2, dim=3, keepdim=True), dim=2, keepdim=True)
+    num = torch.mean(torch.sum(target * pred, dim=3, keepdim=True), dim=2, keepdim=True)
+    return mpjpe((num / den) * pred, target)
+
+
+def p_mpjpe(pred, target):
+    """LOSS:43-81 (Protocol #2) on numpy arrays (N, J, 3), in their own dtype (float32 from evaluate(), RUN:608-611): per frame the
+    similarity transform (scale a, rotation R without reflection, translation t) that best maps the prediction onto the target --
+    centred and norm-scaled point sets, H = X0^T Y0 = U S V^T, R = V U^T with the last singular direction flipped when det R < 0 --, then
+    the mean joint distance of the aligned prediction."""
+    import numpy as np
+    assert pred.shape == target.shape and pred.ndim == 3
+    mu_t, mu_p = target.mean(axis=1, keepdims=True), pred.mean(axis=1, keepdims=True)
+    t0, p0 = target - mu_t, pred - mu_p
+    nt = np.sqrt((t0 ** 2).sum(axis=(1, 2), keepdims=True))
+    npd = np.sqrt((p0 ** 2).sum(axis=(1, 2), keepdims=True))
+    t0 = t0 / nt
+    p0 = p0 / npd
+    U, sv, Vt = np.linalg.svd(np.matmul(t0.transpose(0, 2, 1), p0))
+    V = Vt.transpose(0, 2, 1)
+    sign = np.sign(np.expand_dims(np.linalg.det(np.matmul(V, U.transpose(0, 2, 1))), axis=1))
+    V = V.copy()
+    sv = sv.copy()
+    V[:, :, -1] *= sign
+    sv[:, -1] *= sign.flatten()
+    R = np.matmul(V, U.transpose(0, 2, 1))
+    a = np.expand_dims(sv.sum(axis=1, keepdims=True), axis=2) * nt / npd
+    shift = mu_t - a * np.matmul(mu_p, R)
+    aligned = a * np.matmul(pred, R) + shift
+    return np.mean(np.linalg.norm(aligned - target, axis=2))
+
+
+def mean_velocity_error(pred, target):
+    """LOSS:132-142 (MPJVE) on numpy arrays (N, J, 3): first differences along axis 0 -- the batch's kept frames in their flattened order,
+    window and sequence boundaries included --, mean joint distance of the difference.  N = 1: the mean of an empty array (nan), as there."""
+    import numpy as np
+    assert pred.shape == target.shape
+    return np.mean(np.linalg.norm(np.diff(pred, axis=0) - np.diff(target, axis=0), axis=target.ndim - 1))
+
+
+def protocol_sums(pred: Tensor, target: Tensor):
+    """What one batch adds to evaluate()'s four running sums (RUN:602-614): pred / target (N, 1, J, 3) merged, de-normalised, masked.
+    Returns (N, N * mpjpe, N * p_mpjpe, N * n_mpjpe, N * mean_velocity_error) as Python floats."""
+    n = pred.shape[0] * pred.shape[1]
+    e1 = mpjpe(pred, target).item()
+    e3 = n_mpjpe(pred, target).item()
+    pn = pred.cpu().numpy().reshape(-1, pred.shape[-2], pred.shape[-1])
+    tn = target.cpu().numpy().reshape(-1, target.shape[-2], target.shape[-1])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # (N = 1: numpy's "mean of empty slice")
+        e2, ev = float(p_mpjpe(pn, tn)), float(mean_velocity_error(pn, tn))
+    return n, n * e1, n * e2, n * e3, n * ev
+
+
 # --------------------------------------------------------------------------- eval windows of a whole sequence (GEN:27-48, 247-271)
 
 def chunk_index(n_frames: int, T: int):

@@ -717,10 +717,53 @@ def gen_round5b():
         save("evaluate_3dhp_s2s", seed=np.int32(12), S=np.int32(S), batch_size=np.int32(2), scale=np.float32(refq.scale), **out)
 
 
+def gen_metrics():
+    """evaluate()'s other three protocols (RUN:602-614): the REAL common.loss.p_mpjpe / n_mpjpe / mean_velocity_error on merged, masked
+    batches as evaluate() hands them over -- (N, 1, J, 3) torch tensors for n_mpjpe, (N, J, 3) float32 numpy arrays for the other two.
+    Families: a prediction near its target, an unrelated one, mirrored predictions (the det R < 0 branch of p_mpjpe), planar poses
+    (a singular H), one kept frame (mean_velocity_error of an empty difference: nan), a T = 243 sized batch."""
+    import warnings
+    from common.loss import p_mpjpe as ref_p, n_mpjpe as ref_n, mean_velocity_error as ref_v
+    rng = np.random.RandomState(11)
+    J = 17
+    cases = {}
+    gt = rng.uniform(-1, 1, (40, J, 3)).astype(np.float32)
+    cases["near"] = (gt + 0.05 * rng.standard_normal(gt.shape).astype(np.float32), gt)
+    cases["unrelated"] = (rng.uniform(-1, 1, gt.shape).astype(np.float32), gt)
+    mir = gt.copy()
+    mir[..., 0] *= -1
+    cases["mirrored"] = (mir + 0.02 * rng.standard_normal(gt.shape).astype(np.float32), gt)
+    flat = gt.copy()
+    flat[..., 2] = 0.25
+    cases["planar"] = (flat + np.array([0.0, 0.0, 0.0], np.float32), (flat * 1.3 + 0.1).astype(np.float32))
+    cases["planar"] = (cases["planar"][0] + 0.03 * rng.standard_normal(gt.shape).astype(np.float32) * np.array([1, 1, 0], np.float32), cases["planar"][1])
+    cases["one_frame"] = (cases["near"][0][:1].copy(), gt[:1].copy())
+    big = (1000.0 * np.cumsum(0.01 * rng.standard_normal((729, J, 3)), axis=0)).astype(np.float32)
+    cases["big_mm"] = (big + (30.0 * rng.standard_normal(big.shape)).astype(np.float32), big)
+    out = {}
+    for tag, (pr, tg) in cases.items():
+        pt, tt = torch.from_numpy(pr).unsqueeze(1), torch.from_numpy(tg).unsqueeze(1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            e1 = ref_mpjpe(pt, tt).item()
+            e3 = ref_n(pt, tt).item()
+            e2 = float(ref_p(pr.copy(), tg.copy()))
+            ev = float(ref_v(pr.copy(), tg.copy()))
+        n, s1, s2, s3, sv = orc.protocol_sums(pt, tt)
+        for name, a, b in (("mpjpe", s1 / n, e1), ("p_mpjpe", s2 / n, e2), ("n_mpjpe", s3 / n, e3), ("mpjve", sv / n, ev)):
+            same = (a == b) or (np.isnan(a) and np.isnan(b))
+            print(f"  metrics {tag} {name}: reference {b:.9g} oracle {a:.9g} {'==' if same else 'DIFFERENT'}")
+            if not same:
+                raise SystemExit(f"oracle restatement of {name} diverges from the reference on '{tag}'")
+        out[f"{tag}_pred"], out[f"{tag}_gt"] = pr, tg
+        out[f"{tag}_ref"] = np.asarray([e1, e2, e3, ev], np.float64)
+    save("pose_metrics", tags=np.asarray(list(cases)), **out)
+
+
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
-    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5, "round5b": gen_round5b, "round6": gen_round6,
+    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5, "round5b": gen_round5b, "round6": gen_round6, "metrics": gen_metrics,
 }
 
 if __name__ == "__main__":

@@ -128,3 +128,67 @@ def test_deep_operand_staging_op_level(M, N, K, epi):
         ref = ref + R.double()
     assert maxabs(y1, ref.cpu()) < 3e-6 * (K / 32) ** 0.5 + 2e-6
     assert torch.equal(y0, y1)
+
+
+def test_pose_metrics_kernel_against_the_reference_values():
+    """d3d_pose_metrics (evaluate()'s P-MPJPE / N-MPJPE / MPJVE on the device, one thread per kept frame, fp64 inside, the 3 x 3 SVD by a
+    Jacobi eigen-decomposition) against values of the reference's own functions (tests/golden/pose_metrics.npz): near / unrelated / mirrored
+    (det R < 0) / planar (singular H) / mm-scale batches, the nan of a one-frame batch -- and the same batches with dropped frames spliced
+    in (target_mask): the kept frames alone decide the values, the velocity differences run over consecutive KEPT frames (RUN:588-590)."""
+    import numpy as np
+    from diff3dhpe_amd.engine import pose_metrics
+    g = gold("pose_metrics")
+    rng = np.random.RandomState(3)
+    for tag in g["tags"]:
+        pr, tg, ref = g[f"{tag}_pred"], g[f"{tag}_gt"], g[f"{tag}_ref"]
+        n = pr.shape[0]
+        keep = np.ones(n + n // 3 + 2, dtype=bool)
+        keep[rng.choice(len(keep), len(keep) - n, replace=False)] = False
+        prm = rng.uniform(-5, 5, (len(keep), 17, 3)).astype(np.float32)
+        tgm = rng.uniform(-5, 5, (len(keep), 17, 3)).astype(np.float32)
+        prm[keep], tgm[keep] = pr, tg
+        for P, G, M in ((pr, tg, None), (prm, tgm, keep)):
+            kept, en, ep, ev = pose_metrics(torch.from_numpy(P).cuda(), torch.from_numpy(G).cuda(), None if M is None else torch.from_numpy(M).cuda())
+            assert kept == n
+            for name, got, want in (("p_mpjpe", ep, ref[1]), ("n_mpjpe", en, ref[2]), ("mpjve", ev, ref[3])):
+                if np.isnan(want):
+                    assert np.isnan(got), (tag, name, got)
+                else:
+                    assert abs(got - want) <= 2e-6 * abs(want) + 1e-7, (tag, name, got, want)     # (the reference computes these in fp32)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_evaluate_returns_the_four_protocols(prec):
+    """evaluate() end to end (two DDIM samplings per window, merge, mask, the four running sums weighted by each batch's kept frames,
+    RUN:562-614) against the oracle's sampler + its restatement of the reference's metric functions: two batches, one with masked frames,
+    through as_reference_tuple() -- the reference's own return shape (e1, e2, e3, ev, N, epoch_time)."""
+    from diff3dhpe_amd.evaluate import evaluate, as_reference_tuple, flip_2d, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
+    from oracle import d3d_oracle as orc
+    from helpers import cfg_small, hashed, torch_sd, build_product
+    cfg = cfg_small(27)
+    _, diff = build_product(cfg, 12, sampling=3, precision=prec)
+    sd, tabs = torch_sd(cfg, 12), orc.diffusion_tables("cosine", 1000)
+    kw = dict(num_timesteps=1000, sampling_timesteps=3, depth=cfg.depth)
+    batches, tot, N = [], [0.0, 0.0, 0.0, 0.0], 0
+    for b, (B, seed) in enumerate(((3, 101), (2, 202))):
+        inp = inputs(B, 27, seed)
+        mask = torch.ones(B, 27, dtype=torch.bool)
+        if b == 0:
+            mask[1, :11] = False
+        nz_f = hashed(f"flipnoise{b}", tuple(inp["noise"].shape), 1)
+        batches.append({"inputs_2d": inp["x2d"], "inputs_3d": inp["gt3d"], "target_mask": mask, "init_noise": inp["noise"], "init_noise_flip": nz_f})
+        p = orc.ddim_sample_loop(sd, tabs, inp["x2d"], inp["noise"], **kw)
+        pf = orc.ddim_sample_loop(sd, tabs, flip_2d(inp["x2d"], H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT), nz_f, **kw)
+        merged = orc.merge_flip_tta(p, pf, 1.3, mask)
+        gtm = inp["gt3d"].view(-1, 17, 3)[mask.view(-1)].unsqueeze(1)
+        n, s1, s2, s3, sv = orc.protocol_sums(merged, gtm)
+        N += n
+        for i, v in enumerate((s1, s2, s3, sv)):
+            tot[i] += v
+    e1, e2, e3, ev, frames, secs = as_reference_tuple(evaluate(diff, batches, scale=1.3, verbose=False))
+    assert frames == N and secs > 0
+    for name, got, want in (("mpjpe", e1, tot[0]), ("p_mpjpe", e2, tot[1]), ("n_mpjpe", e3, tot[2]), ("mpjve", ev, tot[3])):
+        assert abs(got - want / N * 1000) < 0.05, (name, got, want / N * 1000)      # mm at scale 1.3: 1e-4 of the sampler's gate and to spare
+    only1 = evaluate(diff, batches, scale=1.3, verbose=False, all_protocols=False)
+    assert only1["p_mpjpe_mm"] is None and abs(only1["mpjpe_mm"] - e1) < 1e-9
+

@@ -239,3 +239,18 @@ def test_operand_rounding_emulation_is_off_by_default_and_scoped():
     assert torch.equal(a, c)
     d = (a - b).abs().max().item()
     assert 1e-4 < d < 0.2, d
+
+
+def test_pose_metrics_protocols():
+    """evaluate()'s other three protocols (RUN:602-614): the oracle's restatement of LOSS:43-93, 132-142 against values of the reference's own
+    p_mpjpe / n_mpjpe / mean_velocity_error (tests/golden/pose_metrics.npz, oracle/gen_golden.py gen_metrics) -- bit for bit, the nan of a
+    one-frame batch included."""
+    import numpy as np
+    g = gold("pose_metrics")
+    for tag in g["tags"]:
+        pr, tg = torch.from_numpy(g[f"{tag}_pred"]).unsqueeze(1), torch.from_numpy(g[f"{tag}_gt"]).unsqueeze(1)
+        n, s1, s2, s3, sv = orc.protocol_sums(pr, tg)
+        ref = g[f"{tag}_ref"]
+        for got, want in zip((s1 / n, s2 / n, s3 / n, sv / n), ref):
+            assert got == want or (np.isnan(got) and np.isnan(want)), (tag, got, want)
+
