@@ -143,9 +143,22 @@ class EvalData:
     def __len__(self) -> int:
         return sum(len(self._windows(s[1].shape[0])) for s in self.sequences)
 
-    def items(self) -> Iterator[Dict[str, np.ndarray]]:
-        """One evaluation window at a time, in the reference's `pairs` order (LOAD:243-291 __getitem__)."""
+    def action_names(self) -> List[str]:
+        """The keys of the runner's `all_actions` (RUN:669-682): the first word of every action of the loaded subjects, in first-seen order
+        -- what run_evaluation() iterates over ("Walking 1" and "Walking" are one entry, "Walking")."""
+        names: List[str] = []
+        for (subject, action, cam), _, _ in self.sequences:
+            n = action.split(' ')[0]
+            if n not in names:
+                names.append(n)
+        return names
+
+    def items(self, action_filter: Optional[Sequence[str]] = None) -> Iterator[Dict[str, np.ndarray]]:
+        """One evaluation window at a time, in the reference's `pairs` order (LOAD:243-291 __getitem__).  action_filter: only the actions
+        whose name STARTS WITH one of these strings (LOAD:185-193 -- a prefix test, as there: "Sitting" takes "SittingDown" along)."""
         for key, p2, p3 in self.sequences:
+            if action_filter is not None and not any(key[1].startswith(a) for a in action_filter):
+                continue
             for start, unused in self._windows(p2.shape[0]):
                 gt = self._gather(p3, start, False)
                 mask = np.full(self.T, True, dtype=bool)
@@ -154,14 +167,15 @@ class EvalData:
                 yield {"key": key, "inputs_3d": gt, "inputs_3d_norm": gt / self.scale, "inputs_2d": self._gather(p2, start, False),
                        "inputs_2d_flip": self._gather(p2, start, True), "target_mask": mask}
 
-    def batches(self, batch_size: int) -> Iterator[Dict[str, torch.Tensor]]:
-        """DataLoader(shuffle=False) batches (RUN:169-170) as the dicts evaluate() takes."""
+    def batches(self, batch_size: int, action_filter: Optional[Sequence[str]] = None) -> Iterator[Dict[str, torch.Tensor]]:
+        """DataLoader(shuffle=False) batches (RUN:169-170) as the dicts evaluate() takes; action_filter as items() -- run_evaluation()
+        builds one data set per action this way (RUN:730-734)."""
         buf: List[Dict[str, np.ndarray]] = []
 
         def flush():
             return {k: torch.from_numpy(np.stack([b[k] for b in buf])) for k in ("inputs_2d", "inputs_2d_flip", "inputs_3d",
                                                                                   "inputs_3d_norm", "target_mask")}
-        for it in self.items():
+        for it in self.items(action_filter):
             buf.append(it)
             if len(buf) == batch_size:
                 yield flush()

@@ -141,6 +141,43 @@ def as_reference_tuple(result: Dict[str, float]):
 
 
 @torch.no_grad()
+def run_evaluation(model_diffusion, data, *, batch_size: int = 1024, action_filter: Optional[Sequence[str]] = None, verbose: bool = True,
+                   unit_scale: float = 1000.0, **evaluate_kw):
+    """The runner's per-action evaluation loop (RUN:712-766): for every action name of the data set (`data.action_names()`: the first
+    word of the action, RUN:669-682) that starts with one of `action_filter` (None: all) -- one evaluate() over the windows of the
+    actions with that PREFIX (`data.batches(batch_size, action_filter=[name])`, RUN:730-736), then the action-wise averages of the four
+    protocols and the totals.  data: diff3dhpe_amd.data.EvalData (or anything with action_names(), batches(), scale, joints_left /
+    joints_right).  Returns {"actions": {name: (e1, e2, e3, ev, N, seconds)}, the four "*_mm" action-wise means, "frames", "seconds"}."""
+    per = {}
+    for name in data.action_names():
+        if action_filter is not None and not any(name.startswith(a) for a in action_filter):
+            continue
+        r = evaluate(model_diffusion, data.batches(batch_size, action_filter=[name]), scale=data.scale, joints_left=data.joints_left,
+                     joints_right=data.joints_right, verbose=False, unit_scale=unit_scale, **evaluate_kw)
+        per[name] = as_reference_tuple(r)
+        if verbose:
+            print('----' + name + '----')
+            print('Protocol #1 Error (MPJPE):', r["mpjpe_mm"], 'mm')
+            print('Protocol #2 Error (P-MPJPE):', r["p_mpjpe_mm"], 'mm')
+            print('Protocol #3 Error (N-MPJPE):', r["n_mpjpe_mm"], 'mm')
+            print('Velocity Error (MPJVE):', r["mpjve_mm"], 'mm')
+    frames = sum(v[4] for v in per.values())
+    secs = sum(v[5] for v in per.values())
+    mean = lambda i: (sum(v[i] for v in per.values()) / len(per)) if per else float("nan")      # np.mean over the actions (RUN:750-753)
+    out = {"actions": per, "mpjpe_mm": mean(0), "p_mpjpe_mm": mean(1), "n_mpjpe_mm": mean(2), "mpjve_mm": mean(3), "frames": frames,
+           "seconds": secs}
+    if verbose:
+        print('Total eval_frame:', frames)
+        print('Total inference_time:', secs / 60, 'min')
+        print('inference_speed:', frames / max(secs, 1e-9), 'frame/s')
+        print('Protocol #1   (MPJPE) action-wise average:', round(out["mpjpe_mm"], 1), 'mm')
+        print('Protocol #2 (P-MPJPE) action-wise average:', round(out["p_mpjpe_mm"], 1), 'mm')
+        print('Protocol #3 (N-MPJPE) action-wise average:', round(out["n_mpjpe_mm"], 1), 'mm')
+        print('Velocity      (MPJVE) action-wise average:', round(out["mpjve_mm"], 2), 'mm')
+    return out
+
+
+@torch.no_grad()
 def evaluate_sequence(model_diffusion, poses_2d: torch.Tensor, poses_3d: torch.Tensor, *, num_frames: int, scale: float = 1.0,
                       joints_left: Sequence[int] = H36M_JOINTS_LEFT, joints_right: Sequence[int] = H36M_JOINTS_RIGHT,
                       kps_left: Optional[Sequence[int]] = None, kps_right: Optional[Sequence[int]] = None,

@@ -138,3 +138,29 @@ def test_oracle_seq2frame_windows_against_the_reference_generator():
         assert np.array_equal(m.numpy(), g[tag + "/mask"])
         assert np.float64((w.numpy().astype(np.float64) * (np.arange(1, T * 34 + 1).reshape(T, 17, 2) % 97)).sum()) == g[tag + "/win_checksum"]
         assert np.float64((wf.numpy().astype(np.float64) * (np.arange(1, T * 34 + 1).reshape(T, 17, 2) % 89)).sum()) == g[tag + "/flip_checksum"]
+
+
+def test_action_names_and_prefix_filter():
+    """run_evaluation()'s bookkeeping (RUN:669-682, 720-734; LOAD:185-193): the action names are the first words of the loaded subjects'
+    actions in first-seen order; a filter keeps the actions that START WITH the name (the reference's prefix test), in the unfiltered
+    order -- so the per-action data sets partition the windows when no name is a prefix of another, and overlap when one is."""
+    import numpy as np
+    from diff3dhpe_amd.data import EvalData, MocapMeta
+    from diff3dhpe_amd.synth import synth_mocap, SYNTH_JOINTS_LEFT as JL, SYNTH_JOINTS_RIGHT as JR
+    pos, cams, kp, meta = synth_mocap(0)
+    ed = EvalData(MocapMeta(pos, cams, JL, JR), kp, meta["keypoints_symmetry"], ["S9", "S11"], 27)
+    assert ed.action_names() == ["Walk", "Sit", "Eat", "Wait"]
+    everything = list(ed.items())
+    seen = 0
+    for name in ed.action_names():
+        part = list(ed.items(action_filter=[name]))
+        want = [it for it in everything if it["key"][1].startswith(name)]
+        assert len(part) == len(want) > 0
+        for a, b in zip(part, want):
+            assert a["key"] == b["key"] and np.array_equal(a["inputs_2d"], b["inputs_2d"]) and np.array_equal(a["target_mask"], b["target_mask"])
+        seen += len(part)
+    assert seen == len(everything)
+    assert len(list(ed.items(action_filter=["W"]))) == len([it for it in everything if it["key"][1][0] == "W"])      # a prefix of two names: both
+    nb = sum(b["inputs_2d"].shape[0] for b in ed.batches(3, action_filter=["Walk"]))
+    assert nb == len([it for it in everything if it["key"][1].startswith("Walk")])
+

@@ -192,3 +192,32 @@ def test_evaluate_returns_the_four_protocols(prec):
     only1 = evaluate(diff, batches, scale=1.3, verbose=False, all_protocols=False)
     assert only1["p_mpjpe_mm"] is None and abs(only1["mpjpe_mm"] - e1) < 1e-9
 
+
+def test_run_evaluation_action_wise_averages():
+    """run_evaluation() (RUN:712-766): one evaluate() per action name over the actions with that prefix, action-wise means of the four
+    protocols, totals -- against the same evaluate() calls made by hand with the generator in the same state."""
+    from diff3dhpe_amd.data import EvalData, MocapMeta
+    from diff3dhpe_amd.evaluate import evaluate, run_evaluation, as_reference_tuple
+    from diff3dhpe_amd.synth import synth_mocap, SYNTH_JOINTS_LEFT as JL, SYNTH_JOINTS_RIGHT as JR
+    from helpers import cfg_small, build_product
+    pos, cams, kp, meta = synth_mocap(0)
+    ed = EvalData(MocapMeta(pos, cams, JL, JR), kp, meta["keypoints_symmetry"], ["S9", "S11"], 27)
+    _, diff = build_product(cfg_small(27), 31, sampling=2, precision="f16x3")
+    torch.manual_seed(5)
+    torch.cuda.manual_seed(5)
+    res = run_evaluation(diff, ed, batch_size=4, verbose=False)
+    torch.manual_seed(5)
+    torch.cuda.manual_seed(5)
+    by_hand = {}
+    for name in ed.action_names():
+        by_hand[name] = as_reference_tuple(evaluate(diff, ed.batches(4, action_filter=[name]), scale=ed.scale, joints_left=ed.joints_left,
+                                                    joints_right=ed.joints_right, verbose=False))
+    assert list(res["actions"]) == ["Walk", "Sit", "Eat", "Wait"]
+    for name, t in by_hand.items():
+        assert res["actions"][name][:5] == t[:5], name
+    for i, key in enumerate(("mpjpe_mm", "p_mpjpe_mm", "n_mpjpe_mm", "mpjve_mm")):
+        assert abs(res[key] - sum(t[i] for t in by_hand.values()) / 4) < 1e-9
+    assert res["frames"] == sum(t[4] for t in by_hand.values()) == sum(int(it["target_mask"].sum()) for it in ed.items())
+    only = run_evaluation(diff, ed, batch_size=4, action_filter=["Wa"], verbose=False)
+    assert list(only["actions"]) == ["Walk", "Wait"]
+
