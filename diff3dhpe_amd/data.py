@@ -153,9 +153,14 @@ class EvalData:
                 names.append(n)
         return names
 
-    def items(self, action_filter: Optional[Sequence[str]] = None) -> Iterator[Dict[str, np.ndarray]]:
+    def items(self, action_filter: Optional[Sequence[str]] = None, noise_std: float = 0.0,
+              joint_drop_rate: float = 0.0) -> Iterator[Dict[str, np.ndarray]]:
         """One evaluation window at a time, in the reference's `pairs` order (LOAD:243-291 __getitem__).  action_filter: only the actions
-        whose name STARTS WITH one of these strings (LOAD:185-193 -- a prefix test, as there: "Sitting" takes "SittingDown" along)."""
+        whose name STARTS WITH one of these strings (LOAD:185-193 -- a prefix test, as there: "Sitting" takes "SittingDown" along).
+        noise_std / joint_drop_rate: the runner's robustness options (--test_extra_noise_std, --test_joint_drop; LOAD:273-290): Gaussian
+        noise on the 2D window and on its flipped copy, then whole joints of whole frames zeroed with that probability -- drawn from
+        numpy's GLOBAL generator in the loader's order (window noise, flipped-copy noise, window drop mask, flipped-copy drop mask per
+        item), so np.random.seed(s) in front reproduces the reference loader's windows bit for bit (tests/golden/dataset_eval_noisy.npz)."""
         for key, p2, p3 in self.sequences:
             if action_filter is not None and not any(key[1].startswith(a) for a in action_filter):
                 continue
@@ -164,18 +169,26 @@ class EvalData:
                 mask = np.full(self.T, True, dtype=bool)
                 if p2.shape[0] >= self.T:
                     mask[:unused] = False
-                yield {"key": key, "inputs_3d": gt, "inputs_3d_norm": gt / self.scale, "inputs_2d": self._gather(p2, start, False),
-                       "inputs_2d_flip": self._gather(p2, start, True), "target_mask": mask}
+                x2, x2f = self._gather(p2, start, False), self._gather(p2, start, True)
+                if noise_std > 0:
+                    x2 = x2 + np.random.normal(0.0, noise_std, x2.shape).astype('float32')
+                    x2f = x2f + np.random.normal(0.0, noise_std, x2f.shape).astype('float32')
+                if joint_drop_rate > 0:
+                    x2 = x2 * np.repeat(np.random.binomial(1, 1 - joint_drop_rate, (x2.shape[0], x2.shape[1], 1)), x2.shape[2], axis=-1).astype('float32')
+                    x2f = x2f * np.repeat(np.random.binomial(1, 1 - joint_drop_rate, (x2f.shape[0], x2f.shape[1], 1)), x2f.shape[2],
+                                          axis=-1).astype('float32')
+                yield {"key": key, "inputs_3d": gt, "inputs_3d_norm": gt / self.scale, "inputs_2d": x2, "inputs_2d_flip": x2f, "target_mask": mask}
 
-    def batches(self, batch_size: int, action_filter: Optional[Sequence[str]] = None) -> Iterator[Dict[str, torch.Tensor]]:
-        """DataLoader(shuffle=False) batches (RUN:169-170) as the dicts evaluate() takes; action_filter as items() -- run_evaluation()
-        builds one data set per action this way (RUN:730-734)."""
+    def batches(self, batch_size: int, action_filter: Optional[Sequence[str]] = None, noise_std: float = 0.0,
+                joint_drop_rate: float = 0.0) -> Iterator[Dict[str, torch.Tensor]]:
+        """DataLoader(shuffle=False, num_workers=0) batches (RUN:169-170) as the dicts evaluate() takes; action_filter / noise_std /
+        joint_drop_rate as items() -- run_evaluation() builds one data set per action this way (RUN:730-734)."""
         buf: List[Dict[str, np.ndarray]] = []
 
         def flush():
             return {k: torch.from_numpy(np.stack([b[k] for b in buf])) for k in ("inputs_2d", "inputs_2d_flip", "inputs_3d",
                                                                                   "inputs_3d_norm", "target_mask")}
-        for it in self.items(action_filter):
+        for it in self.items(action_filter, noise_std, joint_drop_rate):
             buf.append(it)
             if len(buf) == batch_size:
                 yield flush()

@@ -142,17 +142,18 @@ def as_reference_tuple(result: Dict[str, float]):
 
 @torch.no_grad()
 def run_evaluation(model_diffusion, data, *, batch_size: int = 1024, action_filter: Optional[Sequence[str]] = None, verbose: bool = True,
-                   unit_scale: float = 1000.0, **evaluate_kw):
+                   unit_scale: float = 1000.0, noise_std: float = 0.0, joint_drop_rate: float = 0.0, **evaluate_kw):
     """The runner's per-action evaluation loop (RUN:712-766): for every action name of the data set (`data.action_names()`: the first
     word of the action, RUN:669-682) that starts with one of `action_filter` (None: all) -- one evaluate() over the windows of the
     actions with that PREFIX (`data.batches(batch_size, action_filter=[name])`, RUN:730-736), then the action-wise averages of the four
-    protocols and the totals.  data: diff3dhpe_amd.data.EvalData (or anything with action_names(), batches(), scale, joints_left /
-    joints_right).  Returns {"actions": {name: (e1, e2, e3, ev, N, seconds)}, the four "*_mm" action-wise means, "frames", "seconds"}."""
+    protocols and the totals.  noise_std / joint_drop_rate: the runner's --test_extra_noise_std / --test_joint_drop (RUN:731), handed to the
+    data set.  data: diff3dhpe_amd.data.EvalData (or anything with action_names(), batches(), scale, joints_left / joints_right).  Returns {"actions": {name: (e1, e2, e3, ev, N, seconds)}, the four "*_mm" action-wise means, "frames", "seconds"}."""
     per = {}
     for name in data.action_names():
         if action_filter is not None and not any(name.startswith(a) for a in action_filter):
             continue
-        r = evaluate(model_diffusion, data.batches(batch_size, action_filter=[name]), scale=data.scale, joints_left=data.joints_left,
+        extra = {k: v for k, v in (("noise_std", noise_std), ("joint_drop_rate", joint_drop_rate)) if v}
+        r = evaluate(model_diffusion, data.batches(batch_size, action_filter=[name], **extra), scale=data.scale, joints_left=data.joints_left,
                      joints_right=data.joints_right, verbose=False, unit_scale=unit_scale, **evaluate_kw)
         per[name] = as_reference_tuple(r)
         if verbose:

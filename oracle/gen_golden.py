@@ -436,6 +436,24 @@ def gen_dataset():
                 out[f"T{T}/{nm}_checksum"] = np.float64((arr.astype(np.float64) * wts).sum())
             out[f"T{T}/target_mask"] = tm; out[f"T{T}/scale"] = np.float32(ref.scale)
             print(f"  dataset T={T}: {len(items)} windows, scale {float(ref.scale):.6f}: diff3dhpe_amd.data == reference (bit-equal)")
+            if T == 27:
+                # the runner's robustness options (--test_extra_noise_std / --test_joint_drop, RUN:730-731; LOAD:273-290), and its
+                # per-action data sets (action_filter=[action_key], RUN:730): numpy's global generator seeded in front of the iteration
+                noisy = {}
+                for tag, kw in (("noise", dict(noise_std=0.02)), ("drop", dict(joint_drop_rate=0.15)), ("both_walk", dict(noise_std=0.05, joint_drop_rate=0.1,
+                                                                                                                        action_filter=["Walk"]))):
+                    refn = load_Dataset(opt, ds, root, "test", **kw)
+                    np.random.seed(1234)
+                    its = [refn[i] for i in range(len(refn))]
+                    a2, a2f = np.stack([it[3] for it in its]), np.stack([it[4] for it in its])
+                    np.random.seed(1234)
+                    mine = list(ed.items(action_filter=kw.get("action_filter"), noise_std=kw.get("noise_std", 0.0),
+                                         joint_drop_rate=kw.get("joint_drop_rate", 0.0)))
+                    m2, m2f = np.stack([it["inputs_2d"] for it in mine]), np.stack([it["inputs_2d_flip"] for it in mine])
+                    assert m2.dtype == a2.dtype and np.array_equal(m2, a2) and np.array_equal(m2f, a2f), tag
+                    noisy[f"{tag}/inputs_2d"], noisy[f"{tag}/inputs_2d_flip"] = a2, a2f
+                    print(f"  dataset T=27 {tag}: {len(its)} windows, diff3dhpe_amd.data == reference (bit-equal, seed 1234)")
+                save("dataset_eval_noisy", seed=np.int32(1234), **noisy)
     save("dataset_eval", **out)
 
 

@@ -164,3 +164,24 @@ def test_action_names_and_prefix_filter():
     nb = sum(b["inputs_2d"].shape[0] for b in ed.batches(3, action_filter=["Walk"]))
     assert nb == len([it for it in everything if it["key"][1].startswith("Walk")])
 
+
+def test_noisy_and_dropped_windows_equal_the_reference_loader():
+    """The runner's robustness options (--test_extra_noise_std, --test_joint_drop; RUN:730-731, LOAD:273-290) and its per-action data sets:
+    with numpy's global generator seeded as in oracle/gen_golden.py gen_dataset, EvalData.items(noise_std=, joint_drop_rate=,
+    action_filter=) hands out the windows of the reference's load_Dataset(..., noise_std=, joint_drop_rate=, action_filter=) bit for bit."""
+    g = gold("dataset_eval_noisy")
+    ed = _data(27)
+    for tag, kw in (("noise", dict(noise_std=0.02)), ("drop", dict(joint_drop_rate=0.15)),
+                    ("both_walk", dict(noise_std=0.05, joint_drop_rate=0.1, action_filter=["Walk"]))):
+        np.random.seed(int(g["seed"]))
+        items = list(ed.items(**kw))
+        for nm in ("inputs_2d", "inputs_2d_flip"):
+            arr = np.stack([it[nm] for it in items])
+            assert arr.dtype == np.float32 and np.array_equal(arr, g[f"{tag}/{nm}"]), (tag, nm)
+    clean = np.stack([it["inputs_2d"] for it in ed.items()])
+    assert (g["drop/inputs_2d"] == 0).any() and not np.array_equal(clean, g["noise/inputs_2d"])
+    np.random.seed(7)
+    b = next(iter(ed.batches(4, noise_std=0.02)))
+    np.random.seed(7)
+    assert torch.equal(b["inputs_2d"], torch.from_numpy(np.stack([it["inputs_2d"] for it in list(ed.items(noise_std=0.02))[:4]])))
+
