@@ -301,9 +301,20 @@ class EvalData3DHP:
     def __len__(self) -> int:
         return self.num_items()
 
-    def items(self, seq_filter: Optional[str] = None) -> Iterator[Dict[str, np.ndarray]]:
+    def _perturb(self, w2: np.ndarray, w2f: np.ndarray, noise_std: float, joint_drop_rate: float):
+        """--test_extra_noise_std / --test_joint_drop (LOAD:422-440; run_..._3dhp.py:598-600): numpy's GLOBAL generator, in the loader's draw
+        order -- window noise, flipped-copy noise, window drop mask, flipped-copy drop mask."""
+        if noise_std > 0:
+            w2 = w2 + np.random.normal(0.0, noise_std, w2.shape).astype('float32')
+            w2f = w2f + np.random.normal(0.0, noise_std, w2f.shape).astype('float32')
+        if joint_drop_rate > 0:
+            w2 = w2 * np.repeat(np.random.binomial(1, 1 - joint_drop_rate, (w2.shape[0], w2.shape[1], 1)), w2.shape[2], axis=-1).astype('float32')
+            w2f = w2f * np.repeat(np.random.binomial(1, 1 - joint_drop_rate, (w2f.shape[0], w2f.shape[1], 1)), w2f.shape[2], axis=-1).astype('float32')
+        return w2, w2f
+
+    def items(self, seq_filter: Optional[str] = None, noise_std: float = 0.0, joint_drop_rate: float = 0.0) -> Iterator[Dict[str, np.ndarray]]:
         """One evaluation item at a time in the reference's `pairs` order (LOAD:388-441 __getitem__); seq_filter = the per-sequence data
-        sets run_evaluation() builds (run_..._3dhp.py:596-604)."""
+        sets run_evaluation() builds (run_..._3dhp.py:596-604); noise_std / joint_drop_rate: its robustness options (_perturb)."""
         T = self.T
         for name, p2, p3, valid in self.sequences:
             if seq_filter is not None and name != seq_filter:
@@ -320,24 +331,27 @@ class EvalData3DHP:
                     mask &= valid[idx]
                     w2 = p2[idx]
                     gt = p3[idx].copy()
-                    yield {"key": name, "inputs_3d": gt, "inputs_3d_norm": gt / np.float32(self.scale), "inputs_2d": w2.copy(),
-                           "inputs_2d_flip": self._flip2d(w2), "target_mask": mask}
+                    a, af = self._perturb(w2.copy(), self._flip2d(w2), noise_std, joint_drop_rate)
+                    yield {"key": name, "inputs_3d": gt, "inputs_3d_norm": gt / np.float32(self.scale), "inputs_2d": a,
+                           "inputs_2d_flip": af, "target_mask": mask}
             else:
                 for f in range(n):
                     idx = np.clip(np.arange(f - self.pad, f + self.pad + 1), 0, n - 1)
                     w2 = p2[idx]
                     gt = p3[f:f + 1].copy()
-                    yield {"key": name, "inputs_3d": gt, "inputs_3d_norm": gt / np.float32(self.scale), "inputs_2d": w2.copy(),
-                           "inputs_2d_flip": self._flip2d(w2), "target_mask": valid[f:f + 1].copy()}
+                    a, af = self._perturb(w2.copy(), self._flip2d(w2), noise_std, joint_drop_rate)
+                    yield {"key": name, "inputs_3d": gt, "inputs_3d_norm": gt / np.float32(self.scale), "inputs_2d": a,
+                           "inputs_2d_flip": af, "target_mask": valid[f:f + 1].copy()}
 
-    def batches(self, batch_size: int, seq_filter: Optional[str] = None) -> Iterator[Dict[str, torch.Tensor]]:
-        """DataLoader(shuffle=False, drop_last=False) batches (run_..._3dhp.py:601-603) as the dicts evaluate() takes."""
+    def batches(self, batch_size: int, seq_filter: Optional[str] = None, noise_std: float = 0.0,
+                joint_drop_rate: float = 0.0) -> Iterator[Dict[str, torch.Tensor]]:
+        """DataLoader(shuffle=False, drop_last=False, num_workers=0) batches (run_..._3dhp.py:601-603) as the dicts evaluate() takes."""
         buf: List[Dict[str, np.ndarray]] = []
 
         def flush():
             return {k: torch.from_numpy(np.stack([b[k] for b in buf])) for k in ("inputs_2d", "inputs_2d_flip", "inputs_3d",
                                                                                   "inputs_3d_norm", "target_mask")}
-        for it in self.items(seq_filter):
+        for it in self.items(seq_filter, noise_std, joint_drop_rate):
             buf.append(it)
             if len(buf) == batch_size:
                 yield flush()

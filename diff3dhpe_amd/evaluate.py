@@ -34,7 +34,7 @@ def flip_2d(x2d: torch.Tensor, joints_left: Sequence[int], joints_right: Sequenc
 def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, scale: float = 1.0,
              joints_left: Sequence[int] = H36M_JOINTS_LEFT, joints_right: Sequence[int] = H36M_JOINTS_RIGHT,
              test_time_augmentation: bool = True, device: Optional[torch.device] = None, verbose: bool = True,
-             output_loss: bool = False, unit_scale: float = 1000.0, all_protocols: bool = True):
+             output_loss: bool = False, unit_scale: float = 1000.0, all_protocols: bool = True, collect_predictions: bool = False):
     """batches yield dicts with inputs_2d (B,T,J,2), inputs_3d (B,T',J,3) [ground truth in the data set's unit; T' = T, or 1 for a
     seq2frame model], optional inputs_2d_flip, target_mask (B,T') bool, init_noise / init_noise_flip (B,T',J,3), inputs_3d_norm.
     output_loss=True is the 3DHP runner's call shape (run_..._3dhp.py:517-520 leaves forward()'s default): every sampling is preceded
@@ -43,13 +43,16 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
     ground truth in metres -> mm; 1: 3DHP ground truth already in mm).  all_protocols (default, as the reference): besides Protocol #1
     the batch's merged prediction goes through d3d_pose_metrics for P-MPJPE, N-MPJPE and MPJVE, each weighted by the batch's kept frames
     (RUN:602-614) -- False keeps the MPJPE-only tail (one kernel, no merged tensor).  Returns a dict with the four errors, frames,
-    seconds; as_reference_tuple(result) is evaluate()'s own return value (e1, e2, e3, ev, N, epoch_time)."""
+    seconds; as_reference_tuple(result) is evaluate()'s own return value (e1, e2, e3, ev, N, epoch_time).  collect_predictions: the
+    merged, de-normalised predictions of the kept frames, batch after batch, come back as result["predictions"] ((N, J, 3) CPU tensor) --
+    what the 3DHP runner stores per test sequence for its inference_data.mat (run_..._3dhp.py:542-547)."""
     model_diffusion.eval()
     dev = device or torch.device("cuda", torch.cuda.current_device())
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     tot_err, tot_cnt, secs, frames = 0.0, 0, 0.0, 0
     tot_p, tot_n, tot_v = 0.0, 0.0, 0.0            # running sums of (kept frames of the batch) x (the batch's protocol value), RUN:603-614
+    kept_preds = []
     for batch in batches:
         x2d = batch["inputs_2d"]
         gt = batch["inputs_3d"]
@@ -92,11 +95,15 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
                     pred = parallel.all_gather_pred(pred, B)
                 gsl = slice(0, B)
             gtd, md = gt[gsl].to(dev), (None if mask is None else mask[gsl].to(dev))
-            if not all_protocols:
-                return tta_mpjpe(pred, pred_f, gtd, md, scale, list(joints_left), list(joints_right)) + (None,)   # (reads the two sums
-                # back: the batch's one synchronisation)
+            if not all_protocols and not collect_predictions:
+                return tta_mpjpe(pred, pred_f, gtd, md, scale, list(joints_left), list(joints_right)) + (None, None)   # (reads the two
+                # sums back: the batch's one synchronisation)
             err_, cnt_, merged = tta_mpjpe(pred, pred_f, gtd, md, scale, list(joints_left), list(joints_right), want_merged=True)
-            return err_, cnt_, pose_metrics(merged, gtd, md)
+            kept_p = None
+            if collect_predictions:
+                flat = merged.reshape(-1, merged.shape[-2], 3)
+                kept_p = (flat if md is None else flat[md.reshape(-1).bool()]).cpu()
+            return err_, cnt_, (pose_metrics(merged, gtd, md) if all_protocols else None), kept_p
 
         net = getattr(getattr(model_diffusion, "module", model_diffusion), "model", None)
         if world == 1 and hasattr(net, "deferred_range_checks"):
@@ -104,12 +111,14 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
             # own); a flagged batch is repeated on the model's exact-fp32 engine (precision "auto") or raises D3DError ("f16x3")
             rng = torch.cuda.get_rng_state(dev)          # (a repeated batch draws the same noise: the reference's generator sequence)
             with net.deferred_range_checks() as pending:
-                err, cnt, extra = run_batch()
+                err, cnt, extra, kept_p = run_batch()
             if pending.resolve():
                 torch.cuda.set_rng_state(rng, dev)
-                err, cnt, extra = run_batch()
+                err, cnt, extra, kept_p = run_batch()
         else:   # several ranks: a rank must know its own flags BEFORE its shard enters the all-gather -- each sampling waits on its ticket
-            err, cnt, extra = run_batch()
+            err, cnt, extra, kept_p = run_batch()
+        if kept_p is not None:
+            kept_preds.append(kept_p)
         torch.cuda.synchronize(dev)
         secs += time.time() - t0
         tot_err += err
@@ -132,7 +141,10 @@ def evaluate(model_diffusion, batches: Iterable[Dict[str, torch.Tensor]], *, sca
             print('Protocol #2 Error (P-MPJPE):', e2, 'mm')
             print('Protocol #3 Error (N-MPJPE):', e3, 'mm')
             print('Velocity Error (MPJVE):', ev_, 'mm')
-    return {"mpjpe_mm": e1, "p_mpjpe_mm": e2, "n_mpjpe_mm": e3, "mpjve_mm": ev_, "frames": frames, "seconds": secs}
+    out = {"mpjpe_mm": e1, "p_mpjpe_mm": e2, "n_mpjpe_mm": e3, "mpjve_mm": ev_, "frames": frames, "seconds": secs}
+    if collect_predictions:
+        out["predictions"] = torch.cat(kept_preds) if kept_preds else torch.empty(0)
+    return out
 
 
 def as_reference_tuple(result: Dict[str, float]):
@@ -175,6 +187,40 @@ def run_evaluation(model_diffusion, data, *, batch_size: int = 1024, action_filt
         print('Protocol #2 (P-MPJPE) action-wise average:', round(out["p_mpjpe_mm"], 1), 'mm')
         print('Protocol #3 (N-MPJPE) action-wise average:', round(out["n_mpjpe_mm"], 1), 'mm')
         print('Velocity      (MPJVE) action-wise average:', round(out["mpjve_mm"], 2), 'mm')
+    return out
+
+
+@torch.no_grad()
+def run_evaluation_3dhp(model_diffusion, data, *, batch_size: int = 1024, subjects_test: Optional[Sequence[str]] = None, verbose: bool = True,
+                        noise_std: float = 0.0, joint_drop_rate: float = 0.0, output_loss: bool = True, mat_path: Optional[str] = None,
+                        **evaluate_kw):
+    """The 3DHP runner's evaluation loop (run_..._3dhp.py:593-632): one evaluate() per test sequence (`data.batches(batch_size,
+    seq_filter=name)`, :596-604; output_loss=True is forward()'s default, which that runner leaves; errors in the data set's own mm), the
+    sequence-wise averages of the four protocols, and the stored predictions -- data_inference[name] = the kept frames' merged predictions
+    as a (3, J, N) array (:542-547), written to `mat_path` (inference_data.mat, :631-632: the input of the data set's PCK / AUC scripts)
+    when one is given.  data: diff3dhpe_amd.data.EvalData3DHP.  Returns {"sequences": {name: (e1, e2, e3, ev, N, seconds)}, the four
+    "*_mm" means, "data_inference": {name: ndarray}}."""
+    names = list(subjects_test) if subjects_test is not None else [s[0] for s in data.sequences]
+    per, inf = {}, {}
+    extra = {k: v for k, v in (("noise_std", noise_std), ("joint_drop_rate", joint_drop_rate)) if v}
+    for name in names:
+        r = evaluate(model_diffusion, data.batches(batch_size, seq_filter=name, **extra), scale=data.scale, joints_left=data.joints_left,
+                     joints_right=data.joints_right, verbose=False, unit_scale=1.0, output_loss=output_loss, collect_predictions=True,
+                     **evaluate_kw)
+        per[name] = as_reference_tuple(r)
+        inf[name] = r["predictions"].permute(2, 1, 0).numpy()
+        if verbose:
+            print('----' + name + '----')
+    mean = lambda i: (sum(v[i] for v in per.values()) / len(per)) if per else float("nan")
+    out = {"sequences": per, "mpjpe_mm": mean(0), "p_mpjpe_mm": mean(1), "n_mpjpe_mm": mean(2), "mpjve_mm": mean(3), "data_inference": inf}
+    if verbose:
+        print('Protocol #1   (MPJPE) action-wise average:', round(out["mpjpe_mm"], 1), 'mm')
+        print('Protocol #2 (P-MPJPE) action-wise average:', round(out["p_mpjpe_mm"], 1), 'mm')
+        print('Protocol #3 (N-MPJPE) action-wise average:', round(out["n_mpjpe_mm"], 1), 'mm')
+        print('Velocity      (MPJVE) action-wise average:', round(out["mpjve_mm"], 2), 'mm')
+    if mat_path is not None:
+        import scipy.io as scio
+        scio.savemat(mat_path, inf)
     return out
 
 

@@ -735,6 +735,44 @@ def gen_round5b():
         save("evaluate_3dhp_s2s", seed=np.int32(12), S=np.int32(S), batch_size=np.int32(2), scale=np.float32(refq.scale), **out)
 
 
+def gen_3dhp_noisy():
+    """The 3DHP runner's robustness options (--test_extra_noise_std / --test_joint_drop, run_..._3dhp.py:598-600; LOAD:422-440) through the
+    reference's load_Dataset_3dhp on the synthetic 3DHP-shaped files, numpy's global generator seeded in front of the iteration: both
+    window tables, with a per-sequence data set (seq_filter) for one of them."""
+    import tempfile
+    from types import SimpleNamespace
+    from common.mpiinf3dhp_dataset import MPIINF3DHPDataset
+    from data.load_noisy_data import load_Dataset_3dhp
+    from diff3dhpe_amd.synth import write_synth_3dhp
+    from diff3dhpe_amd.data import EvalData3DHP
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        test, train = write_synth_3dhp(root, seed=0)
+        for oa, T, kw in ((False, 27, dict(noise_std=0.03, joint_drop_rate=0.1)), (True, 27, dict(noise_std=0.02)),
+                          (False, 9, dict(joint_drop_rate=0.2, seq_filter="TS5"))):
+            opt = SimpleNamespace(dataset="3dhp", keypoints="gt", subjects_train="S1,S2", subjects_test="TS1,TS5", actions="*", downsample=1,
+                                  subset=1, stride=(T if oa else 1), test_time_augmentation=True, number_of_frames=T, out_all=oa,
+                                  batch_size=4, data_augmentation=False)
+            ds = MPIINF3DHPDataset(opt, root_path=root)
+            ref = load_Dataset_3dhp(opt, ds._test, pos_3d_min=ds._pos_3d_min, pos_3d_max=ds._pos_3d_max, split="test", **kw)
+            np.random.seed(4321)
+            its = [ref[i] for i in range(len(ref))]
+            a2, a2f = np.stack([it[3] for it in its]), np.stack([it[4] for it in its])
+            ed = EvalData3DHP(test, ["TS1", "TS5"], T, out_all=oa, train_data=train)
+            np.random.seed(4321)
+            mine = list(ed.items(seq_filter=kw.get("seq_filter"), noise_std=kw.get("noise_std", 0.0), joint_drop_rate=kw.get("joint_drop_rate", 0.0)))
+            m2, m2f = np.stack([it["inputs_2d"] for it in mine]), np.stack([it["inputs_2d_flip"] for it in mine])
+            tag = f"{'s2s' if oa else 's2f'}_T{T}"
+            assert m2.dtype == a2.dtype and np.array_equal(m2, a2) and np.array_equal(m2f, a2f), tag
+            wts = np.arange(1, a2.size + 1, dtype=np.float64).reshape(a2.shape) % 9973.0
+            out[tag + "/inputs_2d_checksum"] = np.float64((a2.astype(np.float64) * wts).sum())
+            out[tag + "/inputs_2d_flip_checksum"] = np.float64((a2f.astype(np.float64) * wts).sum())
+            out[tag + "/first"] = a2[:3]
+            out[tag + "/zeros"] = np.int64((a2 == 0).sum())
+            print(f"  3dhp noisy {tag} {kw}: {len(its)} items, diff3dhpe_amd.data.EvalData3DHP == reference (bit-equal, seed 4321)")
+    save("dataset_3dhp_eval_noisy", seed=np.int32(4321), **out)
+
+
 def gen_metrics():
     """evaluate()'s other three protocols (RUN:602-614): the REAL common.loss.p_mpjpe / n_mpjpe / mean_velocity_error on merged, masked
     batches as evaluate() hands them over -- (N, 1, J, 3) torch tensors for n_mpjpe, (N, J, 3) float32 numpy arrays for the other two.
@@ -781,7 +819,7 @@ def gen_metrics():
 GENERATORS = {
     "schedules": gen_schedules, "ddim_times": gen_ddim_times, "temb": gen_temb, "attention": gen_attention, "blocks": gen_blocks,
     "denoise": gen_denoise, "ddim": gen_ddim, "repeat_eta": gen_repeat_eta, "plosses": gen_plosses, "evalmath": gen_evalmath, "chunks": gen_chunks,
-    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5, "round5b": gen_round5b, "round6": gen_round6, "metrics": gen_metrics,
+    "dataset": gen_dataset, "trainedlike": gen_trainedlike, "round4": gen_round4, "round5": gen_round5, "round5b": gen_round5b, "round6": gen_round6, "metrics": gen_metrics, "3dhp_noisy": gen_3dhp_noisy,
 }
 
 if __name__ == "__main__":

@@ -185,3 +185,25 @@ def test_noisy_and_dropped_windows_equal_the_reference_loader():
     np.random.seed(7)
     assert torch.equal(b["inputs_2d"], torch.from_numpy(np.stack([it["inputs_2d"] for it in list(ed.items(noise_std=0.02))[:4]])))
 
+
+def test_3dhp_noisy_and_dropped_items_equal_the_reference_loader():
+    """The 3DHP runner's --test_extra_noise_std / --test_joint_drop (run_..._3dhp.py:598-600; LOAD:422-440) for both window tables and a
+    per-sequence data set: EvalData3DHP.items(noise_std=, joint_drop_rate=, seq_filter=) under the seeded global numpy generator equals
+    load_Dataset_3dhp(...) of the reference bit for bit (checksums + the first items of tests/golden/dataset_3dhp_eval_noisy.npz)."""
+    from diff3dhpe_amd.data import EvalData3DHP
+    from diff3dhpe_amd.synth import synth_mocap_3dhp
+    g = gold("dataset_3dhp_eval_noisy")
+    test, train = synth_mocap_3dhp(0)
+    for oa, T, kw in ((False, 27, dict(noise_std=0.03, joint_drop_rate=0.1)), (True, 27, dict(noise_std=0.02)),
+                      (False, 9, dict(joint_drop_rate=0.2, seq_filter="TS5"))):
+        ed = EvalData3DHP(test, ["TS1", "TS5"], T, out_all=oa, train_data=train)
+        np.random.seed(int(g["seed"]))
+        items = list(ed.items(**kw))
+        tag = f"{'s2s' if oa else 's2f'}_T{T}"
+        a2, a2f = np.stack([it["inputs_2d"] for it in items]), np.stack([it["inputs_2d_flip"] for it in items])
+        assert a2.dtype == np.float32 and np.array_equal(a2[:3], g[tag + "/first"])
+        wts = np.arange(1, a2.size + 1, dtype=np.float64).reshape(a2.shape) % 9973.0
+        assert np.float64((a2.astype(np.float64) * wts).sum()) == g[tag + "/inputs_2d_checksum"], tag
+        assert np.float64((a2f.astype(np.float64) * wts).sum()) == g[tag + "/inputs_2d_flip_checksum"], tag
+        assert int((a2 == 0).sum()) == int(g[tag + "/zeros"])
+

@@ -221,3 +221,36 @@ def test_run_evaluation_action_wise_averages():
     only = run_evaluation(diff, ed, batch_size=4, action_filter=["Wa"], verbose=False)
     assert list(only["actions"]) == ["Walk", "Wait"]
 
+
+def test_run_evaluation_3dhp_per_sequence_and_stored_predictions(tmp_path):
+    """run_evaluation_3dhp() (run_..._3dhp.py:593-632) with a seq2frame model on the synthetic 3DHP-shaped data set: one evaluate() per test
+    sequence with forward()'s default output_loss, sequence-wise averages of the four protocols, and data_inference[seq] = the kept frames'
+    merged predictions as (3, J, N) -- equal to what evaluate() computes by hand with the generator in the same state; inference_data.mat
+    readable by scipy."""
+    import numpy as np
+    import scipy.io as scio
+    from diff3dhpe_amd.data import EvalData3DHP
+    from diff3dhpe_amd.evaluate import evaluate, run_evaluation_3dhp, as_reference_tuple
+    from diff3dhpe_amd.synth import synth_mocap_3dhp
+    from helpers import cfg_small
+    test, train = synth_mocap_3dhp(0)
+    ed = EvalData3DHP(test, ["TS1", "TS5"], 27, out_all=False, train_data=train)
+    _, diff = _product(cfg_small(27, seq2frame=True, with_time_emb=False), 9, "f16x3", sampling=2)
+    mat = str(tmp_path / "inference_data.mat")
+    torch.manual_seed(11)
+    torch.cuda.manual_seed(11)
+    res = run_evaluation_3dhp(diff, ed, batch_size=32, verbose=False, mat_path=mat)
+    torch.manual_seed(11)
+    torch.cuda.manual_seed(11)
+    for name in ("TS1", "TS5"):
+        r = evaluate(diff, ed.batches(32, seq_filter=name), scale=ed.scale, joints_left=ed.joints_left, joints_right=ed.joints_right,
+                     verbose=False, unit_scale=1.0, output_loss=True, collect_predictions=True)
+        assert res["sequences"][name][:5] == as_reference_tuple(r)[:5]
+        valid = int(sum(int(it["target_mask"].sum()) for it in ed.items(seq_filter=name)))
+        assert res["data_inference"][name].shape == (3, 17, valid) == tuple(r["predictions"].permute(2, 1, 0).shape)
+        assert np.array_equal(res["data_inference"][name], r["predictions"].permute(2, 1, 0).numpy())
+    for i, key in enumerate(("mpjpe_mm", "p_mpjpe_mm", "n_mpjpe_mm", "mpjve_mm")):
+        assert abs(res[key] - (res["sequences"]["TS1"][i] + res["sequences"]["TS5"][i]) / 2) < 1e-9 and np.isfinite(res[key])
+    m = scio.loadmat(mat)
+    assert np.array_equal(m["TS1"], res["data_inference"]["TS1"]) and m["TS5"].shape[:2] == (3, 17)
+
