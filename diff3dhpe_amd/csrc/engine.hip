@@ -776,7 +776,7 @@ unsigned* d3d::range_sink_word() {
 extern "C" {
 
 const char* d3d_last_error(void) { return g_err.c_str(); }
-int d3d_version(void) { return 130; }
+int d3d_version(void) { return 131; }   // 131: d3d_pose_metrics
 
 int d3d_ddim_times(int32_t num_timesteps, int32_t sampling_timesteps, int32_t* out) {
   // torch.linspace(-1, N-1, S+1) in fp32 (two-sided evaluation around the midpoint), .int() truncation, reversed
